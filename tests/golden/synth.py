@@ -1,0 +1,71 @@
+"""Closed-form synthetic weights and inputs shared by the golden generator and the tests.
+
+No weight blob is shipped: every parameter is a deterministic function of its NAME and
+SHAPE (numpy RandomState = frozen legacy stream, bit-stable across numpy versions and
+hosts), scaled so activations stay O(1) through a 100-layer network.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def _rs(name: str, salt: int = 0) -> np.random.RandomState:
+    return np.random.RandomState((zlib.crc32(name.encode()) + salt) % (2 ** 31))
+
+
+def synth_tensor(name: str, shape, dtype=torch.float32) -> torch.Tensor:
+    shape = tuple(int(s) for s in shape)
+    rs = _rs(name)
+    leaf = name.split(".")[-1]
+    n = int(np.prod(shape)) if shape else 1
+
+    def randn():
+        return rs.standard_normal(n).reshape(shape)
+
+    if leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.long)
+    if leaf == "running_mean":
+        v = 0.1 * randn()
+    elif leaf == "running_var":
+        v = 1.0 + 0.2 * np.abs(randn())
+    elif leaf == "A_logs":
+        v = np.log(0.5 + 1.5 * rs.random_sample(n).reshape(shape))  # A in [-2, -0.5]
+    elif leaf == "Ds":
+        v = 1.0 + 0.1 * randn()
+    elif leaf == "dt_projs_bias":
+        dt = np.exp(rs.random_sample(n).reshape(shape) * (np.log(0.1) - np.log(1e-3)) + np.log(1e-3))
+        v = dt + np.log(-np.expm1(-dt))  # inverse softplus, like mamba_init.py:20-24
+    elif leaf == "dt_projs_weight":
+        v = randn() * (shape[-1] ** -0.5)
+    elif leaf == "x_proj_weight":
+        v = randn() * (shape[-1] ** -0.5)
+    elif leaf == "bias":
+        v = 0.02 * randn()
+    elif leaf == "weight" and len(shape) == 1:  # LayerNorm / BatchNorm scale
+        v = 1.0 + 0.1 * randn()
+    elif leaf == "weight":
+        fan_in = int(np.prod(shape[1:]))
+        v = randn() * (fan_in ** -0.5)
+    else:
+        v = 0.1 * randn()
+    return torch.from_numpy(np.asarray(v)).to(dtype)
+
+
+def synth_state_dict(manifest, keep=(), dtype=torch.float32):
+    """manifest: iterable of (name, shape).  Names containing any of ``keep`` are skipped
+    (e.g. the DCT buffers, which are constants of the architecture)."""
+    out = {}
+    for name, shape in manifest:
+        if any(k in name for k in keep):
+            continue
+        out[name] = synth_tensor(name, shape, dtype)
+    return out
+
+
+def synth_input(tag: str, shape, scale=1.0) -> torch.Tensor:
+    rs = _rs("input:" + tag)
+    return torch.from_numpy(rs.standard_normal(int(np.prod(shape))).reshape(shape) * scale).float()
+
+
+DCT_KEYS = ("DCT2D.dct_x.weight", "DCT2D.dct_y.weight")
