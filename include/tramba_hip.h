@@ -1,0 +1,155 @@
+/* tramba_hip.h -- C ABI of libtramba_hip.so: the MI355X (gfx950) hot path of Tramba.
+ *
+ * Plain pointers and sizes only (no torch types).  Every device pointer is a HIP device
+ * pointer owned by the caller; nothing is retained after the call; every launch goes onto
+ * the caller's `stream` (a hipStream_t passed as void*), with no implicit synchronisation,
+ * no allocation and no host<->device copy inside the call (graph-capture safe).
+ * Return value: 0 on success, <0 on a rejected argument (see tramba_last_error()); the
+ * library never aborts the process.
+ *
+ * Reference interface each entry replaces (paths relative to the mj129/Tramba tree):
+ *   tramba_selective_scan_fwd   selective_scan_cuda_oflex.fwd   Models/SS2D/csms6s.py:910
+ *   tramba_selective_scan_bwd   selective_scan_cuda_oflex.bwd   Models/SS2D/csms6s.py:920-922
+ *   tramba_scan_table           generate_indices / generate_window_indices /
+ *                               generate_dilation_indices       SpiralLine.py:27-82, Window.py:3-35,
+ *                                                               Dilation.py:3-45 (+ csms6s.py:18-22)
+ *   tramba_cross_scan           CrossScan*.forward (= CrossMerge*.backward)
+ *                                                               csms6s.py:13-22,64-72,113-121,161-172
+ *   tramba_cross_merge          CrossMerge*.forward (= CrossScan*.backward)
+ *                                                               csms6s.py:34-42,83-91,132-140,188-201
+ *   tramba_ss2d_scan_cl /       SS2Dv2.forward_corev2 (scan -> x_proj split -> dt_proj ->
+ *   tramba_ss2d_merge_norm_cl   selective scan -> merge -> out_norm) vmamba.py:230-273,
+ *                               fused, channels-last
+ *   tramba_layernorm_cl         LayerNorm2d.forward             Models/modules.py:22-27
+ *   tramba_shuffle_norm_cl      rearrange(...)+norm in PatchExpand / FinalPatchExpand_X4 /
+ *                               FreqExpand2D                    Models/modules.py:209-218,240-249,687-696
+ *   tramba_dwconv_cl            SS2D.conv2d (+SiLU)             Models/vmamba.py:283-285
+ *   tramba_dwms_cl              DWMSMlp: h+dw3+dw5+dw7 -> GELU  Models/vmamba.py:624-625
+ *   tramba_dct_split_cl         DCT2D.forward                   Models/DCT_2D.py:12-29
+ *   tramba_linear_cl            Linear2d.forward (1x1 conv)     Models/modules.py:10-13
+ *
+ * "_cl" = channels-last: activations are (B, H*W, C) row-major, C contiguous.
+ */
+#ifndef TRAMBA_HIP_H
+#define TRAMBA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { TRAMBA_F32 = 0, TRAMBA_F16 = 1, TRAMBA_BF16 = 2 } tramba_dtype;
+
+typedef enum {
+    TRAMBA_SCAN_RASTER = 0,   /* K=4 */
+    TRAMBA_SCAN_LINE = 1,     /* K=4, the Bresenham half of Helix */
+    TRAMBA_SCAN_HELIX = 2,    /* K=8 = raster + line */
+    TRAMBA_SCAN_WINDOW = 3,   /* K=4, param = window size (0 = default rule) */
+    TRAMBA_SCAN_DILATION = 4  /* K=4, param = dilation rate (0 = 4) */
+} tramba_scan_family;
+
+typedef enum { TRAMBA_ACT_NONE = 0, TRAMBA_ACT_SILU = 1, TRAMBA_ACT_GELU = 2 } tramba_act;
+
+#define TRAMBA_OK 0
+#define TRAMBA_ERR_ARG (-1)
+#define TRAMBA_ERR_UNSUPPORTED (-2)
+#define TRAMBA_ERR_HIP (-3)
+
+/* ------------------------------------------------------------------ library */
+const char *tramba_last_error(void);      /* thread-local message of the last failure */
+int tramba_abi_version(void);
+/* HIP-event timing of the kernels launched by this library (used by bench.py for the
+ * roofline figure).  enable=1 brackets every launch of kernel class `which` with events on
+ * the launch stream; tramba_profile_read() synchronises those events and returns the
+ * number of launches, writing the summed duration in milliseconds. */
+int tramba_profile_enable(int which, int enable);
+int tramba_profile_read(int which, double *total_ms, double *total_units);
+#define TRAMBA_PROF_SCAN_BOUNDARY 0
+#define TRAMBA_PROF_SCAN_FUSED 1
+#define TRAMBA_PROF_COUNT 2
+
+/* ------------------------------------------------------------------ scan-order tables (host) */
+/* Number of directions K of a family. */
+int tramba_scan_family_k(int family);
+/* Default window size this library uses for feature size h (reference values for
+ * 12/24/48/96, csms6s.py:107-108; documented rule otherwise). */
+int tramba_default_window(int h);
+/* Fills out[K*h*w] (HOST memory) with the flat pixel index (row*w+col) read at each
+ * sequence position of each direction.  Returns K, or <0. */
+int tramba_scan_table(int family, int h, int w, int param, int32_t *out);
+/* Inverse (CSR) of a table for the deterministic merge: for pixel p,
+ * entries inv_idx[inv_ptr[p] .. inv_ptr[p+1]) hold k*L+l with table[k][l]==p, ascending.
+ * inv_ptr has L+1 entries, inv_idx has K*L.  HOST memory. */
+int tramba_scan_table_inverse(const int32_t *table, int k, int l, int32_t *inv_ptr, int32_t *inv_idx);
+
+/* ------------------------------------------------------------------ L0: selective scan, reference layout */
+/* u, delta: (B, KD, L) io_dtype;  A: (KD, N) f32;  Bm, Cm: (B, K, N, L) io_dtype;
+ * D, delta_bias: (KD) f32 or NULL;  out: (B, KD, L) out_dtype (f32 = "oflex");
+ * ckpt: (B, KD, nchunk, N) f32 chunk-end states for the backward, or NULL;
+ * nchunk = tramba_selective_scan_nchunk(L, io_dtype). */
+int tramba_selective_scan_nchunk(int l, int io_dtype);
+int tramba_selective_scan_fwd(const void *u, const void *delta, const float *A, const void *Bm,
+                              const void *Cm, const float *D, const float *delta_bias, void *out,
+                              float *ckpt, int batch, int kd, int k, int n, int l, int io_dtype,
+                              int out_dtype, int delta_softplus, void *stream);
+/* du, ddelta: (B, KD, L) io_dtype; dA (KD,N), dD, ddelta_bias (KD): f32, ACCUMULATED into
+ * (caller zeroes);  dB, dC: (B, K, N, L) f32, accumulated into (caller zeroes). */
+int tramba_selective_scan_bwd(const void *u, const void *delta, const float *A, const void *Bm,
+                              const void *Cm, const float *D, const float *delta_bias,
+                              const float *dout, const float *ckpt, void *du, void *ddelta,
+                              float *dA, float *dB, float *dC, float *dD, float *ddelta_bias,
+                              int batch, int kd, int k, int n, int l, int io_dtype,
+                              int delta_softplus, void *stream);
+
+/* ------------------------------------------------------------------ L1: scan-order gather / merge, NCHW */
+/* xs[b,k,c,l] = x[b,c,table[k,l]];  x: (B, C, L), xs: (B, K, C, L);  table: DEVICE int32 (K, L). */
+int tramba_cross_scan(const void *x, const int32_t *table, void *xs, int batch, int c, int l, int k,
+                      int dtype, void *stream);
+/* y[b,c,p] = sum over entries e=k*L+l of inv[p] of ys[b,k,c,l];  fp32 accumulation, fixed order. */
+int tramba_cross_merge(const void *ys, const int32_t *inv_ptr, const int32_t *inv_idx, void *y,
+                       int batch, int c, int l, int k, int dtype, void *stream);
+
+/* ------------------------------------------------------------------ fused SS2D core, channels-last */
+/* x:    (B, L, D)           dtype   -- conv+SiLU output, spatial order
+ * xdbl: (B, L, K*(R+2))     f32     -- x_proj output in SPATIAL order: per group k
+ *                                      [dt_0..dt_{R-1}, B, C]   (d_state N = 1 only)
+ * table (K, L) int32 device; dt_w (K, D, R) f32; dt_bias (K*D) f32; A (K*D) f32 (= -exp(A_logs));
+ * Ds (K*D) f32.   ys: (B, K, L, D) ys_dtype in SEQUENCE order.                                   */
+int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
+                        const float *dt_bias, const float *A, const float *Ds, void *ys, int batch,
+                        int l, int d, int k, int r, int dtype, int ys_dtype, void *stream);
+/* y[b,p,:] = act(LayerNorm_D(sum_{e in inv[p]} ys[b, e/L, e%L, :]));  y: (B, L, D) dtype. */
+int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr, const int32_t *inv_idx,
+                              const float *ln_w, const float *ln_b, void *y, int batch, int l, int d,
+                              int k, float eps, int act, int ys_dtype, int dtype, void *stream);
+
+/* ------------------------------------------------------------------ element / stencil kernels, channels-last */
+/* y = act(LayerNorm_C(x));  x, y: (rows, C).  w, b f32. */
+int tramba_layernorm_cl(const void *x, const float *w, const float *b, void *y, int64_t rows, int c,
+                        float eps, int act, int dtype, void *stream);
+/* x: (B, H, W, P*P*C) -> y: (B, H*P, W*P, C) with y[b,hP+p1,wP+p2,:] = LN(x[b,h,w,(p1*P+p2)*C : +C]). */
+int tramba_shuffle_norm_cl(const void *x, const float *w, const float *b, void *y, int batch, int h,
+                           int wd, int c, int p, float eps, int dtype, void *stream);
+/* depth-wise ks x ks, stride 1, "same" padding.  weight (C, ks, ks) f32, bias (C) f32 or NULL. */
+int tramba_dwconv_cl(const void *x, const float *w, const float *bias, void *y, int batch, int h,
+                     int wd, int c, int ks, int act, int dtype, void *stream);
+/* y = GELU(x + dw3(x) + dw5(x) + dw7(x)) with biases. */
+int tramba_dwms_cl(const void *x, const float *w3, const float *b3, const float *w5, const float *b5,
+                   const float *w7, const float *b7, void *y, int batch, int h, int wd, int c,
+                   int dtype, void *stream);
+/* x: (B, n, n, C).  Y = Wy X Wx^T per channel; low = Y[:n/2,:n/2], high = Y[n/2:,n/2:],
+ * both (B, n/2, n/2, C).  wx, wy: (n, n) f32.  tmp: (B, n, n, C) f32 workspace. */
+int tramba_dct_split_cl(const void *x, const float *wx, const float *wy, float *tmp, void *high,
+                        void *low, int batch, int n, int c, int dtype, void *stream);
+/* y[m, :] = epilogue(x[m, :] @ W^T + bias);  x: (M, K) dtype, W: (N, K) dtype, bias (N) f32 or
+ * NULL, y: (M, N) out_dtype.  act applied after bias.  residual (M, N) dtype or NULL is added
+ * last.  MFMA path for f16/bf16. */
+int tramba_linear_cl(const void *x, const void *w, const float *bias, const void *residual, void *y,
+                     int64_t m, int n, int k, int act, int dtype, int out_dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAMBA_HIP_H */
