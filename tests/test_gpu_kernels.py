@@ -1,0 +1,208 @@
+"""GPU parity tests, kernel level: every entry of the C ABI against the CPU oracle
+(or the obvious fp64 torch formula) on seeded inputs.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops as oo
+from oracle import scan_tables as st
+from oracle import selective_scan as oss
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def hip():
+    from tramba_amd import hip as h
+    return h
+
+
+def _scan_inputs(nb, k, dper, n, l, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    kd = k * dper
+    r = lambda *s: torch.randn(*s, generator=g)
+    a = dict(u=r(nb, kd, l), delta=0.5 * r(nb, kd, l) - 0.5, A=-(torch.rand(kd, n, generator=g) + 0.2),
+             B=r(nb, k, n, l), C=r(nb, k, n, l), D=1 + 0.1 * r(kd), delta_bias=0.3 * r(kd))
+    for key in ("u", "delta", "B", "C"):
+        a[key] = a[key].to(dtype)
+    return a
+
+
+def _tol(dtype):
+    # inputs are rounded to `dtype` BEFORE both paths; the kernel computes in fp32, the oracle in fp64
+    return dict(rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 4, 8, 1, 144), (1, 4, 6, 1, 576), (2, 8, 4, 1, 2304), (1, 2, 3, 1, 1000),
+                                   (1, 4, 2, 1, 9216), (1, 1, 5, 1, 37), (2, 2, 3, 2, 200), (1, 2, 2, 4, 64)])
+def test_selective_scan_fwd(dtype, shape):
+    nb, k, dper, n, l = shape
+    a = _scan_inputs(nb, k, dper, n, l, dtype)
+    want = oss.selective_scan_fwd(a["u"].float(), a["delta"].float(), a["A"], a["B"].float(), a["C"].float(),
+                                  a["D"], a["delta_bias"], True)
+    g = {k_: v.to(DEV) for k_, v in a.items()}
+    out, ckpt = hip().selective_scan_fwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g["D"], g["delta_bias"], True, True)
+    assert out.dtype == torch.float32 and out.shape == (nb, k * dper, l)
+    np.testing.assert_allclose(out.cpu().double().numpy(), want.numpy(), **_tol(dtype))
+    assert ckpt.shape == (nb, k * dper, hip().selective_scan_nchunk(l, dtype), n)
+    # no softplus / no D / no bias / same-dtype output
+    want2 = oss.selective_scan_fwd(a["u"].float(), a["delta"].float().abs(), a["A"], a["B"].float(), a["C"].float(),
+                                   None, None, False)
+    out2, _ = hip().selective_scan_fwd(g["u"], g["delta"].abs(), g["A"], g["B"], g["C"], None, None, False, False, False)
+    assert out2.dtype == dtype
+    lo = dict(rtol=2e-2, atol=2e-2) if dtype != torch.float32 else _tol(dtype)
+    np.testing.assert_allclose(out2.cpu().double().numpy(), want2.numpy(), **lo)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 4, 8, 144), (1, 4, 6, 576), (1, 2, 3, 1000), (1, 8, 2, 2304), (1, 1, 5, 37)])
+def test_selective_scan_bwd(dtype, shape):
+    nb, k, dper, l = shape
+    a = _scan_inputs(nb, k, dper, 1, l, dtype, seed=3)
+    dout = torch.randn(nb, k * dper, l, generator=torch.Generator().manual_seed(9))
+    f = lambda t: t.float()
+    want = oss.selective_scan_bwd(f(a["u"]), f(a["delta"]), a["A"], f(a["B"]), f(a["C"]), a["D"], a["delta_bias"], dout, True)
+    g = {k_: v.to(DEV) for k_, v in a.items()}
+    _, ckpt = hip().selective_scan_fwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g["D"], g["delta_bias"], True, True)
+    got = hip().selective_scan_bwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g["D"], g["delta_bias"], dout.to(DEV), ckpt, True)
+    names = ("du", "ddelta", "dA", "dB", "dC", "dD", "dbias")
+    for name, x, w in zip(names, got, want):
+        w = w.numpy()
+        scale = max(1.0, float(np.abs(w).max()))
+        tol = 3e-4 if (dtype == torch.float32 or name not in ("du", "ddelta")) else 1.5e-2
+        err = np.abs(x.cpu().double().numpy() - w).max() / scale
+        assert err < tol, (name, err)
+
+
+@pytest.mark.parametrize("fam", ["raster", "helix", "window", "dilation", "line"])
+@pytest.mark.parametrize("h", [12, 24, 16])
+def test_cross_scan_merge(fam, h):
+    order = hip().scan_order(fam, h, h, torch.device(DEV))
+    assert np.array_equal(order.table.cpu().numpy(), st.table(fam, h))
+    x = torch.randn(2, 5, h, h)
+    xs = hip().cross_scan(x.to(DEV), order)
+    assert torch.equal(xs.cpu(), oo.cross_scan(x, fam))
+    ys = torch.randn(2, order.k, 5, h * h)
+    y = hip().cross_merge(ys.to(DEV), order)
+    np.testing.assert_allclose(y.cpu().numpy(), oo.cross_merge(ys, fam, h, h).numpy(), rtol=1e-5, atol=1e-5)
+    for dtype in (torch.bfloat16, torch.float16):
+        xs16 = hip().cross_scan(x.to(DEV, dtype), order)
+        assert torch.equal(xs16.cpu(), oo.cross_scan(x.to(dtype), fam))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("c", [16, 64, 128, 200, 256, 1024, 2048])
+def test_layernorm_cl(dtype, c):
+    x = torch.randn(3, 7, c) * 2 + 0.5
+    w, b = 1 + 0.1 * torch.randn(c), 0.1 * torch.randn(c)
+    xq = x.to(dtype)
+    want = F.layer_norm(xq.double(), (c,), w.double(), b.double(), 1e-5)
+    for act, fn in ((0, lambda t: t), (2, F.gelu)):
+        got = hip().layernorm_cl(xq.to(DEV), w.to(DEV), b.to(DEV), 1e-5, act)
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        np.testing.assert_allclose(got.cpu().double().numpy(), fn(want).numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 6, 8, 2), (1, 5, 16, 4), (2, 3, 128, 2), (1, 4, 32, 4)])
+def test_shuffle_norm_cl(dtype, cfg):
+    b, h, c, p = cfg
+    x = torch.randn(b, h, h, p * p * c).to(dtype)
+    w, bb = 1 + 0.1 * torch.randn(c), 0.1 * torch.randn(c)
+    xn = x.double().permute(0, 3, 1, 2)
+    want = oo.layernorm2d(oo.pixel_shuffle_groups(xn, p), w.double(), bb.double()).permute(0, 2, 3, 1)
+    got = hip().shuffle_norm_cl(x.to(DEV), w.to(DEV), bb.to(DEV), p)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 12, 32), (1, 7, 6), (1, 24, 64), (1, 5, 3)])
+def test_dwconv_and_dwms_cl(dtype, cfg):
+    b, h, c = cfg
+    x = torch.randn(b, h, h, c).to(dtype)
+    xn = x.double().permute(0, 3, 1, 2)
+    ws = {k: 0.2 * torch.randn(c, 1, k, k) for k in (3, 5, 7)}
+    bs = {k: 0.1 * torch.randn(c) for k in (3, 5, 7)}
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    want = F.silu(F.conv2d(xn, ws[3].double(), None, padding=1, groups=c)).permute(0, 2, 3, 1)
+    got = hip().dwconv_cl(x.to(DEV), ws[3].to(DEV), None, 1)
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
+    for k in (5, 7):
+        want = F.conv2d(xn, ws[k].double(), bs[k].double(), padding=k // 2, groups=c).permute(0, 2, 3, 1)
+        got = hip().dwconv_cl(x.to(DEV), ws[k].to(DEV), bs[k].to(DEV), 0)
+        np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
+    acc = xn
+    for k in (3, 5, 7):
+        acc = acc + F.conv2d(xn, ws[k].double(), bs[k].double(), padding=k // 2, groups=c)
+    want = F.gelu(acc).permute(0, 2, 3, 1)
+    g = lambda t: t.to(DEV)
+    got = hip().dwms_cl(g(x), g(ws[3]), g(bs[3]), g(ws[5]), g(bs[5]), g(ws[7]), g(bs[7]))
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 12, 16), (1, 24, 40), (1, 48, 64), (1, 96, 128), (1, 16, 8)])
+def test_dct_split_cl(dtype, cfg):
+    b, n, c = cfg
+    x = torch.randn(b, n, n, c).to(dtype)
+    w = oo.dct_matrix(n)
+    high, low = oo.dct2d_split(x.double().permute(0, 3, 1, 2), w.double(), w.double())
+    gh, gl = hip().dct_split_cl(x.to(DEV), w.to(DEV), w.to(DEV))
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    np.testing.assert_allclose(gh.cpu().double().numpy(), high.permute(0, 2, 3, 1).numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(gl.cpu().double().numpy(), low.permute(0, 2, 3, 1).numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mnk", [(300, 40, 32), (1000, 264, 256), (144, 128, 1024), (37, 5, 16), (513, 130, 72), (64, 1, 128)])
+def test_linear_cl(dtype, mnk):
+    m, n, k = mnk
+    # A = structured + random, asymmetric W: catches transposed fragment / C-layout mistakes
+    x = (torch.randn(m, k) + torch.arange(k)[None, :] * 0.01).to(dtype)
+    w = (torch.randn(n, k) * 0.2 + torch.arange(n)[:, None] * 0.003).to(dtype)
+    bias = torch.randn(n)
+    res = torch.randn(m, n).to(dtype)
+    base = x.double() @ w.double().T
+    tol = 2e-5 * k ** 0.5 if dtype == torch.float32 else 2e-2
+    got = hip().linear_cl(x.to(DEV), w.to(DEV), None, None, 0, torch.float32)
+    np.testing.assert_allclose(got.cpu().double().numpy(), base.numpy(), rtol=1e-4 if dtype == torch.float32 else 1e-3,
+                               atol=tol if dtype == torch.float32 else 1e-3 * float(base.abs().max()))
+    want = F.gelu(base + bias.double()) + res.double()
+    got = hip().linear_cl(x.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), 2)
+    assert got.dtype == dtype
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol * max(1.0, float(want.abs().max())))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fam", ["raster", "helix", "window", "dilation"])
+@pytest.mark.parametrize("cfg", [(2, 12, 32, 2), (1, 24, 64, 4), (1, 16, 40, 3), (1, 48, 128, 8)])
+def test_ss2d_fused_core(dtype, fam, cfg):
+    """fused channels-last scan + merge/LayerNorm/GELU against the oracle's NCHW composition."""
+    b, h, d, r = cfg
+    k = 8 if fam == "helix" else 4
+    g = torch.Generator().manual_seed(h * d + k)
+    x = torch.randn(b, d, h, h, generator=g).to(dtype)
+    wx = (torch.randn(k, r + 2, d, generator=g) * d ** -0.5).to(dtype)
+    wdt = torch.randn(k, d, r, generator=g) * r ** -0.5
+    dtb = torch.randn(k, d, generator=g) * 0.5 - 2.0
+    a_logs = torch.log(0.5 + torch.rand(k * d, 1, generator=g))
+    ds = 1 + 0.1 * torch.randn(k * d, generator=g)
+    lw, lb = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    y = oo.ss2d_core(x.double(), wx.double(), wdt.double(), dtb.double(), a_logs.double(), ds.double(), fam)
+    want = F.gelu(oo.layernorm2d(y, lw.double(), lb.double())).permute(0, 2, 3, 1)
+
+    H = hip()
+    dev = torch.device(DEV)
+    order = H.scan_order(fam, h, h, dev)
+    xc = x.permute(0, 2, 3, 1).contiguous().view(b, h * h, d).to(dev)
+    xdbl = H.linear_cl(xc, wx.reshape(k * (r + 2), d).to(dev), out_dtype=torch.float32)
+    for ys_dtype in ([torch.float32] if dtype == torch.float32 else [torch.float32, dtype]):
+        ys = H.ss2d_scan_cl(xc, xdbl, order, wdt.to(dev), dtb.reshape(-1).to(dev), (-torch.exp(a_logs)).reshape(-1).to(dev),
+                            ds.to(dev), ys_dtype)
+        out = H.ss2d_merge_norm_cl(ys, order, lw.to(dev), lb.to(dev), 1e-5, 2, dtype)
+        tol = 2e-4 if dtype == torch.float32 else 4e-2
+        np.testing.assert_allclose(out.view(b, h, h, d).cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)

@@ -1,0 +1,90 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the header
+declares, the native scan-table generators agree with the oracle and the reference hashes, and the
+module tree is state_dict-compatible with the reference.  No compute kernel is launched."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scan_tables as st
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from tramba_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "tramba_hip.h")).read()
+    declared = set(re.findall(r"\b(tramba_[a-z0-9_]+)\s*\(", hdr))
+    lib = hip.lib()
+    assert lib.tramba_abi_version() == 1
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/tramba_hip.h but not exported"
+    assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+
+
+def test_bad_arguments_are_rejected_not_fatal():
+    from tramba_amd import hip
+    lib = hip.lib()
+    assert lib.tramba_scan_family_k(99) < 0 and b"family" in lib.tramba_last_error()
+    out = np.empty(4 * 144, dtype=np.int32)
+    assert lib.tramba_scan_table(hip.SCAN_WINDOW, 12, 12, 5, out.ctypes.data) < 0  # 5 does not divide 12
+    assert lib.tramba_scan_table(hip.SCAN_LINE, 12, 10, 0, out.ctypes.data) < 0  # not square
+    # null tensors / bad shapes never reach a launch
+    assert lib.tramba_selective_scan_fwd(None, None, None, None, None, None, None, None, None, 1, 4, 4, 1, 8, 0, 0, 1, None) < 0
+    with pytest.raises(hip.TrambaHipError):
+        hip.layernorm_cl(torch.zeros(2, 8), torch.ones(8), torch.zeros(8))  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("fam", ["raster", "line", "helix", "window", "dilation"])
+@pytest.mark.parametrize("h", [12, 24, 48, 96, 16, 32, 64, 192])
+def test_native_tables_equal_oracle(fam, h):
+    from tramba_amd import hip
+    got = hip.scan_table_host(fam, h)
+    assert np.array_equal(got, st.table(fam, h))
+    ptr, idx = hip.scan_table_inverse_host(got)
+    flat = got.reshape(-1)
+    assert ptr[0] == 0 and ptr[-1] == flat.size and np.all(np.diff(ptr) >= 0)
+    assert np.array_equal(np.sort(idx), np.arange(flat.size))
+    assert np.array_equal(flat[idx], np.repeat(np.arange(h * h), np.diff(ptr)))
+
+
+def test_native_tables_match_reference_hashes(golden_meta):
+    from tramba_amd import hip
+    for h in (12, 24, 48, 96):
+        for fam in ("line", "dilation", "window"):
+            got = [st.table_hash(r) for r in hip.scan_table_host(fam, h)]
+            assert got == golden_meta["G1"][f"{fam}_{h}"]
+    for h in (7, 14, 28, 56):
+        assert [st.table_hash(r) for r in hip.scan_table_host("line", h)] == golden_meta["G1"][f"line_{h}"]
+
+
+def test_state_dict_manifests_match_reference(golden_meta):
+    import tramba_amd as ta
+    mv = ta.bulid_model(use_pretrain=False)
+    assert {k: list(v.shape) for k, v in mv.state_dict().items()} == {k: s for k, s in golden_meta["G6_tramba_v"]}
+    assert sum(p.numel() for p in mv.parameters()) == golden_meta["G6_tramba_v_params"]
+    enc = [n for n, _ in mv.named_parameters() if "encoder" in n]
+    assert enc and all(n.startswith("vssm_encoder.") for n in enc)  # train.py:266-269 optimizer split
+    mr = ta.bulid_model_enc("Tramba-R-TSOD")
+    assert {k: list(v.shape) for k, v in mr.state_dict().items()} == {k: s for k, s in golden_meta["G6_tramba_r"]}
+    assert sum(p.numel() for p in mr.parameters()) == golden_meta["G6_tramba_r_params"]
+
+
+def test_linear2d_accepts_conv_checkpoints():
+    import tramba_amd as ta
+    lin = ta.Linear2d(8, 4, bias=False)
+    w = torch.randn(4, 8, 1, 1)
+    lin.load_state_dict({"weight": w})
+    assert torch.equal(lin.weight, w.view(4, 8))
+
+
+def test_get_model_build_surface():
+    import types
+    import tramba_amd as ta
+    args = types.SimpleNamespace(img_size=384, pretrained_path="")
+    assert isinstance(ta.build("Tramba-R-TSOD", args), ta.BaseUMambaEnc)
+    with pytest.raises(NotImplementedError):
+        ta.build("Tramba-S-TSOD", args)

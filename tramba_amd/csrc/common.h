@@ -1,0 +1,126 @@
+// Shared device/host helpers for libtramba_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tramba_hip.h"
+
+namespace tramba {
+
+constexpr int kWave = 64;
+
+void set_error(const char *fmt, ...);
+
+#define TRAMBA_CHECK(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::tramba::set_error(__VA_ARGS__);   \
+            return TRAMBA_ERR_ARG;              \
+        }                                       \
+    } while (0)
+
+#define TRAMBA_LAUNCH_CHECK()                                                         \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            ::tramba::set_error("%s:%d launch failed: %s", __FILE__, __LINE__,        \
+                                hipGetErrorString(e_));                               \
+            return TRAMBA_ERR_HIP;                                                    \
+        }                                                                             \
+    } while (0)
+
+// ---- profiling hooks (HIP events around one kernel class; see tramba_profile_enable) ----
+struct ProfScope {
+    int which;
+    hipStream_t stream;
+    bool on;
+    hipEvent_t start;
+    ProfScope(int which, hipStream_t s, double units);
+    ~ProfScope();
+};
+
+// ---- dtype traits ----
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+    static __device__ __forceinline__ float to_f(float v) { return v; }
+    static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Cvt<__half> {
+    static __device__ __forceinline__ float to_f(__half v) { return __half2float(v); }
+    static __device__ __forceinline__ __half from_f(float v) { return __float2half(v); }
+};
+template <> struct Cvt<__hip_bfloat16> {
+    static __device__ __forceinline__ float to_f(__hip_bfloat16 v) { return __bfloat162float(v); }
+    static __device__ __forceinline__ __hip_bfloat16 from_f(float v) { return __float2bfloat16(v); }
+};
+
+// A pack of V elements of T moved with one (8/16-byte where possible) access.
+template <typename T, int V> struct alignas(sizeof(T) * V > 16 ? 16 : sizeof(T) * V) Pack {
+    T v[V];
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void load_pack(const T *p, float (&out)[V])
+{
+    Pack<T, V> pk = *reinterpret_cast<const Pack<T, V> *>(p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) out[i] = Cvt<T>::to_f(pk.v[i]);
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void store_pack(T *p, const float (&in)[V])
+{
+    Pack<T, V> pk;
+#pragma unroll
+    for (int i = 0; i < V; ++i) pk.v[i] = Cvt<T>::from_f(in[i]);
+    *reinterpret_cast<Pack<T, V> *>(p) = pk;
+}
+
+// ---- math ----
+// softplus with the reference's threshold (x > 20 -> x).  log1p via the w = 1+z trick keeps
+// full relative precision for small exp(x) while using the hardware exp/log.
+__device__ __forceinline__ float softplus20(float x)
+{
+    if (x > 20.f) return x;
+    float z = __expf(x);
+    float w = 1.f + z;
+    float d = w - 1.f;
+    return d == 0.f ? z : __logf(w) * __fdividef(z, d);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float geluf_(float x)
+{
+    return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float apply_act(float x, int act)
+{
+    if (act == TRAMBA_ACT_SILU) return siluf_(x);
+    if (act == TRAMBA_ACT_GELU) return geluf_(x);
+    return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// dispatch a runtime dtype to a template
+#define TRAMBA_DISPATCH_DTYPE(dt, T, ...)                                   \
+    switch (dt) {                                                           \
+    case TRAMBA_F32: { using T = float; __VA_ARGS__; } break;               \
+    case TRAMBA_F16: { using T = __half; __VA_ARGS__; } break;              \
+    case TRAMBA_BF16: { using T = __hip_bfloat16; __VA_ARGS__; } break;     \
+    default: ::tramba::set_error("bad dtype %d", (int)(dt)); return TRAMBA_ERR_ARG; \
+    }
+
+inline size_t dtype_size(int dt) { return dt == TRAMBA_F32 ? 4 : 2; }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace tramba

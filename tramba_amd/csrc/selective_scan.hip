@@ -1,0 +1,460 @@
+// Selective scan in the reference's own tensor layout (the L0 drop-in boundary).
+//
+// Replaces selective_scan_cuda_oflex.fwd / .bwd (call sites Models/SS2D/csms6s.py:910,
+// :920-922).  Layout: u, delta, out (B, KD, L) with L contiguous; B/C (B, K, N, L).
+//
+// MI355X mapping.  The op is HBM-bound (8 B/element at bf16-in/fp32-out, ~10 flop): the
+// design goal is full-width coalesced streams with enough waves in flight, not MFMA.
+//   * one row (b, d) is owned by LPR consecutive lanes of a wave (LPR = 64, or 32/16 for
+//     short rows so a wave carries 2/4 rows); a chunk is LPR*E consecutive positions and
+//     each lane moves its E=8 elements with 16-byte accesses -> every wave-level load/store
+//     covers contiguous 1 KiB (bf16) / 2 KiB (fp32) segments;
+//   * inside a chunk: per-lane serial recurrence over E elements, then a log-step
+//     wave-level scan of the (decay, state) pairs with DPP/shuffle (the recurrence
+//     h = a h + b is associative under (a2 a1, a2 b1 + b2)), then the per-lane replay
+//     with the now-known carry-in; the chunk carry is broadcast from the row's last lane;
+//   * the next chunk's operands are fetched before the current chunk's scan so the
+//     dependent carry chain never exposes HBM latency;
+//   * state in fp32; softplus threshold 20 like the reference; exp via v_exp_f32.
+// Chunk-end states go to `ckpt` for the backward (same chunking), which replays each chunk
+// forward from its checkpoint and runs the adjoint recurrence right-to-left.
+#include "common.h"
+
+namespace tramba {
+
+constexpr int kE = 8;        // elements per lane per chunk
+constexpr int kMaxN = 4;     // d_state supported by the generic path (Tramba uses 1)
+constexpr int kWavesPerBlock = 4;
+
+__host__ __device__ inline int lanes_per_row(int l)
+{
+    const int need = (l + kE - 1) / kE;
+    return need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+}
+
+// inclusive scan of (a, h) pairs over the LPR lanes that own one row
+template <int LPR>
+__device__ __forceinline__ void row_scan(float &a, float &h, int sub)
+{
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+        const float ap = __shfl_up(a, o, LPR);
+        const float hp = __shfl_up(h, o, LPR);
+        if (sub >= o) {
+            h = fmaf(a, hp, h);
+            a *= ap;
+        }
+    }
+}
+
+template <typename T, typename TO, int LPR, int N>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_fwd_kernel(
+    const T *__restrict__ u, const T *__restrict__ delta, const float *__restrict__ A,
+    const T *__restrict__ Bm, const T *__restrict__ Cm, const float *__restrict__ Dskip,
+    const float *__restrict__ dbias, TO *__restrict__ out, float *__restrict__ ckpt, int rows_total,
+    int kd, int K, int L, int nchunk, int softplus, int vec_ok)
+{
+    constexpr int RPW = kWave / LPR;  // rows per wave
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int sub = lane % LPR;
+    const long row = (long)wave * RPW + lane / LPR;
+    const bool row_ok = row < rows_total;
+    const long rrow = row_ok ? row : 0;
+    const int b = (int)(rrow / kd), d = (int)(rrow % kd);
+    const int k = d / (kd / K);
+
+    const T *ur = u + rrow * L;
+    const T *dr = delta + rrow * L;
+    TO *yr = out + rrow * L;
+    const T *Br = Bm + ((long)b * K + k) * N * L;
+    const T *Cr = Cm + ((long)b * K + k) * N * L;
+
+    float An[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) An[n] = A[(long)d * N + n];
+    const float bias = dbias ? dbias[d] : 0.f;
+    const float skip = Dskip ? Dskip[d] : 0.f;
+
+    float carry[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) carry[n] = 0.f;
+
+    float fu[kE], fd[kE], fB[N][kE], fC[N][kE];
+
+    auto fetch = [&](int chunk, float (&xu)[kE], float (&xd)[kE], float (&xB)[N][kE], float (&xC)[N][kE]) {
+        const int l0 = chunk * (LPR * kE) + sub * kE;
+        if (vec_ok && l0 + kE <= L) {
+            load_pack<T, kE>(ur + l0, xu);
+            load_pack<T, kE>(dr + l0, xd);
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                load_pack<T, kE>(Br + (long)n * L + l0, xB[n]);
+                load_pack<T, kE>(Cr + (long)n * L + l0, xC[n]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kE; ++j) {
+                const bool ok = l0 + j < L;
+                xu[j] = ok ? Cvt<T>::to_f(ur[l0 + j]) : 0.f;
+                xd[j] = ok ? Cvt<T>::to_f(dr[l0 + j]) : 0.f;
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    xB[n][j] = ok ? Cvt<T>::to_f(Br[(long)n * L + l0 + j]) : 0.f;
+                    xC[n][j] = ok ? Cvt<T>::to_f(Cr[(long)n * L + l0 + j]) : 0.f;
+                }
+            }
+        }
+    };
+
+    fetch(0, fu, fd, fB, fC);
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        float cu[kE], cd[kE], cB[N][kE], cC[N][kE];
+#pragma unroll
+        for (int j = 0; j < kE; ++j) {
+            cu[j] = fu[j];
+            cd[j] = fd[j];
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                cB[n][j] = fB[n][j];
+                cC[n][j] = fC[n][j];
+            }
+        }
+        if (chunk + 1 < nchunk) fetch(chunk + 1, fu, fd, fB, fC);
+
+        const int l0 = chunk * (LPR * kE) + sub * kE;
+        float dt[kE];
+#pragma unroll
+        for (int j = 0; j < kE; ++j) {
+            float x = cd[j] + bias;
+            dt[j] = softplus ? softplus20(x) : x;
+            if (l0 + j >= L) dt[j] = 0.f;  // identity element: a = 1, b = 0
+        }
+        float y[kE];
+#pragma unroll
+        for (int j = 0; j < kE; ++j) y[j] = skip * cu[j];
+
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            float a[kE], bb[kE];
+            float pa = 1.f, ph = 0.f;
+#pragma unroll
+            for (int j = 0; j < kE; ++j) {
+                a[j] = __expf(dt[j] * An[n]);
+                bb[j] = dt[j] * cB[n][j] * cu[j];
+                ph = fmaf(a[j], ph, bb[j]);
+                pa *= a[j];
+            }
+            row_scan<LPR>(pa, ph, sub);
+            // exclusive prefix for this lane, then fold in the chunk carry
+            float ea = __shfl_up(pa, 1, LPR), eh = __shfl_up(ph, 1, LPR);
+            if (sub == 0) { ea = 1.f; eh = 0.f; }
+            float h = fmaf(ea, carry[n], eh);
+            // new chunk carry = inclusive prefix of the row's last lane applied to the old carry
+            const float la = __shfl(pa, LPR - 1, LPR), lh = __shfl(ph, LPR - 1, LPR);
+            carry[n] = fmaf(la, carry[n], lh);
+#pragma unroll
+            for (int j = 0; j < kE; ++j) {
+                h = fmaf(a[j], h, bb[j]);
+                y[j] = fmaf(cC[n][j], h, y[j]);
+            }
+            if (ckpt && row_ok && sub == 0) ckpt[(rrow * nchunk + chunk) * N + n] = carry[n];
+        }
+
+        if (row_ok) {
+            if (vec_ok && l0 + kE <= L) {
+                store_pack<TO, kE>(yr + l0, y);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kE; ++j)
+                    if (l0 + j < L) yr[l0 + j] = Cvt<TO>::from_f(y[j]);
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------ backward
+// Adjoint of the recurrence (N = 1).  With g_l = dLoss/dh_l:
+//     g_l      = C_l dout_l + a_{l+1} g_{l+1}                      (right-to-left scan)
+//     d dt_l   = g_l (h_{l-1} a_l A + B_l u_l)        d u_l = dout_l D + g_l dt_l B_l
+//     dB_l    += g_l dt_l u_l   dC_l += dout_l h_l    dA += g_l h_{l-1} a_l dt_l   dD += dout_l u_l
+//     d delta  = d dt * sigmoid(delta + bias)  (1 beyond the softplus threshold)
+// Chunks are walked last-to-first; each chunk is replayed forward from its checkpoint (row_scan)
+// to recover h_{l-1}, then the adjoint runs as a mirrored wave scan.  dB/dC are shared by the
+// KD/K rows of a group: they are reduced with fp32 atomics (one add per element); dA, dD and
+// d delta_bias are reduced per row in registers, then one atomic per row.
+template <int LPR>
+__device__ __forceinline__ void row_scan_rev(float &a, float &g, int sub)
+{
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+        const float an = __shfl_down(a, o, LPR);
+        const float gn = __shfl_down(g, o, LPR);
+        if (sub + o < LPR) {
+            g = fmaf(a, gn, g);
+            a *= an;
+        }
+    }
+}
+
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v)
+{
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR);
+    return v;
+}
+
+template <typename T, int LPR>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_kernel(
+    const T *__restrict__ u, const T *__restrict__ delta, const float *__restrict__ A,
+    const T *__restrict__ Bm, const T *__restrict__ Cm, const float *__restrict__ Dskip,
+    const float *__restrict__ dbias, const float *__restrict__ dout, const float *__restrict__ ckpt,
+    T *__restrict__ du, T *__restrict__ ddelta, float *__restrict__ dA, float *__restrict__ dB,
+    float *__restrict__ dC, float *__restrict__ dD, float *__restrict__ ddbias, int rows_total, int kd,
+    int K, int L, int nchunk, int softplus, int vec_ok)
+{
+    constexpr int RPW = kWave / LPR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int sub = lane % LPR;
+    const long row = (long)wave * RPW + lane / LPR;
+    const bool row_ok = row < rows_total;
+    const long rrow = row_ok ? row : 0;
+    const int b = (int)(rrow / kd), d = (int)(rrow % kd);
+    const int k = d / (kd / K);
+
+    const T *ur = u + rrow * L;
+    const T *dr = delta + rrow * L;
+    const float *gr = dout + rrow * L;
+    const long bc = ((long)b * K + k) * L;
+    const T *Br = Bm + bc;
+    const T *Cr = Cm + bc;
+    const float An = A[d];
+    const float bias = dbias ? dbias[d] : 0.f;
+    const float skip = Dskip ? Dskip[d] : 0.f;
+
+    float g_carry = 0.f;   // g of the first element of the chunk to the right
+    float a_carry = 1.f;   // a of that element
+    float accA = 0.f, accD = 0.f, accBias = 0.f;
+
+    for (int chunk = nchunk - 1; chunk >= 0; --chunk) {
+        const int l0 = chunk * (LPR * kE) + sub * kE;
+        float cu[kE], cd[kE], cB[kE], cC[kE], go[kE];
+        if (vec_ok && l0 + kE <= L) {
+            load_pack<T, kE>(ur + l0, cu);
+            load_pack<T, kE>(dr + l0, cd);
+            load_pack<T, kE>(Br + l0, cB);
+            load_pack<T, kE>(Cr + l0, cC);
+            load_pack<float, kE>(gr + l0, go);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kE; ++j) {
+                const bool ok = l0 + j < L;
+                cu[j] = ok ? Cvt<T>::to_f(ur[l0 + j]) : 0.f;
+                cd[j] = ok ? Cvt<T>::to_f(dr[l0 + j]) : 0.f;
+                cB[j] = ok ? Cvt<T>::to_f(Br[l0 + j]) : 0.f;
+                cC[j] = ok ? Cvt<T>::to_f(Cr[l0 + j]) : 0.f;
+                go[j] = ok ? gr[l0 + j] : 0.f;
+            }
+        }
+        float dt[kE], raw[kE], a[kE], bb[kE];
+        float pa = 1.f, ph = 0.f;
+#pragma unroll
+        for (int j = 0; j < kE; ++j) {
+            raw[j] = cd[j] + bias;
+            dt[j] = softplus ? softplus20(raw[j]) : raw[j];
+            if (l0 + j >= L) dt[j] = 0.f;
+            a[j] = __expf(dt[j] * An);
+            bb[j] = dt[j] * cB[j] * cu[j];
+            ph = fmaf(a[j], ph, bb[j]);
+            pa *= a[j];
+        }
+        // forward replay from the checkpoint: state entering this lane
+        row_scan<LPR>(pa, ph, sub);
+        float ea = __shfl_up(pa, 1, LPR), eh = __shfl_up(ph, 1, LPR);
+        if (sub == 0) { ea = 1.f; eh = 0.f; }
+        const float hstart = chunk > 0 ? ckpt[rrow * nchunk + chunk - 1] : 0.f;
+        float h = fmaf(ea, hstart, eh);
+        float hprev[kE], hcur[kE];
+#pragma unroll
+        for (int j = 0; j < kE; ++j) {
+            hprev[j] = h;
+            h = fmaf(a[j], h, bb[j]);
+            hcur[j] = h;
+        }
+        // adjoint scan: element j carries (a_{j+1}, C_j dout_j)
+        float a_right = __shfl_down(a[0], 1, LPR);          // first a of the lane to the right
+        if (sub == LPR - 1) a_right = a_carry;
+        float an[kE], cg[kE];
+#pragma unroll
+        for (int j = 0; j < kE; ++j) {
+            an[j] = j + 1 < kE ? a[j + 1] : a_right;
+            cg[j] = cC[j] * go[j];
+        }
+        float qa = 1.f, qg = 0.f;
+#pragma unroll
+        for (int j = kE - 1; j >= 0; --j) {
+            qg = fmaf(an[j], qg, cg[j]);
+            qa *= an[j];
+        }
+        row_scan_rev<LPR>(qa, qg, sub);
+        float xa = __shfl_down(qa, 1, LPR), xg = __shfl_down(qg, 1, LPR);   // exclusive suffix
+        if (sub == LPR - 1) { xa = 1.f; xg = 0.f; }
+        float g = fmaf(xa, g_carry, xg);
+        // carries for the chunk to the left: full-row suffix applied to the old carry
+        const float fa = __shfl(qa, 0, LPR), fg = __shfl(qg, 0, LPR);
+        g_carry = fmaf(fa, g_carry, fg);
+        a_carry = __shfl(a[0], 0, LPR);
+
+        float odu[kE], odd[kE];
+#pragma unroll
+        for (int j = kE - 1; j >= 0; --j) {
+            g = fmaf(an[j], g, cg[j]);                       // g_j
+            const bool ok = l0 + j < L;
+            const float ddt = g * fmaf(hprev[j] * a[j], An, cB[j] * cu[j]);
+            odu[j] = fmaf(go[j], skip, g * dt[j] * cB[j]);
+            float dr_ = ddt;
+            if (softplus && raw[j] <= 20.f) dr_ = ddt * sigmoidf_(raw[j]);
+            odd[j] = ok ? dr_ : 0.f;
+            accA = fmaf(g * hprev[j], a[j] * dt[j], accA);
+            accD = fmaf(go[j], cu[j], accD);
+            accBias += odd[j];
+            if (ok && row_ok) {
+                atomicAdd(dB + bc + l0 + j, g * dt[j] * cu[j]);
+                atomicAdd(dC + bc + l0 + j, go[j] * hcur[j]);
+            }
+        }
+        if (row_ok) {
+            if (vec_ok && l0 + kE <= L) {
+                store_pack<T, kE>(du + rrow * L + l0, odu);
+                store_pack<T, kE>(ddelta + rrow * L + l0, odd);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kE; ++j)
+                    if (l0 + j < L) {
+                        du[rrow * L + l0 + j] = Cvt<T>::from_f(odu[j]);
+                        ddelta[rrow * L + l0 + j] = Cvt<T>::from_f(odd[j]);
+                    }
+            }
+        }
+    }
+    accA = row_sum<LPR>(accA);
+    accD = row_sum<LPR>(accD);
+    accBias = row_sum<LPR>(accBias);
+    if (row_ok && sub == 0) {
+        atomicAdd(dA + d, accA);
+        if (dD) atomicAdd(dD + d, accD);
+        if (ddbias) atomicAdd(ddbias + d, accBias);
+    }
+}
+
+template <typename T, typename TO, int N>
+static int launch_fwd(const void *u, const void *delta, const float *A, const void *Bm, const void *Cm,
+                      const float *D, const float *bias, void *out, float *ckpt, int batch, int kd,
+                      int K, int L, int softplus, hipStream_t s)
+{
+    const int lpr = lanes_per_row(L);
+    const int nchunk = (L + lpr * kE - 1) / (lpr * kE);
+    const long rows = (long)batch * kd;
+    const int rpw = kWave / lpr;
+    const long waves = (rows + rpw - 1) / rpw;
+    const long blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int vec_ok = (L % kE == 0) && aligned16(u) && aligned16(delta) && aligned16(Bm) &&
+                       aligned16(Cm) && aligned16(out);
+    dim3 grid((unsigned)blocks), block(kWavesPerBlock * kWave);
+#define LAUNCH_(LPR_)                                                                              \
+    hipLaunchKernelGGL((selective_scan_fwd_kernel<T, TO, LPR_, N>), grid, block, 0, s, (const T *)u, \
+                       (const T *)delta, A, (const T *)Bm, (const T *)Cm, D, bias, (TO *)out, ckpt,  \
+                       (int)rows, kd, K, L, nchunk, softplus, vec_ok)
+    if (lpr == 16) LAUNCH_(16);
+    else if (lpr == 32) LAUNCH_(32);
+    else LAUNCH_(64);
+#undef LAUNCH_
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+}  // namespace tramba
+
+using namespace tramba;
+
+extern "C" int tramba_selective_scan_nchunk(int l, int io_dtype)
+{
+    (void)io_dtype;
+    if (l <= 0) return 0;
+    const int lpr = lanes_per_row(l);
+    return (l + lpr * kE - 1) / (lpr * kE);
+}
+
+extern "C" int tramba_selective_scan_fwd(const void *u, const void *delta, const float *A,
+                                         const void *Bm, const void *Cm, const float *D,
+                                         const float *delta_bias, void *out, float *ckpt, int batch,
+                                         int kd, int k, int n, int l, int io_dtype, int out_dtype,
+                                         int delta_softplus, void *stream)
+{
+    TRAMBA_CHECK(u && delta && A && Bm && Cm && out, "selective_scan_fwd: null tensor");
+    TRAMBA_CHECK(batch > 0 && kd > 0 && k > 0 && l > 0, "selective_scan_fwd: empty shape");
+    TRAMBA_CHECK(kd % k == 0, "selective_scan_fwd: KD=%d is not a multiple of K=%d", kd, k);
+    TRAMBA_CHECK(n >= 1 && n <= kMaxN, "selective_scan_fwd: d_state=%d unsupported (1..%d)", n, kMaxN);
+    TRAMBA_CHECK(out_dtype == TRAMBA_F32 || out_dtype == io_dtype,
+                 "selective_scan_fwd: out dtype must be f32 (oflex) or the input dtype");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(TRAMBA_PROF_SCAN_BOUNDARY, s, (double)batch * kd * l);
+#define GO_(T, TO, N_) \
+    return launch_fwd<T, TO, N_>(u, delta, A, Bm, Cm, D, delta_bias, out, ckpt, batch, kd, k, l, delta_softplus, s)
+#define BY_N_(T, TO)                                                           \
+    switch (n) {                                                               \
+    case 1: GO_(T, TO, 1);                                                     \
+    case 2: GO_(T, TO, 2);                                                     \
+    case 4: GO_(T, TO, 4);                                                     \
+    default: set_error("selective_scan_fwd: d_state=%d not instantiated (1,2,4)", n); \
+             return TRAMBA_ERR_UNSUPPORTED;                                    \
+    }
+    TRAMBA_DISPATCH_DTYPE(io_dtype, T, {
+        if (out_dtype == TRAMBA_F32) { BY_N_(T, float) } else { BY_N_(T, T) }
+    });
+#undef BY_N_
+#undef GO_
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_selective_scan_bwd(const void *u, const void *delta, const float *A, const void *Bm,
+                                         const void *Cm, const float *D, const float *delta_bias,
+                                         const float *dout, const float *ckpt, void *du, void *ddelta,
+                                         float *dA, float *dB, float *dC, float *dD, float *ddelta_bias,
+                                         int batch, int kd, int k, int n, int l, int io_dtype,
+                                         int delta_softplus, void *stream)
+{
+    TRAMBA_CHECK(u && delta && A && Bm && Cm && dout && ckpt && du && ddelta && dA && dB && dC,
+                 "selective_scan_bwd: null tensor");
+    TRAMBA_CHECK(batch > 0 && kd > 0 && k > 0 && l > 0, "selective_scan_bwd: empty shape");
+    TRAMBA_CHECK(kd % k == 0, "selective_scan_bwd: KD=%d is not a multiple of K=%d", kd, k);
+    if (n != 1) {
+        set_error("selective_scan_bwd: d_state=%d unsupported (Tramba uses 1)", n);
+        return TRAMBA_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = lanes_per_row(l);
+    const int nchunk = (l + lpr * kE - 1) / (lpr * kE);
+    const long rows = (long)batch * kd;
+    const int rpw = kWave / lpr;
+    const long waves = (rows + rpw - 1) / rpw;
+    const long blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int vec_ok = (l % kE == 0) && aligned16(u) && aligned16(delta) && aligned16(Bm) && aligned16(Cm) &&
+                       aligned16(dout) && aligned16(du) && aligned16(ddelta);
+    dim3 grid((unsigned)blocks), block(kWavesPerBlock * kWave);
+#define LAUNCH_(T, LPR_)                                                                                    \
+    hipLaunchKernelGGL((selective_scan_bwd_kernel<T, LPR_>), grid, block, 0, s, (const T *)u, (const T *)delta, \
+                       A, (const T *)Bm, (const T *)Cm, D, delta_bias, dout, ckpt, (T *)du, (T *)ddelta, dA, dB, \
+                       dC, dD, ddelta_bias, (int)rows, kd, k, l, nchunk, delta_softplus, vec_ok)
+    TRAMBA_DISPATCH_DTYPE(io_dtype, T, {
+        if (lpr == 16) LAUNCH_(T, 16);
+        else if (lpr == 32) LAUNCH_(T, 32);
+        else LAUNCH_(T, 64);
+    });
+#undef LAUNCH_
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}

@@ -1,0 +1,336 @@
+"""ctypes binding of libtramba_hip.so (the C ABI in include/tramba_hip.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every kernel on the Tramba hot
+path is launched through this module onto torch's CURRENT stream.  There is no fallback: if
+the library is missing or the tensors are not on a HIP device the call raises.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libtramba_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+SCAN_RASTER, SCAN_LINE, SCAN_HELIX, SCAN_WINDOW, SCAN_DILATION = range(5)
+FAMILY = {"raster": SCAN_RASTER, "line": SCAN_LINE, "helix": SCAN_HELIX, "window": SCAN_WINDOW,
+          "dilation": SCAN_DILATION}
+PROF_SCAN_BOUNDARY, PROF_SCAN_FUSED = 0, 1
+
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+c_int, c_i64, c_f, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/tramba_hip.h one to one
+SIGNATURES = {
+    "tramba_last_error": (ctypes.c_char_p, []),
+    "tramba_abi_version": (c_int, []),
+    "tramba_profile_enable": (c_int, [c_int, c_int]),
+    "tramba_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "tramba_scan_family_k": (c_int, [c_int]),
+    "tramba_default_window": (c_int, [c_int]),
+    "tramba_scan_table": (c_int, [c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_scan_table_inverse": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    "tramba_selective_scan_nchunk": (c_int, [c_int, c_int]),
+    "tramba_selective_scan_fwd": (c_int, [c_vp] * 9 + [c_int] * 8 + [c_vp]),
+    "tramba_selective_scan_bwd": (c_int, [c_vp] * 16 + [c_int] * 7 + [c_vp]),
+    "tramba_cross_scan": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_cross_merge": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_ss2d_scan_cl": (c_int, [c_vp] * 8 + [c_int] * 7 + [c_vp]),
+    "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
+    "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
+    "tramba_shuffle_norm_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_f, c_int, c_vp]),
+    "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
+    "tramba_dwms_cl": (c_int, [c_vp] * 8 + [c_int] * 5 + [c_vp]),
+    "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
+    "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load the shared library (raises if it has not been built -- never falls back)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: build it with `python -m tramba_amd.build` "
+                        "(hipcc, gfx950).  tramba_amd has no CPU or PyTorch fallback.")
+                l = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(l, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = l
+    return _lib
+
+
+class TrambaHipError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise TrambaHipError(f"{what}: {lib().tramba_last_error().decode()} (code {rc})")
+    return rc
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TrambaHipError(f"unsupported dtype {t.dtype}") from None
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise TrambaHipError("tramba_amd kernels need tensors on a HIP device (no CPU fallback)")
+        if not t.is_contiguous():
+            raise TrambaHipError("tramba_amd kernels need contiguous tensors")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t):
+    if t is None:
+        return None
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+# ----------------------------------------------------------------------------- tables
+_table_cache = {}
+
+
+def default_window(h: int) -> int:
+    return lib().tramba_default_window(h)
+
+
+def scan_table_host(family: str, h: int, w: int = None, param: int = 0) -> np.ndarray:
+    """(K, L) int32 flat pixel index per sequence position (host)."""
+    w = h if w is None else w
+    fam = FAMILY[family]
+    k = _check(lib().tramba_scan_family_k(fam), "scan_family_k")
+    out = np.empty((k, h * w), dtype=np.int32)
+    _check(lib().tramba_scan_table(fam, h, w, param, out.ctypes.data), f"scan_table({family},{h})")
+    return out
+
+
+def scan_table_inverse_host(table: np.ndarray):
+    k, l = table.shape
+    table = np.ascontiguousarray(table, dtype=np.int32)
+    ptr = np.empty(l + 1, dtype=np.int32)
+    idx = np.empty(k * l, dtype=np.int32)
+    _check(lib().tramba_scan_table_inverse(table.ctypes.data, k, l, ptr.ctypes.data, idx.ctypes.data),
+           "scan_table_inverse")
+    return ptr, idx
+
+
+class ScanOrder:
+    """Device-resident scan table + its inverse (CSR) for one (family, size, device)."""
+
+    def __init__(self, family, h, w, param, device):
+        host = scan_table_host(family, h, w, param)
+        ptr, idx = scan_table_inverse_host(host)
+        self.family, self.h, self.w, self.k, self.l = family, h, w, host.shape[0], host.shape[1]
+        self.table = torch.from_numpy(host).to(device)
+        self.inv_ptr = torch.from_numpy(ptr).to(device)
+        self.inv_idx = torch.from_numpy(idx).to(device)
+
+
+def scan_order(family: str, h: int, w: int, device, param: int = 0) -> ScanOrder:
+    key = (family, h, w, param, str(device))
+    so = _table_cache.get(key)
+    if so is None:
+        so = _table_cache[key] = ScanOrder(family, h, w, param, device)
+    return so
+
+
+# ----------------------------------------------------------------------------- profiling
+def profile_enable(which: int, on: bool):
+    _check(lib().tramba_profile_enable(which, int(on)), "profile_enable")
+
+
+def profile_read(which: int):
+    ms, units = ctypes.c_double(), ctypes.c_double()
+    n = _check(lib().tramba_profile_read(which, ctypes.byref(ms), ctypes.byref(units)), "profile_read")
+    return n, ms.value, units.value
+
+
+# ----------------------------------------------------------------------------- L0 / L1 boundary ops
+def selective_scan_nchunk(l: int, dtype: torch.dtype) -> int:
+    return lib().tramba_selective_scan_nchunk(l, _DT[dtype])
+
+
+def selective_scan_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus=True, oflex=True, want_ckpt=True):
+    _dev(u, delta, A, B, C, D, delta_bias)
+    nb, kd, l = u.shape
+    k, n = B.shape[1], B.shape[2]
+    if delta.shape != u.shape or A.shape != (kd, n) or B.shape != (nb, k, n, l) or C.shape != B.shape:
+        raise TrambaHipError(f"selective_scan_fwd: inconsistent shapes u{tuple(u.shape)} delta{tuple(delta.shape)} "
+                             f"A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(C.shape)}")
+    if not (delta.dtype == B.dtype == C.dtype == u.dtype):
+        raise TrambaHipError("selective_scan_fwd: u, delta, B, C must share a dtype")
+    out = torch.empty((nb, kd, l), dtype=torch.float32 if oflex else u.dtype, device=u.device)
+    ckpt = None
+    if want_ckpt:
+        ckpt = torch.empty((nb, kd, selective_scan_nchunk(l, u.dtype), n), dtype=torch.float32, device=u.device)
+    A, D, delta_bias = _f32(A), _f32(D), _f32(delta_bias)
+    _check(lib().tramba_selective_scan_fwd(
+        _ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(delta_bias), _ptr(out), _ptr(ckpt),
+        nb, kd, k, n, l, dt(u), dt(out), int(delta_softplus), _stream()), "selective_scan_fwd")
+    return out, ckpt
+
+
+def selective_scan_bwd(u, delta, A, B, C, D, delta_bias, dout, ckpt, delta_softplus=True):
+    _dev(u, delta, A, B, C, D, delta_bias, dout, ckpt)
+    nb, kd, l = u.shape
+    k, n = B.shape[1], B.shape[2]
+    A32, D32, b32 = _f32(A), _f32(D), _f32(delta_bias)
+    dout = dout.float().contiguous()
+    du, ddelta = torch.empty_like(u), torch.empty_like(delta)
+    dA = torch.zeros((kd, n), dtype=torch.float32, device=u.device)
+    dB = torch.zeros((nb, k, n, l), dtype=torch.float32, device=u.device)
+    dC = torch.zeros_like(dB)
+    dD = torch.zeros(kd, dtype=torch.float32, device=u.device) if D is not None else None
+    dbias = torch.zeros(kd, dtype=torch.float32, device=u.device) if delta_bias is not None else None
+    _check(lib().tramba_selective_scan_bwd(
+        _ptr(u), _ptr(delta), _ptr(A32), _ptr(B), _ptr(C), _ptr(D32), _ptr(b32), _ptr(dout), _ptr(ckpt),
+        _ptr(du), _ptr(ddelta), _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(dbias),
+        nb, kd, k, n, l, dt(u), int(delta_softplus), _stream()), "selective_scan_bwd")
+    return du, ddelta, dA, dB, dC, dD, dbias
+
+
+def cross_scan(x, order: ScanOrder):
+    """x: (B, C, H, W) or (B, C, L) contiguous NCHW -> (B, K, C, L)."""
+    _dev(x)
+    b, c = x.shape[0], x.shape[1]
+    l = order.l
+    xs = torch.empty((b, order.k, c, l), dtype=x.dtype, device=x.device)
+    _check(lib().tramba_cross_scan(_ptr(x), _ptr(order.table), _ptr(xs), b, c, l, order.k, dt(x), _stream()),
+           "cross_scan")
+    return xs
+
+
+def cross_merge(ys, order: ScanOrder):
+    """ys: (B, K, C, L) -> (B, C, L)."""
+    _dev(ys)
+    b, k, c, l = ys.shape
+    if k != order.k or l != order.l:
+        raise TrambaHipError(f"cross_merge: ys {tuple(ys.shape)} does not match table K={order.k} L={order.l}")
+    y = torch.empty((b, c, l), dtype=ys.dtype, device=ys.device)
+    _check(lib().tramba_cross_merge(_ptr(ys), _ptr(order.inv_ptr), _ptr(order.inv_idx), _ptr(y), b, c, l, k,
+                                    dt(ys), _stream()), "cross_merge")
+    return y
+
+
+# ----------------------------------------------------------------------------- channels-last kernels
+def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch.float32):
+    """x: (B, L, D); xdbl: (B, L, K*(R+2)) f32 -> ys (B, K, L, D)."""
+    _dev(x, xdbl, dt_w, dt_bias, A, Ds)
+    b, l, d = x.shape
+    k, r = order.k, dt_w.shape[-1]
+    if xdbl.dtype != torch.float32 or xdbl.shape != (b, l, k * (r + 2)):
+        raise TrambaHipError(f"ss2d_scan_cl: xdbl must be f32 (B,L,K*(R+2)), got {xdbl.dtype} {tuple(xdbl.shape)}")
+    if l != order.l or dt_w.shape != (k, d, r) or A.numel() != k * d or Ds.numel() != k * d or dt_bias.numel() != k * d:
+        raise TrambaHipError("ss2d_scan_cl: parameter shapes do not match (K, D, R)")
+    ys = torch.empty((b, k, l, d), dtype=ys_dtype, device=x.device)
+    _check(lib().tramba_ss2d_scan_cl(_ptr(x), _ptr(xdbl), _ptr(order.table), _ptr(dt_w), _ptr(dt_bias), _ptr(A),
+                                     _ptr(Ds), _ptr(ys), b, l, d, k, r, dt(x), dt(ys), _stream()), "ss2d_scan_cl")
+    return ys
+
+
+def ss2d_merge_norm_cl(ys, order: ScanOrder, ln_w, ln_b, eps, act, out_dtype):
+    _dev(ys, ln_w, ln_b)
+    b, k, l, d = ys.shape
+    y = torch.empty((b, l, d), dtype=out_dtype, device=ys.device)
+    _check(lib().tramba_ss2d_merge_norm_cl(_ptr(ys), _ptr(order.inv_ptr), _ptr(order.inv_idx), _ptr(ln_w),
+                                           _ptr(ln_b), _ptr(y), b, l, d, k, eps, act, dt(ys), dt(y), _stream()),
+           "ss2d_merge_norm_cl")
+    return y
+
+
+def layernorm_cl(x, w, b, eps=1e-5, act=ACT_NONE):
+    """x: (..., C) contiguous."""
+    _dev(x, w, b)
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    _check(lib().tramba_layernorm_cl(_ptr(x), _ptr(w), _ptr(b), _ptr(y), x.numel() // c, c, eps, act, dt(x),
+                                     _stream()), "layernorm_cl")
+    return y
+
+
+def shuffle_norm_cl(x, w, b, p, eps=1e-5):
+    """x: (B, H, W, P*P*C) -> (B, H*P, W*P, C), pixel-shuffle + LayerNorm over C."""
+    _dev(x, w, b)
+    bb, h, wd, cc = x.shape
+    c = cc // (p * p)
+    y = torch.empty((bb, h * p, wd * p, c), dtype=x.dtype, device=x.device)
+    _check(lib().tramba_shuffle_norm_cl(_ptr(x), _ptr(w), _ptr(b), _ptr(y), bb, h, wd, c, p, eps, dt(x), _stream()),
+           "shuffle_norm_cl")
+    return y
+
+
+def dwconv_cl(x, w, bias, act=ACT_NONE):
+    """x: (B, H, W, C); w: (C, 1, ks, ks) or (C, ks, ks) f32."""
+    _dev(x, w, bias)
+    bb, h, wd, c = x.shape
+    ks = w.shape[-1]
+    y = torch.empty_like(x)
+    _check(lib().tramba_dwconv_cl(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), bb, h, wd, c, ks, act, dt(x), _stream()),
+           "dwconv_cl")
+    return y
+
+
+def dwms_cl(x, w3, b3, w5, b5, w7, b7):
+    _dev(x, w3, b3, w5, b5, w7, b7)
+    bb, h, wd, c = x.shape
+    y = torch.empty_like(x)
+    _check(lib().tramba_dwms_cl(_ptr(x), _ptr(w3), _ptr(b3), _ptr(w5), _ptr(b5), _ptr(w7), _ptr(b7), _ptr(y),
+                                bb, h, wd, c, dt(x), _stream()), "dwms_cl")
+    return y
+
+
+def dct_split_cl(x, wx, wy):
+    """x: (B, n, n, C) -> (high, low), each (B, n/2, n/2, C)."""
+    _dev(x, wx, wy)
+    bb, n, n2, c = x.shape
+    if n != n2 or n % 2:
+        raise TrambaHipError(f"dct_split_cl: need an even square map, got {n}x{n2}")
+    tmp = torch.empty((bb, n, n, c), dtype=torch.float32, device=x.device)
+    high = torch.empty((bb, n // 2, n // 2, c), dtype=x.dtype, device=x.device)
+    low = torch.empty_like(high)
+    _check(lib().tramba_dct_split_cl(_ptr(x), _ptr(wx), _ptr(wy), _ptr(tmp), _ptr(high), _ptr(low), bb, n, c,
+                                     dt(x), _stream()), "dct_split_cl")
+    return high, low
+
+
+def linear_cl(x, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
+    """x: (..., K); w: (N, K) same dtype; -> (..., N)."""
+    _dev(x, w, bias, residual)
+    k = x.shape[-1]
+    n = w.shape[0]
+    m = x.numel() // k
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    y = torch.empty(x.shape[:-1] + (n,), dtype=out_dtype, device=x.device)
+    if w.dtype != x.dtype or w.shape[1] != k:
+        raise TrambaHipError("linear_cl: weight dtype/shape mismatch")
+    _check(lib().tramba_linear_cl(_ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), m, n, k, act, dt(x),
+                                  dt(y), _stream()), "linear_cl")
+    return y

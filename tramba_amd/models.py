@@ -1,0 +1,281 @@
+"""Model assembly with the reference's module surface (Trambav6.py, Trambav6_enc.py, get_model.py).
+
+``BaseUMamba.forward(x:(B,3,S,S)) -> [logits...]`` (last = full resolution), parameter names
+``vssm_encoder.* / encoder.* / decoder.*`` (train.py:266-269 splits the optimizer on the substring
+"encoder"), 679 state_dict entries for Tramba-V so ``load_state_dict(strict=True)`` of a reference
+checkpoint works (test_TSOD.py:36-38).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+from .modules import (FinalPatchExpand_X4, FreqBlockv6, LayerNorm2d, Linear2d, MultiScaleDecoderBlock, PatchExpand,
+                      VSSMEncoder, _init_weights, _need_device, from_cl, load_pretrained_Base, to_cl)
+from .ops import CrossMerge_Line, CrossScan_Line
+
+
+class VSSMDecoder(nn.Module):
+    """Trambav6.py:13-139 and Trambav6_enc.py:27-159 (they differ only in the in-features of
+    ``concat_back_dim``: 2*skip vs below//2 + skip, selected by ``concat_from_below``)."""
+
+    def __init__(self, deep_supervision, features_per_stage=None, drop_path_rate=0.0, depths=None, img_size=384,
+                 channel_first=True, concat_from_below=False, scan=CrossScan_Line, merge=CrossMerge_Line):
+        super().__init__()
+        assert channel_first
+        chans = list(features_per_stage)
+        self.deep_supervision = deep_supervision
+        n_stages = len(chans)
+        dpr = [x.item() for x in torch.linspace(drop_path_rate, 0, (n_stages - 1) * 2)]
+        depths = [2, 2, 2, 2] if depths is None else depths
+        res0 = img_size // 2 ** len(depths)
+        self.channel_first = True
+        self.stage_layers = nn.ModuleList()
+        self.expand_layers = nn.ModuleList()
+        self.guide_layers = nn.ModuleList()
+        self.seg_layers = nn.ModuleList()
+        self.concat_back_dim = nn.ModuleList()
+        skip = chans[0]
+        for stage in range(1, n_stages):
+            below, skip = chans[-stage], chans[-(stage + 1)]
+            self.expand_layers.append(PatchExpand(dim=below, dim_scale=2, norm_layer=LayerNorm2d, channel_first=True))
+            r = res0 * (2 ** (stage - 1))
+            self.guide_layers.append(FreqBlockv6(dim=skip, num_heads=4, input_resolution=(r, r), mlp_ratio=4.0,
+                                                 drop_path=0.0, norm_layer=LayerNorm2d))
+            blocks = [MultiScaleDecoderBlock(hidden_dim=skip, drop_path=dp, norm_layer=LayerNorm2d, channel_first=True,
+                                             scan=scan, merge=merge)
+                      for dp in dpr[sum(depths[:stage - 1]):sum(depths[:stage])]]
+            self.stage_layers.append(nn.Sequential(OrderedDict(blocks=nn.Sequential(*blocks))))
+            self.seg_layers.append(nn.Conv2d(skip, 1, 1, 1, 0, bias=True))
+            cat_in = (below // 2 + skip) if concat_from_below else 2 * skip
+            self.concat_back_dim.append(Linear2d(cat_in, skip))
+        self.expand_layers.append(FinalPatchExpand_X4(dim=chans[0], dim_scale=4, norm_layer=LayerNorm2d, channel_first=True))
+        self.stage_layers.append(nn.Identity())
+        self.seg_layers.append(nn.Conv2d(skip, 1, 1, 1, 0, bias=True))
+        self.apply(_init_weights)
+
+    @staticmethod
+    def _seg_cl(conv: nn.Conv2d, x):
+        """1x1 conv C -> 1 on a channels-last map; returns NCHW logits (B,1,H,W)."""
+        w = conv.weight.view(1, -1).to(x.dtype)
+        y = F.linear(x, w, conv.bias.to(x.dtype))
+        return y.permute(0, 3, 1, 2)
+
+    def _forward_cl(self, skips_cl):
+        """skips_cl: [image, s1..sn] with s* channels-last.  Trambav6.py:114-139."""
+        x_low = skips_cl[-1]
+        outs = []
+        n = len(self.stage_layers)
+        for s in range(n):
+            x = self.expand_layers[s]._forward_cl(x_low)
+            if s < n - 1:
+                mid = self.guide_layers[s]._forward_cl(skips_cl[-(s + 2)])
+                x = self.concat_back_dim[s]._forward_cl(torch.cat((x, mid), dim=-1))
+                for blk in self.stage_layers[s].blocks:
+                    x = blk._forward_cl(x)
+            if self.deep_supervision or s == n - 1:
+                outs.append(self._seg_cl(self.seg_layers[s], x))
+            x_low = x
+        return outs if self.deep_supervision else outs[0]
+
+    def forward(self, skips):
+        return self._forward_cl([skips[0]] + [to_cl(s) for s in skips[1:]])
+
+
+class BaseUMamba(nn.Module):
+    """Trambav6.py:142-165 (Tramba-V)."""
+
+    def __init__(self, vss_args, decoder_args, use_pretrain=True, pretrained_path=""):
+        super().__init__()
+        self.vssm_encoder = VSSMEncoder(**vss_args)
+        self.decoder = VSSMDecoder(**decoder_args)
+        self.compute_dtype = None
+        if use_pretrain:
+            load_pretrained_Base(self.vssm_encoder, ckpt_path=pretrained_path)
+
+    def forward(self, x):
+        _need_device(x)
+        if self.compute_dtype is not None:
+            x = x.to(self.compute_dtype)
+        skips = self.vssm_encoder._forward_cl(x)
+        out = self.decoder._forward_cl(skips)
+        if self.compute_dtype is not None:
+            out = [o.float() for o in out] if isinstance(out, list) else out.float()
+        return out
+
+    @torch.no_grad()
+    def freeze_encoder(self):
+        for name, p in self.vssm_encoder.named_parameters():
+            if "patch_embed" not in name:
+                p.requires_grad = False
+
+    @torch.no_grad()
+    def unfreeze_encoder(self):
+        for p in self.vssm_encoder.parameters():
+            p.requires_grad = True
+
+
+def bulid_model(deep_supervision=True, use_pretrain=True, img_size=384, dims=128, depths=[2, 2, 2, 2],
+                pretrained_path=""):
+    """Trambav6.py:168-200 (the reference's spelling is kept: callers import ``bulid_model``)."""
+    vss_args = dict(patch_size=4, in_chans=3, depths=[2, 2, 15, 2], dims=dims, drop_path_rate=0.6, patch_norm=True,
+                    norm_layer="LN2D", posembed=False, imgsize=img_size)
+    decoder_args = dict(deep_supervision=deep_supervision, features_per_stage=[dims, dims * 2, dims * 4, dims * 8],
+                        depths=depths, img_size=img_size, drop_path_rate=0.2)
+    return BaseUMamba(vss_args, decoder_args, use_pretrain=use_pretrain, pretrained_path=pretrained_path)
+
+
+# ----------------------------------------------------------------------------- Tramba-R (ResNet50 encoder)
+class Bottleneck(nn.Module):
+    """resnet_encoder.py:62-79.  Stock conv/BN: runs on MIOpen (out of kernel scope)."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=(3 * dilation - 1) // 2,
+                               bias=False, dilation=dilation)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        out = F.relu(self.bn2(self.conv2(out)), inplace=True)
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return F.relu(out + x, inplace=True)
+
+
+class ResNet(nn.Module):
+    """resnet_encoder.py:81-110 (ResNet50 trunk; returns out5..out1 like the reference).  The
+    reference loads a hard-coded checkpoint path in __init__ (:113); here weights come from
+    ``load_state_dict`` / ``pretrained_path`` instead."""
+
+    def __init__(self, cfg=None, pretrained_path=None):
+        super().__init__()
+        self.cfg = cfg
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = self.make_layer(64, 3, stride=1, dilation=1)
+        self.layer2 = self.make_layer(128, 4, stride=2, dilation=1)
+        self.layer3 = self.make_layer(256, 6, stride=2, dilation=1)
+        self.layer4 = self.make_layer(512, 3, stride=2, dilation=1)
+        if pretrained_path:
+            self.load_state_dict(torch.load(pretrained_path, map_location="cpu"), strict=False)
+
+    def make_layer(self, planes, blocks, stride, dilation):
+        downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                   nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample, dilation=dilation)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes, dilation=dilation))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        out1 = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        out1 = F.max_pool2d(out1, kernel_size=3, stride=2, padding=1)
+        out2 = self.layer1(out1)
+        out3 = self.layer2(out2)
+        out4 = self.layer3(out3)
+        out5 = self.layer4(out4)
+        return out5, out4, out3, out2, out1
+
+
+class BaseUMambaEnc(nn.Module):
+    """Trambav6_enc.py:162-231.  Tramba-R (ResNet50) is built in; the Swin-B / PVTv2-b4 encoders of
+    Tramba-S / Tramba-P are outside this round's scope and raise."""
+
+    def __init__(self, enc_type, decoder_args, pretrained_path=None):
+        super().__init__()
+        self.enc_type = enc_type
+        self.compute_dtype = None
+        if enc_type in ("Tramba-R-TSOD", "Tramba-R-SOD"):
+            self.encoder = ResNet(pretrained_path=pretrained_path)
+            decoder_args = dict(decoder_args, features_per_stage=[256, 512, 1024], depths=[2, 2, 2],
+                                concat_from_below=True)
+            self.decoder = VSSMDecoder(**decoder_args)
+        elif enc_type in ("Tramba-S-TSOD", "Tramba-S-SOD", "Tramba-P-TSOD", "Tramba-P-SOD"):
+            raise NotImplementedError(f"{enc_type}: Swin-B / PVTv2 encoders are not part of the MI355X hot path yet")
+        else:
+            raise ValueError(f"Unsupported encoder type: {enc_type}")
+
+    def forward(self, x):
+        _need_device(x)
+        if self.compute_dtype is not None:
+            x = x.to(self.compute_dtype)
+        xc = x.contiguous(memory_format=torch.channels_last)
+        outs = self.encoder(xc)
+        skips = [x] + [to_cl(o) for o in outs[1:-1][::-1]]  # Trambav6_enc.py:212-213
+        out = self.decoder._forward_cl(skips)
+        if self.compute_dtype is not None:
+            out = [o.float() for o in out]
+        return out
+
+    @torch.no_grad()
+    def freeze_encoder(self):
+        for name, p in self.encoder.named_parameters():
+            if "patch_embed" not in name:
+                p.requires_grad = False
+
+    @torch.no_grad()
+    def unfreeze_encoder(self):
+        for p in self.encoder.parameters():
+            p.requires_grad = True
+
+
+def bulid_model_enc(enc_type, deep_supervision=True, img_size=384, pretrained_path=None):
+    """Trambav6_enc.py:233-248."""
+    decoder_args = dict(deep_supervision=deep_supervision, features_per_stage=None, depths=None, img_size=img_size,
+                        drop_path_rate=0.2)
+    return BaseUMambaEnc(enc_type, decoder_args, pretrained_path=pretrained_path)
+
+
+def build(model_name, args):
+    """get_model.py:2-31."""
+    if model_name in ("Tramba-V-TSOD", "Tramba-V-SOD"):
+        path = getattr(args, "pretrained_path", "") or ""
+        return bulid_model(deep_supervision=True, use_pretrain=bool(path), img_size=args.img_size, dims=128,
+                           depths=[2, 2, 2, 2], pretrained_path=path)
+    if model_name in ("Tramba-S-TSOD", "Tramba-P-TSOD", "Tramba-R-TSOD", "Tramba-S-SOD", "Tramba-P-SOD", "Tramba-R-SOD"):
+        return bulid_model_enc(enc_type=model_name, deep_supervision=True, img_size=args.img_size)
+    if model_name == "BaseUMamba-SOD":
+        raise NotImplementedError("BaseUMamba-SOD is the reference's ablation baseline (out of scope, SURVEY 2 #10)")
+    return None
+
+
+# ----------------------------------------------------------------------------- precision policy
+@torch.no_grad()
+def prepare_inference(model: nn.Module, dtype=torch.bfloat16):
+    """Put the model in eval mode with `dtype` activations.
+
+    Policy (the reference is fp32-only; this is the MI355X bf16/fp16 policy):
+    GEMM / dense-conv weights are stored in `dtype`; everything numerically delicate stays fp32 --
+    LayerNorm affine, depth-wise stencil taps, dt_proj, dt bias, A_logs, Ds, DCT tables, all biases,
+    and every accumulation / scan state inside the kernels.
+    """
+    model.eval()
+    if dtype == torch.float32:
+        model.compute_dtype = None
+        return model
+    for m in model.modules():
+        if isinstance(m, Linear2d):
+            m.weight.data = m.weight.data.to(dtype)
+        elif isinstance(m, nn.Conv2d) and m.groups == 1:
+            m.weight.data = m.weight.data.to(dtype)
+            if m.bias is not None:
+                m.bias.data = m.bias.data.to(dtype)
+        elif isinstance(m, nn.BatchNorm2d):
+            m.to(dtype)
+    from .modules import SS2D
+    for m in model.modules():
+        if isinstance(m, SS2D):
+            m.x_proj_weight.data = m.x_proj_weight.data.to(dtype)
+    model.compute_dtype = dtype
+    return model

@@ -1,0 +1,721 @@
+"""Host-side mirror of the reference's nn.Module surface for the Tramba hot path.
+
+Same class names, constructor arguments, parameter/buffer names and shapes as the reference
+(state_dict-compatible: 679 entries for Tramba-V), same ``forward(x:(B,C,H,W)) -> (B,C,H,W)``
+contracts -- but a different machine underneath:
+
+* activations live CHANNELS-LAST ((B, H, W, C) contiguous) between modules; a module's public
+  ``forward`` accepts/returns NCHW-shaped tensors whose memory is channels-last, so chaining
+  modules never copies.  ``_forward_cl`` is the internal entry working on (B,H,W,C).
+* with autograd off (inference) every op on the path is a hand-written HIP kernel from
+  libtramba_hip (tramba_amd/hip.py); the SS2D core runs fused (no (B,K,D,L) gather, no `delta`
+  tensor, merge + out_norm + GELU in one kernel).
+* with autograd on (training) the SS2D core runs through the reference's own plugin path --
+  ``scan.apply -> grouped projections -> SelectiveScanOflex.apply -> merge.apply`` -- whose
+  gather/merge and selective-scan forward AND backward are HIP kernels; the surrounding
+  LayerNorm / depth-wise conv / GELU use stock PyTorch-ROCm ops for their autograd.
+* there is no CPU path: a CPU tensor raises.
+
+Reference files mirrored: Models/modules.py:10-27,134-153,183-274,678-696; Models/vmamba.py:18-323
+(SS2D), :327-396 (VSSBlock), :399-518 (VSSMEncoder), :595-704 (DWConv, DWMSMlp,
+MultiScaleDecoderBlock); Models/DCT_2D.py; Models/freq_mamba.py; Models/mamba_init.py.
+"""
+import math
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+from .ops import (CrossMerge, CrossMerge_Dilation, CrossMerge_Line, CrossMerge_Window, CrossScan,
+                  CrossScan_Dilation, CrossScan_Line, CrossScan_Window, SelectiveScanOflex)
+
+# GEMMs: "hip" = libtramba_hip MFMA kernel with fused epilogue, "blas" = torch.matmul (hipBLASLt)
+GEMM_BACKEND = os.environ.get("TRAMBA_GEMM", "hip")
+# dtype of the (B,K,L,D) scan output between the fused scan and the merge kernel in inference:
+# "f32" mirrors the reference's oflex fp32 output, "act" stores it in the activation dtype
+YS_DTYPE = os.environ.get("TRAMBA_YS", "f32")
+
+
+def to_cl(x: torch.Tensor) -> torch.Tensor:
+    """NCHW-shaped -> (B,H,W,C) contiguous (free when x is already channels-last in memory)."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def from_cl(x: torch.Tensor) -> torch.Tensor:
+    """(B,H,W,C) contiguous -> NCHW-shaped view with channels-last strides."""
+    return x.permute(0, 3, 1, 2)
+
+
+def _need_device(x):
+    if not x.is_cuda:
+        raise RuntimeError("tramba_amd runs on a HIP device only (MI355X); got a CPU tensor. "
+                           "There is deliberately no CPU fallback.")
+
+
+def _infer(*tensors) -> bool:
+    """True when no autograd graph is needed -> all-HIP inference kernels."""
+    if not torch.is_grad_enabled():
+        return True
+    return not any(t is not None and t.requires_grad for t in tensors)
+
+
+def _f32(p):
+    return hip._f32(p)
+
+
+def _act_torch(x, act):
+    if act == hip.ACT_GELU:
+        return F.gelu(x)
+    if act == hip.ACT_SILU:
+        return F.silu(x)
+    return x
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm.models.layers.DropPath semantics)."""
+
+    def __init__(self, drop_prob: float = 0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        return x * mask.div_(keep)
+
+    def extra_repr(self):
+        return f"drop_prob={self.drop_prob}"
+
+
+# ----------------------------------------------------------------------------- basic layers
+class Linear2d(nn.Linear):
+    """1x1 convolution stored as an (out,in) matrix (modules.py:10-19)."""
+
+    def _forward_cl(self, x, act=hip.ACT_NONE, residual=None, out_dtype=None):
+        w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
+        if _infer(x, self.weight) and GEMM_BACKEND == "hip":
+            return hip.linear_cl(x, w.detach(), _f32(self.bias), residual, act, out_dtype)
+        b = self.bias
+        if b is not None and b.dtype != x.dtype:
+            b = b.to(x.dtype)
+        y = _act_torch(F.linear(x, w, b), act)
+        if residual is not None:
+            y = y + residual
+        return y if out_dtype is None else y.to(out_dtype)
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        key = prefix + "weight"
+        if key in state_dict:  # accept (out,in,1,1) conv checkpoints like the reference
+            state_dict[key] = state_dict[key].view(self.weight.shape)
+        return super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
+                                             unexpected_keys, error_msgs)
+
+
+class LayerNorm2d(nn.LayerNorm):
+    """LayerNorm over C of an NCHW tensor (modules.py:22-27) -- no permutes needed in channels-last."""
+
+    def _forward_cl(self, x, act=hip.ACT_NONE):
+        if _infer(x, self.weight):
+            return hip.layernorm_cl(x, _f32(self.weight), _f32(self.bias), self.eps, act)
+        y = F.layer_norm(x.float(), self.normalized_shape, self.weight.float(), self.bias.float(), self.eps)
+        return _act_torch(y, act).to(x.dtype)
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+
+class Permute(nn.Module):
+    def __init__(self, *args):
+        super().__init__()
+        self.args = args
+
+    def forward(self, x):
+        return x.permute(*self.args).contiguous()
+
+
+class Mlp(nn.Module):
+    """modules.py:134-153."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0,
+                 channels_first=False):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        assert channels_first, "the Tramba path is channel-first everywhere (Trambav6.py:21,34)"
+        self.fc1 = Linear2d(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = Linear2d(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def _forward_cl(self, x, residual=None):
+        h = self.fc1._forward_cl(x, act=hip.ACT_GELU)
+        h = self.drop(h)
+        return self.drop(self.fc2._forward_cl(h, residual=residual))
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+
+class _ExpandShuffleNorm(nn.Module):
+    """1x1 expand -> 'b (p1 p2 c) h w -> b c (h p1) (w p2)' -> LayerNorm2d(c)."""
+
+    scale = 2
+
+    def _shuffle_norm(self, xe):
+        p = self.scale
+        if _infer(xe, self.norm.weight):
+            return hip.shuffle_norm_cl(xe, _f32(self.norm.weight), _f32(self.norm.bias), p, self.norm.eps)
+        b, h, w, cc = xe.shape
+        c = cc // (p * p)
+        y = xe.view(b, h, w, p, p, c).permute(0, 1, 3, 2, 4, 5).reshape(b, h * p, w * p, c)
+        return self.norm._forward_cl(y)
+
+    def _forward_cl(self, x):
+        assert x.shape[1] == x.shape[2], "square maps only (modules.py:212)"
+        return self._shuffle_norm(self.expand._forward_cl(x))
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+
+class PatchExpand(_ExpandShuffleNorm):
+    """modules.py:183-221."""
+
+    def __init__(self, dim, dim_scale=2, norm_layer=LayerNorm2d, channel_first=True):
+        super().__init__()
+        assert channel_first and dim_scale == 2
+        self.dim = dim
+        self.channel_first = channel_first
+        self.expand = Linear2d(dim, 2 * dim, bias=False)
+        self.norm = norm_layer(dim // dim_scale)
+        self.scale = 2
+
+
+class FinalPatchExpand_X4(_ExpandShuffleNorm):
+    """modules.py:224-274."""
+
+    def __init__(self, dim, dim_scale=4, norm_layer=LayerNorm2d, channel_first=True):
+        super().__init__()
+        assert channel_first
+        self.dim = dim
+        self.channel_first = channel_first
+        self.dim_scale = dim_scale
+        self.expand = Linear2d(dim, (dim_scale ** 2) * dim, bias=False)
+        self.output_dim = dim
+        self.norm = norm_layer(self.output_dim)
+        self.scale = dim_scale
+
+
+class FreqExpand2D(_ExpandShuffleNorm):
+    """modules.py:678-696."""
+
+    def __init__(self, dim, norm_layer=LayerNorm2d, channel_first=True):
+        super().__init__()
+        assert channel_first
+        self.dim = dim
+        self.channel_first = channel_first
+        self.expand = Linear2d(dim, 4 * dim, bias=False)
+        self.norm = norm_layer(dim)
+        self.scale = 2
+
+
+# ----------------------------------------------------------------------------- DCT split
+def _dct_filter(n: int) -> torch.Tensor:
+    """DCT_2D.py:37-45: orthonormal DCT-II basis, built in Python floats, stored fp32."""
+    m = torch.zeros(n, n)
+    for v in range(n):
+        s = math.sqrt(2.0) if v != 0 else 1.0
+        for j in range(n):
+            m[v, j] = math.cos(math.pi * (0.5 + j) * v / n) / math.sqrt(n) * s
+    return m
+
+
+class DCT2DSpatialTransformLayer_x(nn.Module):
+    def __init__(self, width):
+        super().__init__()
+        self.register_buffer("weight", _dct_filter(width))
+
+
+class DCT2DSpatialTransformLayer_y(nn.Module):
+    def __init__(self, height):
+        super().__init__()
+        self.register_buffer("weight", _dct_filter(height))
+
+
+class DCT2D(nn.Module):
+    """DCT_2D.py:6-29: Y = Wy X Wx^T; returns (high = HH quadrant, low = LL quadrant)."""
+
+    def __init__(self, height, width):
+        super().__init__()
+        self.dct_x = DCT2DSpatialTransformLayer_x(width)
+        self.dct_y = DCT2DSpatialTransformLayer_y(height)
+
+    def _forward_cl(self, x):
+        wx, wy = self.dct_x.weight, self.dct_y.weight
+        if x.shape[1] != wy.shape[0] or x.shape[2] != wx.shape[0]:
+            raise RuntimeError(f"DCT2D built for {wy.shape[0]}x{wx.shape[0]}, got {x.shape[1]}x{x.shape[2]}")
+        if _infer(x):
+            return hip.dct_split_cl(x, _f32(wx), _f32(wy))
+        y = torch.einsum("bhwc,uw->bhuc", x.float(), wx.float())
+        y = torch.einsum("bhuc,vh->bvuc", y, wy.float()).to(x.dtype)
+        hh, hw = y.shape[1] // 2, y.shape[2] // 2
+        return y[:, hh:, hw:].contiguous(), y[:, :hh, :hw].contiguous()
+
+    def forward(self, x):
+        _need_device(x)
+        high, low = self._forward_cl(to_cl(x))
+        return from_cl(high), from_cl(low)
+
+
+# ----------------------------------------------------------------------------- mamba parameter init
+def Dt_init(dt_rank, d_inner, dt_scale=1.0, dt_init="random", dt_min=0.001, dt_max=0.1, dt_init_floor=1e-4):
+    """mamba_init.py:7-31."""
+    proj = nn.Linear(dt_rank, d_inner, bias=True)
+    std = dt_rank ** -0.5 * dt_scale
+    if dt_init == "constant":
+        nn.init.constant_(proj.weight, std)
+    elif dt_init == "random":
+        nn.init.uniform_(proj.weight, -std, std)
+    else:
+        raise NotImplementedError(dt_init)
+    dt = torch.exp(torch.rand(d_inner) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min)).clamp(min=dt_init_floor)
+    with torch.no_grad():
+        proj.bias.copy_(dt + torch.log(-torch.expm1(-dt)))  # inverse softplus
+    return proj
+
+
+def A_log_init(d_state, d_inner, copies=-1, device=None, merge=True):
+    """mamba_init.py:34-48 (S4D-real)."""
+    a = torch.arange(1, d_state + 1, dtype=torch.float32, device=device).repeat(d_inner, 1)
+    a_log = torch.log(a)
+    if copies > 0:
+        a_log = a_log.unsqueeze(0).repeat(copies, 1, 1)
+        if merge:
+            a_log = a_log.flatten(0, 1)
+    p = nn.Parameter(a_log.contiguous())
+    p._no_weight_decay = True
+    return p
+
+
+def D_init(d_inner, copies=-1, device=None, merge=True):
+    """mamba_init.py:51-60."""
+    d = torch.ones(d_inner, device=device)
+    if copies > 0:
+        d = d.unsqueeze(0).repeat(copies, 1)
+        if merge:
+            d = d.flatten(0, 1)
+    p = nn.Parameter(d.contiguous())
+    p._no_weight_decay = True
+    return p
+
+
+# ----------------------------------------------------------------------------- SS2D
+class SS2D(nn.Module):
+    """vmamba.py:18-323, forward_type v2 / channel_first / disable_z (the only configuration the
+    shipped models use).  ``scan`` / ``merge`` / ``k_group`` are the reference's plugin API."""
+
+    def __init__(self, d_model=96, d_state=16, ssm_ratio=2.0, dt_rank="auto", act_layer=nn.SiLU,
+                 d_conv=3, conv_bias=False, dropout=0.0, bias=False,
+                 dt_min=0.001, dt_max=0.1, dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, initialize="v0",
+                 forward_type="v2", channel_first=False, disable_z=True,
+                 scan=CrossScan, merge=CrossMerge, k_group=4, **kwargs):
+        super().__init__()
+        if not channel_first or not disable_z:
+            raise NotImplementedError("tramba_amd.SS2D implements the channel_first / disable_z configuration")
+        if act_layer is not nn.SiLU:
+            raise NotImplementedError("SS2D act_layer must be SiLU (fused into the depth-wise conv kernel)")
+        d_inner = int(ssm_ratio * d_model)
+        dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
+        self.channel_first = channel_first
+        self.with_dconv = d_conv > 1
+        self.disable_z = disable_z
+        self.d_state, self.d_inner, self.dt_rank, self.k_group = d_state, d_inner, dt_rank, k_group
+        self.scan, self.merge = scan, merge
+
+        self.out_norm = LayerNorm2d(d_inner)
+        self.in_proj = Linear2d(d_model, d_inner, bias=bias)
+        self.act = act_layer()
+        if self.with_dconv:
+            self.conv2d = nn.Conv2d(d_inner, d_inner, groups=d_inner, bias=conv_bias, kernel_size=d_conv,
+                                    padding=(d_conv - 1) // 2)
+        x_proj = [nn.Linear(d_inner, dt_rank + d_state * 2, bias=False) for _ in range(k_group)]
+        self.x_proj_weight = nn.Parameter(torch.stack([t.weight for t in x_proj], dim=0))  # (K, R+2N, D)
+        self.out_act = nn.GELU()
+        self.out_proj = Linear2d(d_inner, d_model, bias=bias)
+        self.dropout = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
+        if initialize != "v0":
+            raise NotImplementedError(initialize)
+        dt_projs = [Dt_init(dt_rank, d_inner, dt_scale, dt_init, dt_min, dt_max, dt_init_floor) for _ in range(k_group)]
+        self.dt_projs_weight = nn.Parameter(torch.stack([t.weight for t in dt_projs], dim=0))  # (K, D, R)
+        self.dt_projs_bias = nn.Parameter(torch.stack([t.bias for t in dt_projs], dim=0))  # (K, D)
+        self.A_logs = A_log_init(d_state, d_inner, copies=k_group, merge=True)  # (K*D, N)
+        self.Ds = D_init(d_inner, copies=k_group, merge=True)  # (K*D)
+
+    # -- the two core paths -----------------------------------------------------------------
+    def _fused_ok(self, x):
+        return (self.d_state == 1 and getattr(self.scan, "_tramba_family", None) is not None
+                and getattr(self.merge, "_tramba_family", None) == self.scan._tramba_family
+                and self.scan._tramba_k == self.k_group
+                and _infer(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs))
+
+    def _core_fused_cl(self, x):
+        """x (B,H,W,D) after conv+SiLU -> GELU(out_norm(merge(scan(...)))), all HIP."""
+        b, h, w, d = x.shape
+        k, r = self.k_group, self.dt_rank
+        order = hip.scan_order(self.scan._tramba_family, h, w, x.device)
+        xf = x.view(b, h * w, d)
+        wx = self.x_proj_weight.detach().reshape(k * (r + 2), d)
+        if wx.dtype != x.dtype:
+            wx = wx.to(x.dtype)
+        xdbl = hip.linear_cl(xf, wx, out_dtype=torch.float32)  # x_proj once, spatial order
+        a_neg = -torch.exp(self.A_logs.detach().float()).reshape(-1)
+        ys_dtype = torch.float32 if YS_DTYPE == "f32" else x.dtype
+        ys = hip.ss2d_scan_cl(xf, xdbl, order, _f32(self.dt_projs_weight), _f32(self.dt_projs_bias).reshape(-1),
+                              a_neg, _f32(self.Ds), ys_dtype)
+        y = hip.ss2d_merge_norm_cl(ys, order, _f32(self.out_norm.weight), _f32(self.out_norm.bias),
+                                   self.out_norm.eps, hip.ACT_GELU, x.dtype)
+        return y.view(b, h, w, d)
+
+    def _core_plugin_cl(self, x):
+        """Reference graph (vmamba.py:230-273) with the scan classes as plugins; autograd-capable."""
+        b, h, w, d = x.shape
+        k, r, n = self.k_group, self.dt_rank, self.d_state
+        l = h * w
+        xn = from_cl(x).contiguous()  # (B,D,H,W), NCHW contiguous as the plugin API expects
+        xs = self.scan.apply(xn)  # (B,K,D,L)
+        wx = self.x_proj_weight.to(xs.dtype)
+        x_dbl = F.conv1d(xs.view(b, -1, l), wx.view(-1, d, 1), groups=k)
+        dts, bs, cs = torch.split(x_dbl.view(b, k, -1, l), [r, n, n], dim=2)
+        dts = F.conv1d(dts.contiguous().view(b, -1, l), self.dt_projs_weight.to(xs.dtype).view(k * d, -1, 1), groups=k)
+        a_neg = -torch.exp(self.A_logs.float())
+        ys = SelectiveScanOflex.apply(
+            xs.view(b, -1, l), dts.contiguous().view(b, -1, l), a_neg, bs.contiguous().view(b, k, n, l),
+            cs.contiguous().view(b, k, n, l), self.Ds.float(), self.dt_projs_bias.view(-1).float(), True, 1, 1, True)
+        y = self.merge.apply(ys.view(b, k, -1, h, w))  # (B,D,L) fp32
+        y = to_cl(y.view(b, -1, h, w))
+        y = self.out_norm._forward_cl(y, act=hip.ACT_GELU)
+        return y.to(x.dtype)
+
+    def _forward_cl(self, x, residual=None):
+        x = self.in_proj._forward_cl(x)
+        if self.with_dconv:
+            if _infer(x, self.conv2d.weight):
+                x = hip.dwconv_cl(x, _f32(self.conv2d.weight), _f32(self.conv2d.bias), hip.ACT_SILU)
+            else:
+                wc = self.conv2d.weight.to(x.dtype)
+                bc = None if self.conv2d.bias is None else self.conv2d.bias.to(x.dtype)
+                x = to_cl(F.silu(F.conv2d(from_cl(x), wc, bc, padding=self.conv2d.padding, groups=wc.shape[0])))
+        else:
+            x = F.silu(x)
+        y = self._core_fused_cl(x) if self._fused_ok(x) else self._core_plugin_cl(x)
+        return self.dropout(self.out_proj._forward_cl(y, residual=residual))
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+
+class _ResidualBlock(nn.Module):
+    def _residual(self, x, branch, drop_path):
+        """x + drop_path(branch(x_normed)); the add is fused into the branch's last GEMM when possible."""
+        if isinstance(drop_path, DropPath) and drop_path.training and drop_path.drop_prob > 0.0:
+            return x + drop_path(branch(None))
+        return branch(x)
+
+
+class VSSBlock(_ResidualBlock):
+    """vmamba.py:327-396 (pre-norm): x += SS2D(LN(x)); x += Mlp(LN(x))."""
+
+    def __init__(self, hidden_dim, drop_path=0.0, norm_layer=LayerNorm2d, channel_first=True,
+                 ssm_d_state=1, ssm_ratio=2.0, ssm_dt_rank="auto", ssm_act_layer=nn.SiLU, ssm_conv=3,
+                 ssm_conv_bias=False, ssm_drop_rate=0.0, ssm_init="v0", forward_type="v05",
+                 mlp_ratio=4.0, mlp_act_layer=nn.GELU, mlp_drop_rate=0.0, post_norm=False, **kwargs):
+        super().__init__()
+        assert channel_first and not post_norm and ssm_ratio > 0 and mlp_ratio > 0
+        self.norm = norm_layer(hidden_dim)
+        self.op = SS2D(d_model=hidden_dim, d_state=ssm_d_state, ssm_ratio=ssm_ratio, dt_rank=ssm_dt_rank,
+                       act_layer=ssm_act_layer, d_conv=ssm_conv, conv_bias=ssm_conv_bias, dropout=ssm_drop_rate,
+                       initialize=ssm_init, forward_type=forward_type, channel_first=channel_first)
+        self.drop_path = DropPath(drop_path)
+        self.norm2 = norm_layer(hidden_dim)
+        self.mlp = Mlp(in_features=hidden_dim, hidden_features=int(hidden_dim * mlp_ratio), act_layer=mlp_act_layer,
+                       drop=mlp_drop_rate, channels_first=channel_first)
+
+    def _forward_cl(self, x):
+        x = self._residual(x, lambda res: self.op._forward_cl(self.norm._forward_cl(x), residual=res), self.drop_path)
+        x = self._residual(x, lambda res: self.mlp._forward_cl(self.norm2._forward_cl(x), residual=res), self.drop_path)
+        return x
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+
+class DWConv(nn.Module):
+    """vmamba.py:595-603."""
+
+    def __init__(self, in_channels, kernel_size, bias):
+        super().__init__()
+        self.dw_conv = nn.Conv2d(in_channels, in_channels, kernel_size, stride=1, padding=(kernel_size - 1) // 2,
+                                 bias=bias, groups=in_channels)
+
+    def _forward_cl(self, x):
+        c = self.dw_conv
+        if _infer(x, c.weight):
+            return hip.dwconv_cl(x, _f32(c.weight), _f32(c.bias), hip.ACT_NONE)
+        return to_cl(F.conv2d(from_cl(x), c.weight.to(x.dtype), None if c.bias is None else c.bias.to(x.dtype),
+                              padding=c.padding, groups=c.groups))
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+
+class DWMSMlp(nn.Module):
+    """vmamba.py:606-629: fc1 -> h + dw3(h) + dw5(h) + dw7(h) -> GELU -> fc2."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0,
+                 channels_first=False):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        assert channels_first
+        self.fc1 = Linear2d(in_features, hidden_features)
+        self.act = act_layer()
+        self.dwc3 = DWConv(hidden_features, 3, True)
+        self.dwc5 = DWConv(hidden_features, 5, True)
+        self.dwc7 = DWConv(hidden_features, 7, True)
+        self.fc2 = Linear2d(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def _forward_cl(self, x, residual=None):
+        h = self.fc1._forward_cl(x)
+        c3, c5, c7 = self.dwc3.dw_conv, self.dwc5.dw_conv, self.dwc7.dw_conv
+        if _infer(h, c3.weight, c5.weight, c7.weight):
+            g = hip.dwms_cl(h, _f32(c3.weight), _f32(c3.bias), _f32(c5.weight), _f32(c5.bias), _f32(c7.weight),
+                            _f32(c7.bias))
+        else:
+            g = F.gelu(h + self.dwc3._forward_cl(h) + self.dwc5._forward_cl(h) + self.dwc7._forward_cl(h))
+        g = self.drop(g)
+        return self.drop(self.fc2._forward_cl(g, residual=residual))
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+
+class MultiScaleDecoderBlock(_ResidualBlock):
+    """vmamba.py:632-704: Helix-SS2D (K=8) + multi-scale depth-wise MLP."""
+
+    def __init__(self, hidden_dim, drop_path=0.0, norm_layer=LayerNorm2d, channel_first=True,
+                 ssm_d_state=1, ssm_ratio=2.0, ssm_dt_rank="auto", ssm_act_layer=nn.SiLU, ssm_conv=3,
+                 ssm_conv_bias=False, ssm_drop_rate=0.0, ssm_init="v0", forward_type="v05",
+                 mlp_ratio=4.0, mlp_act_layer=nn.GELU, mlp_drop_rate=0.0, post_norm=False,
+                 scan=CrossScan_Line, merge=CrossMerge_Line, k_group=8, **kwargs):
+        super().__init__()
+        assert channel_first and not post_norm and ssm_ratio > 0 and mlp_ratio > 0
+        self.norm1 = norm_layer(hidden_dim)
+        self.op = SS2D(d_model=hidden_dim, d_state=ssm_d_state, ssm_ratio=ssm_ratio, dt_rank=ssm_dt_rank,
+                       act_layer=ssm_act_layer, d_conv=ssm_conv, conv_bias=ssm_conv_bias, dropout=ssm_drop_rate,
+                       initialize=ssm_init, forward_type=forward_type, channel_first=channel_first, disable_z=True,
+                       scan=scan, merge=merge, k_group=k_group)
+        self.drop_path = DropPath(drop_path)
+        self.norm2 = norm_layer(hidden_dim)
+        self.mlp = DWMSMlp(in_features=hidden_dim, hidden_features=int(hidden_dim * mlp_ratio), act_layer=mlp_act_layer,
+                           drop=mlp_drop_rate, channels_first=channel_first)
+
+    def _forward_cl(self, x):
+        x = self._residual(x, lambda res: self.op._forward_cl(self.norm1._forward_cl(x), residual=res), self.drop_path)
+        x = self._residual(x, lambda res: self.mlp._forward_cl(self.norm2._forward_cl(x), residual=res), self.drop_path)
+        return x
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+
+# ----------------------------------------------------------------------------- Dual-Frequency VSS
+class FreqSS2Dv6(nn.Module):
+    """freq_mamba.py:11-57: DCT split -> Hi-Fi (window scan) / Lo-Fi (dilated scan) SS2D -> sigmoid gate."""
+
+    def __init__(self, dim, input_resolution=None, norm_layer=LayerNorm2d,
+                 l_scan=CrossScan_Dilation, h_scan=CrossScan_Window,
+                 l_merge=CrossMerge_Dilation, h_merge=CrossMerge_Window):
+        super().__init__()
+        self.dim = dim
+        self.DCT2D = DCT2D(input_resolution[0], input_resolution[1])
+        ss = dict(d_model=dim, d_state=1, ssm_ratio=2.0, dt_rank="auto", act_layer=nn.SiLU, d_conv=3, conv_bias=False,
+                  dropout=0.0, initialize="v0", channel_first=True, bias=False, disable_z=True, k_group=4)
+        self.l_expand = FreqExpand2D(dim)
+        self.l_ssm = SS2D(scan=l_scan, merge=l_merge, **ss)
+        self.h_expand = FreqExpand2D(dim)
+        self.h_ssm = SS2D(scan=h_scan, merge=h_merge, **ss)
+        self.sig = nn.Sigmoid()
+        self.concat_back_dim = Linear2d(dim * 2, dim, bias=False)
+
+    def _forward_cl(self, x):
+        high, low = self.DCT2D._forward_cl(x)
+        high = self.h_expand._forward_cl(high)
+        low = self.l_expand._forward_cl(low)
+        hifi = self.h_ssm._forward_cl(high)
+        lofi = self.l_ssm._forward_cl(low)
+        attn = self.concat_back_dim._forward_cl(torch.cat((hifi, lofi), dim=-1))
+        return torch.sigmoid(attn) * x
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+
+class FreqBlockv6(nn.Module):
+    """freq_mamba.py:60-82."""
+
+    def __init__(self, dim=128, input_resolution=None, num_heads=6, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                 drop=0.0, attn_drop=0.0, drop_path=0.0,
+                 l_scan=CrossScan_Dilation, h_scan=CrossScan_Window, l_merge=CrossMerge_Dilation,
+                 h_merge=CrossMerge_Window, act_layer=nn.GELU, norm_layer=LayerNorm2d, local_ws=2, alpha=0.5):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.dim = dim
+        self.mlp_ratio = mlp_ratio
+        self.norm1 = LayerNorm2d(dim)
+        self.attn = FreqSS2Dv6(dim, input_resolution=input_resolution, norm_layer=norm_layer, l_scan=l_scan,
+                               h_scan=h_scan, l_merge=l_merge, h_merge=h_merge)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = LayerNorm2d(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=0.0,
+                       channels_first=True)
+
+    def _forward_cl(self, x):
+        x = x + self.drop_path(self.attn._forward_cl(self.norm1._forward_cl(x)))
+        if isinstance(self.drop_path, nn.Identity):
+            return self.mlp._forward_cl(self.norm2._forward_cl(x), residual=x)
+        return x + self.drop_path(self.mlp._forward_cl(self.norm2._forward_cl(x)))
+
+    def forward(self, x):
+        _need_device(x)
+        return from_cl(self._forward_cl(to_cl(x)))
+
+
+# ----------------------------------------------------------------------------- encoder
+def _init_weights(m: nn.Module):
+    """vmamba.py:459-471 / Trambav6.py:86-97."""
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=0.02)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+    elif isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d, nn.ConvTranspose3d)):
+        nn.init.kaiming_normal_(m.weight, a=1e-2)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+
+def _conv_cl(conv: nn.Conv2d, x_cl):
+    """A regular (non depth-wise) strided conv on a channels-last activation (MIOpen NHWC)."""
+    x = from_cl(x_cl)
+    w = conv.weight.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    b = None if conv.bias is None else conv.bias.to(x.dtype)
+    return to_cl(F.conv2d(x, w, b, stride=conv.stride, padding=conv.padding))
+
+
+class VSSMEncoder(nn.Module):
+    """vmamba.py:399-518 (VMamba-B backbone: dims 128..1024, depths [2,2,15,2])."""
+
+    def __init__(self, patch_size=4, in_chans=3, depths=[2, 2, 15, 2], dims=128, drop_path_rate=0.6,
+                 patch_norm=True, norm_layer="LN2D", posembed=False, imgsize=224, **kwargs):
+        super().__init__()
+        assert norm_layer.lower() == "ln2d" and patch_norm and not posembed
+        self.channel_first = True
+        self.num_layers = len(depths)
+        if isinstance(dims, int):
+            dims = [int(dims * 2 ** i) for i in range(self.num_layers)]
+        self.num_features = dims[-1]
+        self.dims = dims
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.pos_embed = None
+        stride = patch_size // 2
+        self.patch_embed = nn.Sequential(
+            nn.Conv2d(in_chans, dims[0] // 2, kernel_size=stride + 1, stride=stride, padding=1),
+            nn.Identity(), LayerNorm2d(dims[0] // 2), nn.Identity(), nn.GELU(),
+            nn.Conv2d(dims[0] // 2, dims[0], kernel_size=stride + 1, stride=stride, padding=1),
+            nn.Identity(), LayerNorm2d(dims[0]))
+        self.layers = nn.ModuleList()
+        self.downsample = nn.ModuleList()
+        for i in range(self.num_layers):
+            if i < self.num_layers - 1:
+                self.downsample.append(nn.Sequential(
+                    nn.Identity(), nn.Conv2d(dims[i], dims[i] * 2, kernel_size=3, stride=2, padding=1),
+                    nn.Identity(), LayerNorm2d(dims[i] * 2)))
+            else:
+                self.downsample.append(nn.Identity())
+            blocks = [VSSBlock(hidden_dim=dims[i], drop_path=dp, norm_layer=LayerNorm2d, channel_first=True)
+                      for dp in dpr[sum(depths[:i]):sum(depths[:i + 1])]]
+            self.layers.append(nn.Sequential(OrderedDict(blocks=nn.Sequential(*blocks))))
+        self.apply(_init_weights)
+
+    def _forward_cl(self, x_img):
+        """x_img: NCHW image batch.  Returns [image, s1, s2, s3, s4] with s* channels-last (B,H,W,C)."""
+        feats = [x_img]
+        pe = self.patch_embed
+        x = _conv_cl(pe[0], to_cl(x_img))
+        x = pe[2]._forward_cl(x, act=hip.ACT_GELU)
+        x = _conv_cl(pe[5], x)
+        x = pe[7]._forward_cl(x)
+        for s, layer in enumerate(self.layers):
+            for blk in layer.blocks:
+                x = blk._forward_cl(x)
+            feats.append(x)
+            if s < self.num_layers - 1:
+                ds = self.downsample[s]
+                x = ds[3]._forward_cl(_conv_cl(ds[1], x))
+        return feats
+
+    def forward(self, x):
+        _need_device(x)
+        feats = self._forward_cl(x)
+        return [feats[0]] + [from_cl(f) for f in feats[1:]]
+
+
+def load_pretrained_Base(model, ckpt_path=""):
+    """vmamba.py:707-732: load a VMamba classification checkpoint into the encoder
+    (``layers.i.downsample.*`` -> ``downsample.i.*``, classifier dropped)."""
+    import re
+    print(f"Loading weights from: {ckpt_path}")
+    ckpt = torch.load(ckpt_path, map_location="cpu")
+    model_dict = model.state_dict()
+    loaded = set()
+    for k, v in ckpt["model"].items():
+        if "classifier" in k:
+            continue
+        if "downsample" in k:
+            i_ds = int(re.findall(r"layers\.(\d+)\.downsample", k)[0])
+            k = k.replace(f"layers.{i_ds}.downsample", f"downsample.{i_ds}")
+            assert k in model_dict, k
+        if k in model_dict:
+            if v.shape != model_dict[k].shape:
+                v = v.view(model_dict[k].shape)  # (out,in,1,1) conv weights -> Linear2d
+            model_dict[k] = v
+            loaded.add(k)
+        else:
+            print(f"Module can not find: {k}")
+    model.load_state_dict(model_dict)
+    for k in model_dict:
+        if k not in loaded:
+            print(f"Module {k} has not been inited!")
+    return model
