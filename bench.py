@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Tramba hot-path benchmark on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one forward of Tramba-V (VMamba-B encoder + Dual-Frequency/Helix decoder) over one
+synthetic batch already resident in HBM (BASELINE.json configs[1]: 384x384, bf16, batch 4 per GPU).
+Inference shards by image: every rank runs an independent replica on its own batch, no data-path
+collective ("weak" scaling); the barrier only brackets the timed region.
+
+Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline      dominant HIP kernel of the step (the fused channels-last selective scan): algorithmic
+                bytes / HIP-event time of ITS launches inside the timed steps, against 8 TB/s HBM peak
+  roofline_boundary   the same for the reference-layout selective scan (the L0 drop-in op, 8 B/element
+                at bf16-in/fp32-out) on the largest call shape of this model
+  cpu_baseline  the CPU oracle (a port of the reference forward, oracle/) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (config: 4)")
+    ap.add_argument("--img", type=int, default=384)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    return ap.parse_args()
+
+
+def build_model(img, dtype):
+    import tramba_amd as ta
+    torch.manual_seed(1026)  # train.py:284
+    m = ta.bulid_model(deep_supervision=True, use_pretrain=False, img_size=img, dims=128, depths=[2, 2, 2, 2])
+    return ta.prepare_inference(m.cuda(), dtype)
+
+
+def cpu_baseline(img):
+    """Reference forward as restated by the oracle (kind "port"), bounded sample on the host."""
+    import synth
+    from oracle import model as om
+    from oracle import ops as oo
+    import tramba_amd as ta
+    torch.manual_seed(1026)
+    m = ta.bulid_model(use_pretrain=False, img_size=img)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    x = torch.randn(1, 3, img, img, generator=torch.Generator().manual_seed(0))
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        om.tramba_v(sd, x)  # warm-up (builds tables, loads the C scan)
+        n, t0 = 0, time.perf_counter()
+        while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 8):
+            om.tramba_v(sd, x)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"{n} forward passes of Tramba-V {img}x{img}, batch 1, fp32, oracle/model.py "
+                      f"(torch-CPU ops + OpenMP C scan)"}
+
+
+def boundary_scan_roofline(dtype):
+    """Op-level run of the L0 selective scan on this model's largest call shape (4,1024,9216)."""
+    from tramba_amd import hip
+    dev = torch.device("cuda")
+    nb, kd, k, l = 4, 1024, 4, 9216
+    g = torch.Generator(device="cpu").manual_seed(0)
+    u = torch.randn(nb, kd, l, generator=g).to(dev, dtype)
+    delta = (0.5 * torch.randn(nb, kd, l, generator=g)).to(dev, dtype)
+    A = -torch.ones(kd, 1, device=dev)
+    B = torch.randn(nb, k, 1, l, generator=g).to(dev, dtype)
+    C = torch.randn(nb, k, 1, l, generator=g).to(dev, dtype)
+    D = torch.ones(kd, device=dev)
+    bias = torch.full((kd,), -3.0, device=dev)
+    for _ in range(5):
+        hip.selective_scan_fwd(u, delta, A, B, C, D, bias, True, True, want_ckpt=False)
+    torch.cuda.synchronize()
+    hip.profile_enable(hip.PROF_SCAN_BOUNDARY, True)
+    for _ in range(20):
+        hip.selective_scan_fwd(u, delta, A, B, C, D, bias, True, True, want_ckpt=False)
+    n, ms, nbytes = hip.profile_read(hip.PROF_SCAN_BOUNDARY)
+    hip.profile_enable(hip.PROF_SCAN_BOUNDARY, False)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "selective_scan_fwd_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "shape": [nb, kd, l], "launches": n, "avg_us": round(ms / n * 1e3, 2)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0 and world == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    from tramba_amd import hip
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    model = build_model(args.img, dtype)
+    x = torch.randn(args.batch, 3, args.img, args.img, generator=torch.Generator().manual_seed(rank)).cuda()
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- optional hipGraph capture of the whole forward (launch-bound otherwise)
+    graph = None
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out_static = step()
+        except Exception as e:  # graph capture is an optimisation, never a requirement
+            if rank == 0:
+                print(f"bench.py: hipGraph capture unavailable ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = (lambda: graph.replay()) if graph is not None else step
+
+    for _ in range(args.warmup):
+        run()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync_all()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    value = world * args.batch * args.steps / dt
+
+    # ---- roofline of the dominant kernel: eager pass of the same steps with HIP events around
+    #      every launch of the fused scan kernel (events cannot live inside a captured graph)
+    roof = roof_b = cpu = None
+    if rank == 0:
+        hip.profile_enable(hip.PROF_SCAN_FUSED, True)
+        nrep = min(args.steps, 10)
+        for _ in range(nrep):
+            step()
+        n, ms, nbytes = hip.profile_read(hip.PROF_SCAN_FUSED)
+        hip.profile_enable(hip.PROF_SCAN_FUSED, False)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "ss2d_scan_cl_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
+                "avg_us": round(ms / n * 1e3, 2), "ms_per_step": round(ms / nrep, 3)}
+        roof_b = boundary_scan_roofline(dtype)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.img)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        line = {
+            "metric": "images/sec fwd Tramba-V 384x384", "value": round(value, 2), "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Tramba-V (VMamba-B encoder) {args.img}x{args.img} {args.dtype} inference, "
+                                   f"batch {args.batch} per GPU, random-init weights (seed 1026), randn images",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world} replicas, no collective",
+                       "launch": "hipGraph replay" if graph is not None else "eager"},
+            "roofline": roof, "roofline_boundary": roof_b, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

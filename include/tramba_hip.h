@@ -63,9 +63,10 @@ int tramba_abi_version(void);
 /* HIP-event timing of the kernels launched by this library (used by bench.py for the
  * roofline figure).  enable=1 brackets every launch of kernel class `which` with events on
  * the launch stream; tramba_profile_read() synchronises those events and returns the
- * number of launches, writing the summed duration in milliseconds. */
+ * number of launches, writing the summed duration in milliseconds and the summed ALGORITHMIC
+ * bytes of those launches (DESIGN.md states the per-kernel formula). */
 int tramba_profile_enable(int which, int enable);
-int tramba_profile_read(int which, double *total_ms, double *total_units);
+int tramba_profile_read(int which, double *total_ms, double *total_bytes);
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1
 #define TRAMBA_PROF_COUNT 2

@@ -1,4 +1,4 @@
-"""Build libtramba_hip.so (gfx950) in-tree with hipcc.  `python -m tramba_amd.build [--force]`."""
+"""Build libtramba_hip.so (gfx950) in-tree with hipcc.  `python -m tramba_amd.buildlib [--force]`."""
 import os
 import subprocess
 import sys

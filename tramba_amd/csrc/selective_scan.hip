@@ -401,7 +401,10 @@ extern "C" int tramba_selective_scan_fwd(const void *u, const void *delta, const
     TRAMBA_CHECK(out_dtype == TRAMBA_F32 || out_dtype == io_dtype,
                  "selective_scan_fwd: out dtype must be f32 (oflex) or the input dtype");
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(TRAMBA_PROF_SCAN_BOUNDARY, s, (double)batch * kd * l);
+    // algorithmic bytes at the op boundary: u, delta read + out written (+ the small B/C rows)
+    const double esz = (double)dtype_size(io_dtype), osz = (double)dtype_size(out_dtype);
+    ProfScope prof(TRAMBA_PROF_SCAN_BOUNDARY, s,
+                   (double)batch * kd * l * (2.0 * esz + osz) + 2.0 * batch * k * n * (double)l * esz);
 #define GO_(T, TO, N_) \
     return launch_fwd<T, TO, N_>(u, delta, A, Bm, Cm, D, delta_bias, out, ckpt, batch, kd, k, l, delta_softplus, s)
 #define BY_N_(T, TO)                                                           \

@@ -184,7 +184,10 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     int W = (l + kLC - 1) / kLC;
     if (W > kMaxW) W = kMaxW;
     dim3 grid((d + kWave - 1) / kWave, k, batch), block(W * kWave);
-    ProfScope prof(TRAMBA_PROF_SCAN_FUSED, s, (double)batch * k * d * l);
+    // algorithmic bytes of this kernel: x read once, the low-rank x_proj rows, ys written
+    ProfScope prof(TRAMBA_PROF_SCAN_FUSED, s,
+                   (double)batch * l * d * dtype_size(dtype) + (double)batch * l * k * (r + 2) * 4.0 +
+                       (double)batch * k * l * (double)d * dtype_size(ys_dtype));
 #define GO_(T, TY, RT_)                                                                              \
     hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, RT_>), grid, block, 0, s, (const T *)x, xdbl, table, \
                        dt_w, dt_bias, A, Ds, (TY *)ys, l, d, k, r, W)

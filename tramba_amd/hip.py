@@ -62,7 +62,7 @@ def lib():
             if _lib is None:
                 if not os.path.exists(LIB_PATH):
                     raise RuntimeError(
-                        f"{LIB_PATH} is missing: build it with `python -m tramba_amd.build` "
+                        f"{LIB_PATH} is missing: build it with `python -m tramba_amd.buildlib` "
                         "(hipcc, gfx950).  tramba_amd has no CPU or PyTorch fallback.")
                 l = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
