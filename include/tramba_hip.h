@@ -114,10 +114,12 @@ int tramba_cross_merge(const void *ys, const int32_t *inv_ptr, const int32_t *in
 
 /* ------------------------------------------------------------------ fused SS2D core, channels-last */
 /* x:    (B, L, D)           dtype   -- conv+SiLU output, spatial order
- * xdbl: (B, L, K*(R+2))     f32     -- x_proj output in SPATIAL order: per group k
- *                                      [dt_0..dt_{R-1}, B, C]   (d_state N = 1 only)
+ * xdbl: (B, L, K*RG)        f32     -- x_proj output in SPATIAL order: per group k
+ *                                      [dt_0..dt_{R-1}, B, C, pad]   (d_state N = 1 only);
+ *                                      RG = tramba_ss2d_group_stride(R) = (R+2) rounded up to 4
  * table (K, L) int32 device; dt_w (K, D, R) f32; dt_bias (K*D) f32; A (K*D) f32 (= -exp(A_logs));
  * Ds (K*D) f32.   ys: (B, K, L, D) ys_dtype in SEQUENCE order.                                   */
+int tramba_ss2d_group_stride(int r);
 int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
                         const float *dt_bias, const float *A, const float *Ds, void *ys, int batch,
                         int l, int d, int k, int r, int dtype, int ys_dtype, void *stream);

@@ -179,7 +179,7 @@ def test_linear_cl(dtype, mnk):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("fam", ["raster", "helix", "window", "dilation"])
-@pytest.mark.parametrize("cfg", [(2, 12, 32, 2), (1, 24, 64, 4), (1, 16, 40, 3), (1, 48, 128, 8)])
+@pytest.mark.parametrize("cfg", [(2, 12, 32, 2), (1, 24, 64, 4), (1, 16, 40, 3), (1, 48, 128, 8), (1, 12, 96, 40), (1, 24, 32, 64)])
 def test_ss2d_fused_core(dtype, fam, cfg):
     """fused channels-last scan + merge/LayerNorm/GELU against the oracle's NCHW composition."""
     b, h, d, r = cfg
@@ -199,7 +199,7 @@ def test_ss2d_fused_core(dtype, fam, cfg):
     dev = torch.device(DEV)
     order = H.scan_order(fam, h, h, dev)
     xc = x.permute(0, 2, 3, 1).contiguous().view(b, h * h, d).to(dev)
-    xdbl = H.linear_cl(xc, wx.reshape(k * (r + 2), d).to(dev), out_dtype=torch.float32)
+    xdbl = H.linear_cl(xc, H.pad_x_proj_weight(wx.to(dev)), out_dtype=torch.float32)
     for ys_dtype in ([torch.float32] if dtype == torch.float32 else [torch.float32, dtype]):
         ys = H.ss2d_scan_cl(xc, xdbl, order, wdt.to(dev), dtb.reshape(-1).to(dev), (-torch.exp(a_logs)).reshape(-1).to(dev),
                             ds.to(dev), ys_dtype)

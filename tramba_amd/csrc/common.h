@@ -88,7 +88,7 @@ __device__ __forceinline__ float softplus20(float x)
     float z = __expf(x);
     float w = 1.f + z;
     float d = w - 1.f;
-    return d == 0.f ? z : __logf(w) * __fdividef(z, d);
+    return d == 0.f ? z : __logf(w) * z * __builtin_amdgcn_rcpf(d);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }

@@ -112,6 +112,179 @@ __global__ __launch_bounds__(256) void linear16_kernel(const T *__restrict__ x, 
             store_tile<T, TO>(acc[i][j], y, bias, res, m0 + i * 32, n0 + j * 32, M, N, act, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2: LDS-staged, double-buffered tile kernel for 16-bit operands.
+//   block = 256 threads = 2x2 waves; block tile BM x BN, K step 64; wave tile (BM/2) x (BN/2) made of
+//   32x32 MFMA tiles.  Global -> registers -> LDS (16-byte chunks, XOR-swizzled by row so the
+//   ds_read_b128 fragment reads of 128-byte rows are conflict-free), tile k+1 is in flight while tile
+//   k is multiplied; one barrier per K step.  The accumulators leave through LDS so that bias,
+//   activation, residual and the store all run on whole 128-byte row segments (the MFMA C layout
+//   has one COLUMN per lane, which would store 2-byte scalars at a row stride).
+constexpr int kBK = 64;
+
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ (row & 7); }
+
+template <typename T, typename TO, int BM, int BN>
+__global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__ x, const T *__restrict__ w,
+                                                          const float *__restrict__ bias,
+                                                          const T *__restrict__ res, TO *__restrict__ y, long M,
+                                                          int N, int K, int act)
+{
+    constexpr int TM = BM / 64, TN = BN / 64;           // 32x32 tiles per wave in m / n
+    constexpr int A_CHUNKS = BM * (kBK / 8), B_CHUNKS = BN * (kBK / 8);
+    constexpr int A_PER_T = A_CHUNKS / 256, B_PER_T = B_CHUNKS / 256;
+    constexpr int TILE_BYTES = (BM + BN) * kBK * 2;
+    constexpr int EPI_BYTES = 4 * (BM / 2) * (BN / 2) * 4;
+    constexpr int LDS_BYTES = 2 * TILE_BYTES > EPI_BYTES ? 2 * TILE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = (long)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int nk = (K + kBK - 1) / kBK;
+
+    acc16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    frag8_t ra[A_PER_T], rb[B_PER_T];
+    auto gload = [&](int kt) {
+        const int k0 = kt * kBK;
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            const int q = tid + i * 256, row = q >> 3, c = q & 7;
+            const long gr = m0 + row;
+            frag8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gr < M && k0 + c * 8 < K) v = *reinterpret_cast<const frag8_t *>(x + gr * K + k0 + c * 8);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) {
+            const int q = tid + i * 256, row = q >> 3, c = q & 7;
+            const int gn = n0 + row;
+            frag8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gn < N && k0 + c * 8 < K) v = *reinterpret_cast<const frag8_t *>(w + (long)gn * K + k0 + c * 8);
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char *As = lds + buf * TILE_BYTES, *Bs = As + BM * kBK * 2;
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            const int q = tid + i * 256, row = q >> 3, c = q & 7;
+            *reinterpret_cast<frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) {
+            const int q = tid + i * 256, row = q >> 3, c = q & 7;
+            *reinterpret_cast<frag8_t *>(Bs + row * 128 + swz_chunk(row, c) * 16) = rb[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int r32 = lane & 31, hi = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char *As = lds + (kt & 1) * TILE_BYTES, *Bs = As + BM * kBK * 2;
+#pragma unroll
+        for (int kk = 0; kk < kBK / 16; ++kk) {
+            frag8_t a[TM], b[TN];
+            const int c = kk * 2 + hi;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * (BM / 2) + i * 32 + r32;
+                a[i] = *reinterpret_cast<const frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * (BN / 2) + j * 32 + r32;
+                b[j] = *reinterpret_cast<const frag8_t *>(Bs + row * 128 + swz_chunk(row, c) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS: wave-private (BM/2) x (BN/2) fp32 tile, row stride WN floats
+    constexpr int WM = BM / 2, WN = BN / 2;
+    float *ep = reinterpret_cast<float *>(lds) + wave * WM * WN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                ep[row * WN + j * 32 + r32] = acc[i][j][r];
+            }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tile is wave-private, no barrier needed
+    constexpr int LPRW = WN / 4;          // lanes per row, 4 columns each
+    constexpr int RPI = 64 / LPRW;        // rows per wave iteration
+    const int cl = (lane % LPRW) * 4, rl = lane / LPRW;
+    const int gcol = n0 + wn * WN + cl;
+#pragma unroll
+    for (int it = 0; it < WM / RPI; ++it) {
+        const int row = it * RPI + rl;
+        const long grow = m0 + wm * WM + row;
+        if (grow >= M || gcol >= N) continue;
+        float4 v = *reinterpret_cast<const float4 *>(ep + row * WN + cl);
+        float o[4] = {v.x, v.y, v.z, v.w};
+        if (gcol + 4 <= N && (N & 3) == 0) {
+            if (bias) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bias + gcol);
+                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = apply_act(o[q], act);
+            if (res) {
+                float rv[4];
+                load_pack<T, 4>(res + grow * N + gcol, rv);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] += rv[q];
+            }
+            store_pack<TO, 4>(y + grow * N + gcol, o);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (gcol + q < N) {
+                    float t = apply_act(o[q] + (bias ? bias[gcol + q] : 0.f), act);
+                    if (res) t += Cvt<T>::to_f(res[grow * N + gcol + q]);
+                    y[grow * N + gcol + q] = Cvt<TO>::from_f(t);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename TO>
+static void launch_tiled(const void *x, const void *w, const float *bias, const void *res, void *y, long m, int n,
+                         int k, int act, hipStream_t s)
+{
+    // big tiles when they still fill the 256 CUs, small tiles otherwise (short-M stages)
+    const long big = ((m + 127) / 128) * ((n + 127) / 128);
+    if (big >= 384) {
+        dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
+        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                           (const T *)res, (TO *)y, m, n, k, act);
+    } else {
+        dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
+        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 64, 64>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                           (const T *)res, (TO *)y, m, n, k, act);
+    }
+}
+
 // fp32: v_mfma_f32_32x32x2_f32, A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]
 template <typename TO>
 __global__ __launch_bounds__(256) void linear32_kernel(const float *__restrict__ x, const float *__restrict__ w,
@@ -172,6 +345,19 @@ extern "C" int tramba_linear_cl(const void *x, const void *w, const float *bias,
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)gx, (unsigned)gy), block(256);
     const int vec = (k % 8 == 0) && aligned16(x) && aligned16(w);
+    const bool tiled = vec && dtype != TRAMBA_F32 && aligned16(y) && (residual == nullptr || aligned16(residual)) &&
+                       (m + 63) / 64 <= 65535;
+    if (tiled) {
+        if (dtype == TRAMBA_BF16) {
+            if (out_dtype == TRAMBA_F32) launch_tiled<__hip_bfloat16, float>(x, w, bias, residual, y, m, n, k, act, s);
+            else launch_tiled<__hip_bfloat16, __hip_bfloat16>(x, w, bias, residual, y, m, n, k, act, s);
+        } else {
+            if (out_dtype == TRAMBA_F32) launch_tiled<__half, float>(x, w, bias, residual, y, m, n, k, act, s);
+            else launch_tiled<__half, __half>(x, w, bias, residual, y, m, n, k, act, s);
+        }
+        TRAMBA_LAUNCH_CHECK();
+        return TRAMBA_OK;
+    }
     if (dtype == TRAMBA_F32) {
         hipLaunchKernelGGL(linear32_kernel<float>, grid, block, 0, s, (const float *)x, (const float *)w, bias,
                            (const float *)residual, (float *)y, (long)m, n, k, act);

@@ -13,12 +13,21 @@
 // Because x_proj is linear and a scan order only permutes positions, x_proj is evaluated
 // ONCE in spatial order (a plain GEMM, K*(R+2) outputs) and gathered here.
 //
-// ss2d_scan_cl:   grid (D/64, K, B); a workgroup of W waves owns 64 channels of one
-//   direction for the whole sequence.  Per super-chunk of W*LC positions every wave
-//   (A) gathers its LC rows, evaluates dt = softplus(<dt_w[d,:], dts> + bias) on the VALU
-//   with the R-vector in SGPRs, a = exp(dt*A), b = dt*B*u, and reduces its chunk to a
-//   (decay, state) pair; (B) after ONE barrier folds the preceding waves' pairs (LDS) into
-//   its carry-in; (C) replays its LC steps from registers and streams y rows out.
+// ss2d_scan_cl:   grid (D/32, K, B); a workgroup of W waves owns 32 channels of one direction for
+//   the whole sequence.  The unit of work is a TILE of 32 positions x 32 channels:
+//   * dt_proj runs on the matrix cores: dt_raw[pos][ch] = <x_dbl[pos, :R], dt_w[ch, :R]> is one
+//     v_mfma_f32_32x32x16_bf16 per 16 ranks (A = the gathered x_dbl rows, one position per lane;
+//     B = this wave's dt_w slice, loop-invariant registers).  fp32 activations use the split
+//     hi+lo bf16 form (3 MFMAs, ~2^-16 relative) so the fp32 path keeps fp32-level accuracy.
+//   * the MFMA accumulator leaves each lane with 16 positions of ONE channel (4 runs of 4
+//     consecutive positions, interleaved with the partner lane l^32), so softplus / exp / the
+//     recurrence are pure per-lane VALU work on all 64 lanes; the two half-waves exchange their 4
+//     run aggregates once per tile and fold them in sequence order.
+//   * per super-chunk of W tiles: every wave reduces its tile to a (decay, state) pair, ONE
+//     barrier, each wave folds the preceding waves' pairs (LDS) into its carry-in, replays its
+//     16 steps from registers and streams y rows out.
+//   * operands are prefetched two tiles deep (index vector -> row / u gathers -> compute), all
+//     as vector loads with per-lane addresses; x_dbl groups are padded to 16-byte multiples.
 // ss2d_merge_norm_cl: one wave per pixel sums the rows listed by the inverse table
 //   (deterministic, atomic-free even for the many-to-one Helix lines), applies out_norm
 //   (LayerNorm over D, two-pass fp32) and the following GELU, writes the activation dtype.
@@ -27,90 +36,239 @@
 
 namespace tramba {
 
-constexpr int kLC = 16;      // positions per wave per super-chunk
 constexpr int kMaxW = 8;     // waves per workgroup
 
-template <typename T, typename TY, int RT>
+typedef __attribute__((ext_vector_type(8))) short frag8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float acc16_t;
+
+constexpr int kTP = 32;  // positions per tile (one MFMA tile)
+
+__host__ __device__ inline int xdbl_group_stride(int r) { return (r + 2 + 3) & ~3; }
+
+// split 8 floats into bf16 hi (+ bf16 lo = rounding residual) fragments
+template <bool SPLIT>
+__device__ __forceinline__ void pack_frag(const float (&v)[8], frag8_t &hi, frag8_t &lo)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __hip_bfloat16 h = __float2bfloat16(v[j]);
+        hi[j] = __builtin_bit_cast(short, h);
+        if (SPLIT) lo[j] = __builtin_bit_cast(short, __float2bfloat16(v[j] - __bfloat162float(h)));
+    }
+}
+
+__device__ __forceinline__ acc16_t mfma_bf16(frag8_t a, frag8_t b, acc16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+template <int NK>
+struct TileOps {
+    float araw[NK][8];  // x_dbl row of MY position (lane & 31), ranks 16kk + 8hi .. +7
+    float bv, cv;       // B, C of MY position
+    float u[16];        // x of my 16 (position, channel) elements
+};
+
+template <typename T, typename TY, int NK, bool SPLIT>
 __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
     const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W)
 {
-    __shared__ float agg[2][kMaxW][2][kWave];
+    __shared__ float agg[2][kMaxW][2][kTP];
+    __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];  // per wave: pixel idx, B, C per position
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, hi = lane >> 5;
     const int k = blockIdx.y, b = blockIdx.z;
-    const int d = blockIdx.x * kWave + lane;
-    const bool dok = d < D;
-    const int dc = dok ? d : D - 1;
-    const int PC = K * (R + 2);
+    const int c = blockIdx.x * kTP + r32;
+    const bool cok = c < D;
+    const int cc_ = cok ? c : D - 1;
+    const int RG = xdbl_group_stride(R);
+    const int PC = K * RG;
+    const bool rvec = (R & 7) == 0;  // every 8-rank run is whole and 16-byte aligned
 
-    float w[RT > 0 ? RT : 1];
-    const float *wrow = dt_w + ((long)k * D + dc) * R;
-    if (RT > 0) {
+    // loop-invariant B operand: dt_w[k][channel][16kk + 8hi + j]
+    frag8_t wh[NK], wl[NK];
+    {
+        const float *wrow = dt_w + ((long)k * D + cc_) * R;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) w[r] = wrow[r];
+        for (int kk = 0; kk < NK; ++kk) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = kk * 16 + hi * 8 + j;
+                t[j] = r < R ? wrow[r] : 0.f;
+            }
+            pack_frag<SPLIT>(t, wh[kk], wl[kk]);
+        }
     }
-    const float bias = dt_bias[(long)k * D + dc];
-    const float An = Aneg[(long)k * D + dc];
-    const float Dk = Ds[(long)k * D + dc];
+    const float bias = dt_bias[(long)k * D + cc_];
+    const float An = Aneg[(long)k * D + cc_];
+    const float Dk = Ds[(long)k * D + cc_];
 
-    const T *xb = x + (long)b * L * D + dc;
-    const float *pb = xdbl + (long)b * L * PC + (long)k * (R + 2);
+    const T *xb = x + (long)b * L * D + cc_;
+    const float *pb = xdbl + (long)b * L * PC + (long)k * RG;
     const int32_t *tk = table + (long)k * L;
-    TY *yb = ys + ((long)b * K + k) * L * D + dc;
+    TY *yb = ys + ((long)b * K + k) * L * D + cc_;
+    float *st = &stage[wv][0][0];
+
+    const int span = W * kTP;
+    const int nsuper = (L + span - 1) / span;
+
+    auto load_idx = [&](int s) -> int {
+        const int l = s * span + wv * kTP + r32;
+        return l < L ? tk[l] : 0;
+    };
+    auto load_rows = [&](int pix, TileOps<NK> &o) {
+        const float *row = pb + (long)pix * PC;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int r0 = kk * 16 + hi * 8;
+            if (rvec) {
+                if (r0 < R) {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(row + r0);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(row + r0 + 4);
+                    o.araw[kk][0] = v0.x; o.araw[kk][1] = v0.y; o.araw[kk][2] = v0.z; o.araw[kk][3] = v0.w;
+                    o.araw[kk][4] = v1.x; o.araw[kk][5] = v1.y; o.araw[kk][6] = v1.z; o.araw[kk][7] = v1.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o.araw[kk][j] = 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o.araw[kk][j] = r0 + j < R ? row[r0 + j] : 0.f;
+            }
+        }
+        o.bv = row[R];
+        o.cv = row[R + 1];
+    };
+    // my 16 elements sit at positions POS(r) = (r&3) + 8(r>>2) + 4hi of the tile
+    auto read_stage4 = [&](int which, float (&out)[16]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4 *>(st + which * kTP + 8 * g + 4 * hi);
+            out[4 * g + 0] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
+        }
+    };
+    auto load_u = [&](const float (&pixf)[16], TileOps<NK> &o) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pix = __builtin_bit_cast(int, pixf[r]);
+            o.u[r] = Cvt<T>::to_f(xb[(long)pix * D]);
+        }
+    };
+
+    TileOps<NK> cur, nxt;
+    float pixf[16];
+    {   // prologue: tile 0 operands, index vector of tile 1
+        const int i0 = load_idx(0);
+        if (hi == 0) st[r32] = __builtin_bit_cast(float, i0);
+        __builtin_amdgcn_wave_barrier();
+        read_stage4(0, pixf);
+        load_rows(i0, cur);
+        load_u(pixf, cur);
+    }
+    int idx_n = nsuper > 1 ? load_idx(1) : 0;
 
     float carry = 0.f;
-    const int span = W * kLC;
-    const int nsuper = (L + span - 1) / span;
     for (int s = 0; s < nsuper; ++s) {
-        const int l0 = s * span + wv * kLC;
-        float a[kLC], bb[kLC], cc[kLC], du[kLC];
-        float pa = 1.f, ph = 0.f;
+        const int l0 = s * span + wv * kTP;
+        const bool more = s + 1 < nsuper;
+        // publish per-position scalars of THIS tile (B, C) and the pixel indices of the NEXT tile
+        if (hi == 0) {
+            st[r32] = __builtin_bit_cast(float, idx_n);
+            st[kTP + r32] = cur.bv;
+            st[2 * kTP + r32] = cur.cv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float Bp[16], Cp[16];
+        read_stage4(1, Bp);
+        read_stage4(2, Cp);
+        if (more) {  // wave-uniform: next tile's gathers fly under this tile's arithmetic
+            read_stage4(0, pixf);
+            load_rows(idx_n, nxt);
+            load_u(pixf, nxt);
+            idx_n = s + 2 < nsuper ? load_idx(s + 2) : 0;
+        }
+
+        // ---- dt_proj on the matrix core
+        acc16_t acc;
 #pragma unroll
-        for (int j = 0; j < kLC; ++j) {
-            const int l = l0 + j;
-            if (l < L) {  // wave-uniform
-                const int p = tk[l];
-                const float u = Cvt<T>::to_f(xb[(long)p * D]);
-                const float *prow = pb + (long)p * PC;
-                float dtv = bias;
-                if (RT > 0) {
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) dtv = fmaf(w[r], prow[r], dtv);
-                } else {
-                    for (int r = 0; r < R; ++r) dtv = fmaf(wrow[r], prow[r], dtv);
-                }
-                const float dt = softplus20(dtv);
-                a[j] = __expf(dt * An);
-                bb[j] = dt * prow[R] * u;
-                cc[j] = prow[R + 1];
-                du[j] = Dk * u;
-            } else {
-                a[j] = 1.f; bb[j] = 0.f; cc[j] = 0.f; du[j] = 0.f;
+        for (int kk = 0; kk < NK; ++kk) {
+            frag8_t ah, al;
+            pack_frag<SPLIT>(cur.araw[kk], ah, al);
+            acc = mfma_bf16(ah, wh[kk], acc);
+            if (SPLIT) {
+                acc = mfma_bf16(ah, wl[kk], acc);
+                acc = mfma_bf16(al, wh[kk], acc);
             }
-            ph = fmaf(a[j], ph, bb[j]);
-            pa *= a[j];
+        }
+        // ---- per-element terms
+        float a[16], bb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pos = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float dt = (l0 + pos < L) ? softplus20(acc[r] + bias) : 0.f;
+            a[r] = __expf(dt * An);
+            bb[r] = dt * Bp[r] * cur.u[r];
+        }
+        // ---- 4 runs of 4 consecutive positions per lane; runs of the two half-waves interleave
+        float sa[4], sh[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float pa = 1.f, ph = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ph = fmaf(a[4 * g + q], ph, bb[4 * g + q]);
+                pa *= a[4 * g + q];
+            }
+            sa[g] = pa;
+            sh[g] = ph;
+        }
+        float preA[4], preH[4];   // prefix (relative to the tile start) entering MY run g
+        float runA = 1.f, runH = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float oa = __shfl_xor(sa[g], 32, 64), oh = __shfl_xor(sh[g], 32, 64);
+            const float ea = hi ? oa : sa[g], eh = hi ? oh : sh[g];   // run 2g   (lower half-wave)
+            const float fa = hi ? sa[g] : oa, fh = hi ? sh[g] : oh;   // run 2g+1 (upper half-wave)
+            const float midH = fmaf(ea, runH, eh), midA = ea * runA;
+            preA[g] = hi ? midA : runA;
+            preH[g] = hi ? midH : runH;
+            runH = fmaf(fa, midH, fh);
+            runA = fa * midA;
         }
         const int buf = s & 1;
-        agg[buf][wv][0][lane] = pa;
-        agg[buf][wv][1][lane] = ph;
+        if (hi == 0) {
+            agg[buf][wv][0][r32] = runA;
+            agg[buf][wv][1][r32] = runH;
+        }
         __syncthreads();
-        // fold all W chunks: pick my carry-in on the way, end with the next carry
         float h = carry, hin = carry;
         for (int q = 0; q < W; ++q) {
             if (q == wv) hin = h;
-            h = fmaf(agg[buf][q][0][lane], h, agg[buf][q][1][lane]);
+            h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
         }
         carry = h;
-        h = hin;
+        // ---- replay and stream out
 #pragma unroll
-        for (int j = 0; j < kLC; ++j) {
-            h = fmaf(a[j], h, bb[j]);
-            const int l = l0 + j;
-            if (l < L && dok) yb[(long)l * D] = Cvt<TY>::from_f(fmaf(cc[j], h, du[j]));
+        for (int g = 0; g < 4; ++g) {
+            float hh = fmaf(preA[g], hin, preH[g]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * g + q;
+                hh = fmaf(a[r], hh, bb[r]);
+                const int l = l0 + q + 8 * g + 4 * hi;
+                if (l < L && cok) yb[(long)l * D] = Cvt<TY>::from_f(fmaf(Cp[r], hh, Dk * cur.u[r]));
+            }
         }
+        if (more) cur = nxt;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -179,33 +337,41 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     TRAMBA_CHECK(x && xdbl && table && dt_w && dt_bias && A && Ds && ys, "ss2d_scan_cl: null tensor");
     TRAMBA_CHECK(batch > 0 && l > 0 && d > 0 && k > 0 && r > 0, "ss2d_scan_cl: empty shape");
     TRAMBA_CHECK(batch <= 65535 && k <= 65535, "ss2d_scan_cl: B or K exceeds grid limits");
+    TRAMBA_CHECK(r <= 64, "ss2d_scan_cl: dt_rank %d > 64 unsupported", r);
     TRAMBA_CHECK(ys_dtype == TRAMBA_F32 || ys_dtype == dtype, "ss2d_scan_cl: ys must be f32 or the input dtype");
+    TRAMBA_CHECK(aligned16(xdbl), "ss2d_scan_cl: xdbl must be 16-byte aligned");
+    TRAMBA_CHECK((double)batch * k * l * (double)d < 2.0e9, "ss2d_scan_cl: tensor too large for this build");
     hipStream_t s = (hipStream_t)stream;
-    int W = (l + kLC - 1) / kLC;
+    int W = (l + kTP - 1) / kTP;
     if (W > kMaxW) W = kMaxW;
-    dim3 grid((d + kWave - 1) / kWave, k, batch), block(W * kWave);
+    const int nk = (r + 15) / 16;
+    const int rg = xdbl_group_stride(r);
+    dim3 grid((d + kTP - 1) / kTP, k, batch), block(W * kWave);
     // algorithmic bytes of this kernel: x read once, the low-rank x_proj rows, ys written
     ProfScope prof(TRAMBA_PROF_SCAN_FUSED, s,
-                   (double)batch * l * d * dtype_size(dtype) + (double)batch * l * k * (r + 2) * 4.0 +
+                   (double)batch * l * d * dtype_size(dtype) + (double)batch * l * k * rg * 4.0 +
                        (double)batch * k * l * (double)d * dtype_size(ys_dtype));
-#define GO_(T, TY, RT_)                                                                              \
-    hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, RT_>), grid, block, 0, s, (const T *)x, xdbl, table, \
+#define GO_(T, TY, NK_, SP_)                                                                               \
+    hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK_, SP_>), grid, block, 0, s, (const T *)x, xdbl, table, \
                        dt_w, dt_bias, A, Ds, (TY *)ys, l, d, k, r, W)
-#define BY_R_(T, TY)                                   \
-    switch (r) {                                       \
-    case 1: GO_(T, TY, 1); break;                      \
-    case 2: GO_(T, TY, 2); break;                      \
-    case 4: GO_(T, TY, 4); break;                      \
-    case 8: GO_(T, TY, 8); break;                      \
-    case 16: GO_(T, TY, 16); break;                    \
-    case 32: GO_(T, TY, 32); break;                    \
-    case 64: GO_(T, TY, 64); break;                    \
-    default: GO_(T, TY, 0); break;                     \
+#define BY_NK_(T, TY, SP_)                  \
+    switch (nk) {                           \
+    case 1: GO_(T, TY, 1, SP_); break;      \
+    case 2: GO_(T, TY, 2, SP_); break;      \
+    case 3: GO_(T, TY, 3, SP_); break;      \
+    default: GO_(T, TY, 4, SP_); break;     \
     }
-    TRAMBA_DISPATCH_DTYPE(dtype, T, {
-        if (ys_dtype == TRAMBA_F32) { BY_R_(T, float) } else { BY_R_(T, T) }
-    });
-#undef BY_R_
+    if (dtype == TRAMBA_F32) {
+        BY_NK_(float, float, true)
+    } else if (dtype == TRAMBA_BF16) {
+        if (ys_dtype == TRAMBA_F32) { BY_NK_(__hip_bfloat16, float, false) } else { BY_NK_(__hip_bfloat16, __hip_bfloat16, false) }
+    } else if (dtype == TRAMBA_F16) {
+        if (ys_dtype == TRAMBA_F32) { BY_NK_(__half, float, false) } else { BY_NK_(__half, __half, false) }
+    } else {
+        set_error("ss2d_scan_cl: bad dtype %d", dtype);
+        return TRAMBA_ERR_ARG;
+    }
+#undef BY_NK_
 #undef GO_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
@@ -241,3 +407,5 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
+
+extern "C" int tramba_ss2d_group_stride(int r) { return tramba::xdbl_group_stride(r); }

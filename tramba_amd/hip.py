@@ -40,6 +40,7 @@ SIGNATURES = {
     "tramba_selective_scan_bwd": (c_int, [c_vp] * 16 + [c_int] * 7 + [c_vp]),
     "tramba_cross_scan": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_cross_merge": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_ss2d_group_stride": (c_int, [c_int]),
     "tramba_ss2d_scan_cl": (c_int, [c_vp] * 8 + [c_int] * 7 + [c_vp]),
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
@@ -241,13 +242,27 @@ def cross_merge(ys, order: ScanOrder):
 
 
 # ----------------------------------------------------------------------------- channels-last kernels
+def ss2d_group_stride(r: int) -> int:
+    """Floats per direction group of the x_proj output: [dt_0..dt_{R-1}, B, C] padded to 4."""
+    return lib().tramba_ss2d_group_stride(r)
+
+
+def pad_x_proj_weight(x_proj_weight: torch.Tensor) -> torch.Tensor:
+    """(K, R+2, D) -> (K*RG, D) with zero rows as padding, the layout ss2d_scan_cl consumes."""
+    k, r2, d = x_proj_weight.shape
+    rg = ss2d_group_stride(r2 - 2)
+    w = x_proj_weight.new_zeros((k, rg, d))
+    w[:, :r2] = x_proj_weight
+    return w.reshape(k * rg, d)
+
+
 def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch.float32):
-    """x: (B, L, D); xdbl: (B, L, K*(R+2)) f32 -> ys (B, K, L, D)."""
+    """x: (B, L, D); xdbl: (B, L, K*RG) f32 -> ys (B, K, L, D)."""
     _dev(x, xdbl, dt_w, dt_bias, A, Ds)
     b, l, d = x.shape
     k, r = order.k, dt_w.shape[-1]
-    if xdbl.dtype != torch.float32 or xdbl.shape != (b, l, k * (r + 2)):
-        raise TrambaHipError(f"ss2d_scan_cl: xdbl must be f32 (B,L,K*(R+2)), got {xdbl.dtype} {tuple(xdbl.shape)}")
+    if xdbl.dtype != torch.float32 or xdbl.shape != (b, l, k * ss2d_group_stride(r)):
+        raise TrambaHipError(f"ss2d_scan_cl: xdbl must be f32 (B,L,K*RG), got {xdbl.dtype} {tuple(xdbl.shape)}")
     if l != order.l or dt_w.shape != (k, d, r) or A.numel() != k * d or Ds.numel() != k * d or dt_bias.numel() != k * d:
         raise TrambaHipError("ss2d_scan_cl: parameter shapes do not match (K, D, R)")
     ys = torch.empty((b, k, l, d), dtype=ys_dtype, device=x.device)

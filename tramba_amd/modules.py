@@ -366,10 +366,21 @@ class SS2D(nn.Module):
 
     # -- the two core paths -----------------------------------------------------------------
     def _fused_ok(self, x):
-        return (self.d_state == 1 and getattr(self.scan, "_tramba_family", None) is not None
+        return (self.d_state == 1 and self.dt_rank <= 64
+                and getattr(self.scan, "_tramba_family", None) is not None
                 and getattr(self.merge, "_tramba_family", None) == self.scan._tramba_family
                 and self.scan._tramba_k == self.k_group
                 and _infer(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs))
+
+    def _padded_x_proj(self, dtype):
+        """x_proj weight in the (K*RG, D) layout of the fused scan; cached until the parameter changes."""
+        p = self.x_proj_weight
+        key = (p._version, p.data_ptr(), dtype, p.device)
+        cache = getattr(self, "_xproj_cache", None)
+        if cache is None or cache[0] != key:
+            cache = (key, hip.pad_x_proj_weight(p.detach().to(dtype)).contiguous())
+            self._xproj_cache = cache
+        return cache[1]
 
     def _core_fused_cl(self, x):
         """x (B,H,W,D) after conv+SiLU -> GELU(out_norm(merge(scan(...)))), all HIP."""
@@ -377,10 +388,7 @@ class SS2D(nn.Module):
         k, r = self.k_group, self.dt_rank
         order = hip.scan_order(self.scan._tramba_family, h, w, x.device)
         xf = x.view(b, h * w, d)
-        wx = self.x_proj_weight.detach().reshape(k * (r + 2), d)
-        if wx.dtype != x.dtype:
-            wx = wx.to(x.dtype)
-        xdbl = hip.linear_cl(xf, wx, out_dtype=torch.float32)  # x_proj once, spatial order
+        xdbl = hip.linear_cl(xf, self._padded_x_proj(x.dtype), out_dtype=torch.float32)  # x_proj once, spatial order
         a_neg = -torch.exp(self.A_logs.detach().float()).reshape(-1)
         ys_dtype = torch.float32 if YS_DTYPE == "f32" else x.dtype
         ys = hip.ss2d_scan_cl(xf, xdbl, order, _f32(self.dt_projs_weight), _f32(self.dt_projs_bias).reshape(-1),
