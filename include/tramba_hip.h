@@ -24,7 +24,7 @@
  *   tramba_shuffle_norm_cl      rearrange(...)+norm in PatchExpand / FinalPatchExpand_X4 /
  *                               FreqExpand2D                    Models/modules.py:209-218,240-249,687-696
  *   tramba_dwconv_cl            SS2D.conv2d (+SiLU)             Models/vmamba.py:283-285
- *   tramba_dwms_cl              DWMSMlp: h+dw3+dw5+dw7 -> GELU  Models/vmamba.py:624-625
+ *   tramba_dw_pack              weight re-layout + DWMSMlp fold (h+dw3+dw5+dw7, vmamba.py:624)
  *   tramba_dct_split_cl         DCT2D.forward                   Models/DCT_2D.py:12-29
  *   tramba_linear_cl            Linear2d.forward (1x1 conv)     Models/modules.py:10-13
  *
@@ -135,13 +135,15 @@ int tramba_layernorm_cl(const void *x, const float *w, const float *b, void *y, 
 /* x: (B, H, W, P*P*C) -> y: (B, H*P, W*P, C) with y[b,hP+p1,wP+p2,:] = LN(x[b,h,w,(p1*P+p2)*C : +C]). */
 int tramba_shuffle_norm_cl(const void *x, const float *w, const float *b, void *y, int batch, int h,
                            int wd, int c, int p, float eps, int dtype, void *stream);
-/* depth-wise ks x ks, stride 1, "same" padding.  weight (C, ks, ks) f32, bias (C) f32 or NULL. */
-int tramba_dwconv_cl(const void *x, const float *w, const float *bias, void *y, int batch, int h,
+/* Depth-wise stencils take TAP-MAJOR weights wt (ks*ks, C) f32 + bias bt (C) f32 produced by
+ * tramba_dw_pack from the reference layout w (C, ks, ks), bias (C) or NULL.  With w3/b3/w5/b5
+ * non-NULL (ks = 7) it packs the multi-scale stencil of DWMSMlp: identity + 3x3 + 5x5 + 7x7 folded
+ * into one 7x7 (and b3 + b5 + b7), so y = GELU(h + dw3(h) + dw5(h) + dw7(h)) is ONE dwconv pass. */
+int tramba_dw_pack(const float *w, const float *bias, const float *w3, const float *b3, const float *w5,
+                   const float *b5, float *wt, float *bt, int c, int ks, void *stream);
+/* depth-wise ks x ks, stride 1, "same" padding, y = act(conv(x) + bt). */
+int tramba_dwconv_cl(const void *x, const float *wt, const float *bt, void *y, int batch, int h,
                      int wd, int c, int ks, int act, int dtype, void *stream);
-/* y = GELU(x + dw3(x) + dw5(x) + dw7(x)) with biases. */
-int tramba_dwms_cl(const void *x, const float *w3, const float *b3, const float *w5, const float *b5,
-                   const float *w7, const float *b7, void *y, int batch, int h, int wd, int c,
-                   int dtype, void *stream);
 /* x: (B, n, n, C).  Y = Wy X Wx^T per channel; low = Y[:n/2,:n/2], high = Y[n/2:,n/2:],
  * both (B, n/2, n/2, C).  wx, wy: (n, n) f32.  tmp: (B, n, n, C) f32 workspace. */
 int tramba_dct_split_cl(const void *x, const float *wx, const float *wy, float *tmp, void *high,

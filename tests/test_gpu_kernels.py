@@ -129,18 +129,18 @@ def test_dwconv_and_dwms_cl(dtype, cfg):
     bs = {k: 0.1 * torch.randn(c) for k in (3, 5, 7)}
     tol = 1e-5 if dtype == torch.float32 else 3e-2
     want = F.silu(F.conv2d(xn, ws[3].double(), None, padding=1, groups=c)).permute(0, 2, 3, 1)
-    got = hip().dwconv_cl(x.to(DEV), ws[3].to(DEV), None, 1)
+    got = hip().dwconv_cl(x.to(DEV), *hip().dw_pack(ws[3].to(DEV)), 1)
     np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
     for k in (5, 7):
         want = F.conv2d(xn, ws[k].double(), bs[k].double(), padding=k // 2, groups=c).permute(0, 2, 3, 1)
-        got = hip().dwconv_cl(x.to(DEV), ws[k].to(DEV), bs[k].to(DEV), 0)
+        got = hip().dwconv_cl(x.to(DEV), *hip().dw_pack(ws[k].to(DEV), bs[k].to(DEV)), 0)
         np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
     acc = xn
     for k in (3, 5, 7):
         acc = acc + F.conv2d(xn, ws[k].double(), bs[k].double(), padding=k // 2, groups=c)
     want = F.gelu(acc).permute(0, 2, 3, 1)
     g = lambda t: t.to(DEV)
-    got = hip().dwms_cl(g(x), g(ws[3]), g(bs[3]), g(ws[5]), g(bs[5]), g(ws[7]), g(bs[7]))
+    got = hip().dwconv_cl(g(x), *hip().dw_pack(g(ws[7]), g(bs[7]), g(ws[3]), g(bs[3]), g(ws[5]), g(bs[5])), 2)
     np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
 
 

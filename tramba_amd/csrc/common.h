@@ -84,11 +84,12 @@ __device__ __forceinline__ void store_pack(T *p, const float (&in)[V])
 // full relative precision for small exp(x) while using the hardware exp/log.
 __device__ __forceinline__ float softplus20(float x)
 {
-    if (x > 20.f) return x;
-    float z = __expf(x);
-    float w = 1.f + z;
-    float d = w - 1.f;
-    return d == 0.f ? z : __logf(w) * z * __builtin_amdgcn_rcpf(d);
+    // branch-free: evaluate log1p(exp(min(x,20))) and select x beyond the threshold
+    const float z = __expf(fminf(x, 20.f));
+    const float w = 1.f + z;
+    const float d = w - 1.f;
+    const float sp = d == 0.f ? z : __logf(w) * z * __builtin_amdgcn_rcpf(d);
+    return x > 20.f ? x : sp;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }

@@ -125,7 +125,7 @@ constexpr int kBK = 64;
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ (row & 7); }
 
-template <typename T, typename TO, int BM, int BN>
+template <typename T, typename TO, int BM, int BN, int PF>
 __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__ x, const T *__restrict__ w,
                                                           const float *__restrict__ bias,
                                                           const T *__restrict__ res, TO *__restrict__ y, long M,
@@ -153,46 +153,51 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    frag8_t ra[A_PER_T], rb[B_PER_T];
-    auto gload = [&](int kt) {
+    // register pipeline: stage i holds the operands of tile kt+1+i (PF tiles in flight: short-M GEMMs
+    // run ~1 block per CU, so the K loop itself must cover the HBM/L2 latency)
+    struct Stage { frag8_t a[A_PER_T], b[B_PER_T]; };
+    auto gload = [&](int kt, Stage &st) {
         const int k0 = kt * kBK;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             const int q = tid + i * 256, row = q >> 3, c = q & 7;
             const long gr = m0 + row;
             frag8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gr < M && k0 + c * 8 < K) v = *reinterpret_cast<const frag8_t *>(x + gr * K + k0 + c * 8);
-            ra[i] = v;
+            if (kt < nk && gr < M && k0 + c * 8 < K) v = *reinterpret_cast<const frag8_t *>(x + gr * K + k0 + c * 8);
+            st.a[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
             const int q = tid + i * 256, row = q >> 3, c = q & 7;
             const int gn = n0 + row;
             frag8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gn < N && k0 + c * 8 < K) v = *reinterpret_cast<const frag8_t *>(w + (long)gn * K + k0 + c * 8);
-            rb[i] = v;
+            if (kt < nk && gn < N && k0 + c * 8 < K) v = *reinterpret_cast<const frag8_t *>(w + (long)gn * K + k0 + c * 8);
+            st.b[i] = v;
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const Stage &st) {
         unsigned char *As = lds + buf * TILE_BYTES, *Bs = As + BM * kBK * 2;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             const int q = tid + i * 256, row = q >> 3, c = q & 7;
-            *reinterpret_cast<frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16) = ra[i];
+            *reinterpret_cast<frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16) = st.a[i];
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
             const int q = tid + i * 256, row = q >> 3, c = q & 7;
-            *reinterpret_cast<frag8_t *>(Bs + row * 128 + swz_chunk(row, c) * 16) = rb[i];
+            *reinterpret_cast<frag8_t *>(Bs + row * 128 + swz_chunk(row, c) * 16) = st.b[i];
         }
     };
 
-    gload(0);
-    lstore(0);
+    Stage pipe[PF], incoming;
+    gload(0, incoming);
+    lstore(0, incoming);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) gload(1 + i, pipe[i]);
     __syncthreads();
     const int r32 = lane & 31, hi = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
+        gload(kt + 1 + PF, incoming);
         const unsigned char *As = lds + (kt & 1) * TILE_BYTES, *Bs = As + BM * kBK * 2;
 #pragma unroll
         for (int kk = 0; kk < kBK / 16; ++kk) {
@@ -213,7 +218,10 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
         }
-        if (kt + 1 < nk) lstore((kt + 1) & 1);
+        if (kt + 1 < nk) lstore((kt + 1) & 1, pipe[0]);
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i) pipe[i] = pipe[i + 1];
+        pipe[PF - 1] = incoming;
         __syncthreads();
     }
 
@@ -276,11 +284,11 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
     const long big = ((m + 127) / 128) * ((n + 127) / 128);
     if (big >= 384) {
         dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
-        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
                            (const T *)res, (TO *)y, m, n, k, act);
     } else {
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
-        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 64, 64>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 64, 64, 3>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
                            (const T *)res, (TO *)y, m, n, k, act);
     }
 }

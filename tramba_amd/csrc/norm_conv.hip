@@ -6,11 +6,11 @@
 //                     PatchExpand / FinalPatchExpand_X4 / FreqExpand2D (modules.py:209-218,
 //                     240-249, 687-696): in channels-last the shuffle only re-addresses whole
 //                     C-vectors, so it is fused into the norm's store.
-//   dwconv_cl         SS2D's depth-wise 3x3 + SiLU (vmamba.py:283-285).
-//   dwms_cl           DWMSMlp's h + dw3(h) + dw5(h) + dw7(h) -> GELU (vmamba.py:624-625): the
-//                     four linear terms are ONE 7x7 depth-wise stencil whose taps are summed
-//                     in registers (identity + 3x3 + 5x5 + 7x7), so h is read once.
-// One wave normalises one row; lanes map to channels with 2..16-byte accesses.
+//   dwconv_cl         SS2D's depth-wise 3x3 + SiLU (vmamba.py:283-285) and, with the stencil packed
+//                     by dw_pack, DWMSMlp's h + dw3(h) + dw5(h) + dw7(h) -> GELU (vmamba.py:624-625):
+//                     the four linear terms are ONE 7x7 depth-wise stencil (identity + 3x3 + 5x5 +
+//                     7x7 summed at pack time), so h is read once.
+// Lanes map to channels with 4..16-byte accesses.
 #include "common.h"
 #include "norm.h"
 
@@ -68,10 +68,87 @@ __global__ __launch_bounds__(256) void layernorm_cl_kernel(const T *__restrict__
     }
 }
 
+// Short rows (C <= 64*V): LPR lanes per row, 64/LPR rows per wave, 16-byte accesses -- a wave keeps
+// 64/LPR independent rows in flight instead of one (the one-row form is latency-bound at C = 128).
+template <typename T, int V, int LPR>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const T *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bvec, T *__restrict__ y,
+                                                            long rows, int C, float eps, int act, int P, int H,
+                                                            int W)
+{
+    constexpr int RPW = kWave / LPR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int sub = lane % LPR;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long row = wave * RPW + lane / LPR;
+    const bool rok = row < rows;
+    const int c0 = sub * V;
+    const bool cok = c0 + V <= C;
+    float v[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = 0.f;
+    if (rok && cok) load_pack<T, V>(x + row * C + c0, v);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) s += v[i];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, LPR);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const float t = cok ? v[i] - mean : 0.f;
+        q = fmaf(t, t, q);
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, LPR);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!(rok && cok)) return;
+    long orow = row;
+    if (P > 1) {
+        const int pp = (int)(row % (P * P));
+        const long pix = row / (P * P);
+        const int wi = (int)(pix % W);
+        const long bh = pix / W;
+        const int hi = (int)(bh % H);
+        const long b = bh / H;
+        orow = (b * (long)(H * P) + (long)hi * P + pp / P) * (long)(W * P) + (long)wi * P + pp % P;
+    }
+    float wv[V], bv[V], o[V];
+    load_pack<float, V>(w + c0, wv);
+    load_pack<float, V>(bvec + c0, bv);
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = apply_act((v[i] - mean) * rstd * wv[i] + bv[i], act);
+    store_pack<T, V>(y + orow * C + c0, o);
+}
+
 template <typename T>
 static int launch_layernorm(const void *x, const float *w, const float *b, void *y, long rows, int c,
                             float eps, int act, int P, int H, int W, hipStream_t s)
 {
+    constexpr int VM = sizeof(T) == 2 ? 8 : 4;
+    if (c % VM == 0 && c / VM <= kWave && aligned16(w) && aligned16(b)) {
+        const int need = c / VM;
+        int lpr = 1;
+        while (lpr < need) lpr <<= 1;
+        const long waves = (rows + (kWave / lpr) - 1) / (kWave / lpr);
+        dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define GOR_(L_)                                                                                            \
+    hipLaunchKernelGGL((layernorm_rows_kernel<T, VM, L_>), grid, block, 0, s, (const T *)x, w, b, (T *)y, rows, c, \
+                       eps, act, P, H, W)
+        switch (lpr) {
+        case 1: GOR_(1); break;
+        case 2: GOR_(2); break;
+        case 4: GOR_(4); break;
+        case 8: GOR_(8); break;
+        case 16: GOR_(16); break;
+        case 32: GOR_(32); break;
+        default: GOR_(64); break;
+        }
+#undef GOR_
+        TRAMBA_LAUNCH_CHECK();
+        return TRAMBA_OK;
+    }
     const int maxv = sizeof(T) == 2 ? 8 : 4;
     const int v = norm_vec(c, maxv);
     if ((c + kWave * v - 1) / (kWave * v) > kNormMaxIt) {
@@ -94,59 +171,69 @@ static int launch_layernorm(const void *x, const float *w, const float *b, void 
 }
 
 // ------------------------------------------------------------------------------ depth-wise stencils
-// thread = V channels x TW consecutive output columns of one row.  MS = multi-scale (dwms).
-template <typename T, int KS, int V, int TW, bool MS>
-__global__ __launch_bounds__(256) void dwconv_cl_kernel(const T *__restrict__ x, const float *__restrict__ w,
-                                                       const float *__restrict__ bias,
-                                                       const float *__restrict__ w3, const float *__restrict__ b3,
-                                                       const float *__restrict__ w5, const float *__restrict__ b5,
-                                                       T *__restrict__ y, int B, int H, int W, int C, int act,
-                                                       long nthreads)
+// Weights arrive TAP-MAJOR (ks*ks, C): lanes map to channels, so every tap is one coalesced load
+// (the reference's (C,1,ks,ks) layout would make each lane walk its own 49-float row).
+// dw_pack_kernel builds that layout once per weight version; for the multi-scale MLP it also folds
+// identity + 3x3 + 5x5 + 7x7 (and the three biases) into ONE 7x7 stencil.
+__global__ __launch_bounds__(256) void dw_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                                     const float *__restrict__ w3, const float *__restrict__ b3,
+                                                     const float *__restrict__ w5, const float *__restrict__ b5,
+                                                     float *__restrict__ wt, float *__restrict__ bt, int C, int ks,
+                                                     int multiscale)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int R = ks / 2;
+    for (int dy = 0; dy < ks; ++dy)
+        for (int dx = 0; dx < ks; ++dx) {
+            float v = w[(long)c * ks * ks + dy * ks + dx];
+            if (multiscale) {  // ks == 7
+                const int y5 = dy - 1, x5 = dx - 1, y3 = dy - 2, x3 = dx - 2;
+                if (y5 >= 0 && y5 < 5 && x5 >= 0 && x5 < 5) v += w5[(long)c * 25 + y5 * 5 + x5];
+                if (y3 >= 0 && y3 < 3 && x3 >= 0 && x3 < 3) v += w3[(long)c * 9 + y3 * 3 + x3];
+                if (dy == R && dx == R) v += 1.f;
+            }
+            wt[(long)(dy * ks + dx) * C + c] = v;
+        }
+    float bv = bias ? bias[c] : 0.f;
+    if (multiscale) bv += b3[c] + b5[c];
+    bt[c] = bv;
+}
+
+// thread = V channels x TW consecutive output columns of one row.
+template <typename T, int KS, int V, int TW>
+__global__ __launch_bounds__(256) void dwconv_cl_kernel(const T *__restrict__ x, const float *__restrict__ wt,
+                                                       const float *__restrict__ bt, T *__restrict__ y, int B,
+                                                       int H, int W, int C, int act, long nthreads)
 {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= nthreads) return;
-    const int cg = C / V, wt = (W + TW - 1) / TW;
+    const int cg = C / V, wtiles = (W + TW - 1) / TW;
     const int c0 = (int)(tid % cg) * V;
     long rest = tid / cg;
-    const int w0 = (int)(rest % wt) * TW;
-    rest /= wt;
+    const int w0 = (int)(rest % wtiles) * TW;
+    rest /= wtiles;
     const int h = (int)(rest % H);
     const int b = (int)(rest / H);
     constexpr int R = KS / 2;
 
-    float wr[KS * KS][V];
-    float bs[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-        const int c = c0 + v;
-        bs[v] = bias ? bias[c] : 0.f;
-#pragma unroll
-        for (int t = 0; t < KS * KS; ++t) wr[t][v] = w[(long)c * KS * KS + t];
-        if (MS) {  // fold identity, 3x3 and 5x5 into the 7x7 taps
-            bs[v] += b3[c] + b5[c];
-#pragma unroll
-            for (int dy = 0; dy < 5; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 5; ++dx) wr[(dy + 1) * KS + dx + 1][v] += w5[(long)c * 25 + dy * 5 + dx];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) wr[(dy + 2) * KS + dx + 2][v] += w3[(long)c * 9 + dy * 3 + dx];
-            wr[R * KS + R][v] += 1.f;
-        }
-    }
-
     float acc[TW][V];
+    {
+        float bs[V];
+        load_pack<float, V>(bt + c0, bs);
 #pragma unroll
-    for (int t = 0; t < TW; ++t)
+        for (int t = 0; t < TW; ++t)
 #pragma unroll
-        for (int v = 0; v < V; ++v) acc[t][v] = bs[v];
-
+            for (int v = 0; v < V; ++v) acc[t][v] = bs[v];
+    }
     const T *xb = x + (long)b * H * W * C + c0;
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
         const int hy = h + dy - R;
         if (hy < 0 || hy >= H) continue;
+        float wr[KS][V];
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) load_pack<float, V>(wt + (long)(dy * KS + dx) * C + c0, wr[dx]);
         float xin[TW + KS - 1][V];
 #pragma unroll
         for (int i = 0; i < TW + KS - 1; ++i) {
@@ -163,7 +250,7 @@ __global__ __launch_bounds__(256) void dwconv_cl_kernel(const T *__restrict__ x,
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
-                for (int v = 0; v < V; ++v) acc[t][v] = fmaf(wr[dy * KS + dx][v], xin[t + dx][v], acc[t][v]);
+                for (int v = 0; v < V; ++v) acc[t][v] = fmaf(wr[dx][v], xin[t + dx][v], acc[t][v]);
     }
     T *yb = y + (long)b * H * W * C + c0;
 #pragma unroll
@@ -177,23 +264,22 @@ __global__ __launch_bounds__(256) void dwconv_cl_kernel(const T *__restrict__ x,
     }
 }
 
-template <typename T, int KS, bool MS>
-static int launch_dw(const void *x, const float *w, const float *bias, const float *w3, const float *b3,
-                     const float *w5, const float *b5, void *y, int B, int H, int W, int C, int act,
+template <typename T, int KS>
+static int launch_dw(const void *x, const float *wt, const float *bt, void *y, int B, int H, int W, int C, int act,
                      hipStream_t s)
 {
     constexpr int TW = 4;
-    const int cg_v2 = C / 2;
-    const bool v2 = (C % 2 == 0);
-    const int wt = (W + TW - 1) / TW;
-    const long nthreads = (long)(v2 ? cg_v2 : C) * wt * H * B;
+    const int wtiles = (W + TW - 1) / TW;
+    const int v = (C % 4 == 0) ? 4 : ((C % 2 == 0) ? 2 : 1);
+    const long nthreads = (long)(C / v) * wtiles * H * B;
     dim3 grid((unsigned)((nthreads + 255) / 256)), block(256);
-    if (v2)
-        hipLaunchKernelGGL((dwconv_cl_kernel<T, KS, 2, TW, MS>), grid, block, 0, s, (const T *)x, w, bias, w3,
-                           b3, w5, b5, (T *)y, B, H, W, C, act, nthreads);
-    else
-        hipLaunchKernelGGL((dwconv_cl_kernel<T, KS, 1, TW, MS>), grid, block, 0, s, (const T *)x, w, bias, w3,
-                           b3, w5, b5, (T *)y, B, H, W, C, act, nthreads);
+#define GO_(V_)                                                                                            \
+    hipLaunchKernelGGL((dwconv_cl_kernel<T, KS, V_, TW>), grid, block, 0, s, (const T *)x, wt, bt, (T *)y, B, H, W, \
+                       C, act, nthreads)
+    if (v == 4) GO_(4);
+    else if (v == 2) GO_(2);
+    else GO_(1);
+#undef GO_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
@@ -225,29 +311,32 @@ extern "C" int tramba_shuffle_norm_cl(const void *x, const float *w, const float
     return TRAMBA_OK;
 }
 
-extern "C" int tramba_dwconv_cl(const void *x, const float *w, const float *bias, void *y, int batch, int h,
-                                int wd, int c, int ks, int act, int dtype, void *stream)
+extern "C" int tramba_dw_pack(const float *w, const float *bias, const float *w3, const float *b3,
+                              const float *w5, const float *b5, float *wt, float *bt, int c, int ks,
+                              void *stream)
 {
-    TRAMBA_CHECK(x && w && y, "dwconv_cl: null tensor");
-    TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0, "dwconv_cl: empty shape");
-    TRAMBA_CHECK(ks == 3 || ks == 5 || ks == 7, "dwconv_cl: kernel size %d unsupported (3,5,7)", ks);
-    hipStream_t s = (hipStream_t)stream;
-    TRAMBA_DISPATCH_DTYPE(dtype, T, {
-        if (ks == 3) return launch_dw<T, 3, false>(x, w, bias, nullptr, nullptr, nullptr, nullptr, y, batch, h, wd, c, act, s);
-        if (ks == 5) return launch_dw<T, 5, false>(x, w, bias, nullptr, nullptr, nullptr, nullptr, y, batch, h, wd, c, act, s);
-        return launch_dw<T, 7, false>(x, w, bias, nullptr, nullptr, nullptr, nullptr, y, batch, h, wd, c, act, s);
-    });
+    TRAMBA_CHECK(w && wt && bt && c > 0, "dw_pack: null tensor");
+    TRAMBA_CHECK(ks == 3 || ks == 5 || ks == 7, "dw_pack: kernel size %d unsupported (3,5,7)", ks);
+    const int ms = (w3 || w5) ? 1 : 0;
+    TRAMBA_CHECK(!ms || (ks == 7 && w3 && b3 && w5 && b5 && bias), "dw_pack: multi-scale needs ks=7 and all six tensors");
+    hipLaunchKernelGGL(dw_pack_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, bias, w3, b3, w5, b5,
+                       wt, bt, c, ks, ms);
+    TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
 
-extern "C" int tramba_dwms_cl(const void *x, const float *w3, const float *b3, const float *w5,
-                              const float *b5, const float *w7, const float *b7, void *y, int batch, int h,
-                              int wd, int c, int dtype, void *stream)
+extern "C" int tramba_dwconv_cl(const void *x, const float *wt, const float *bt, void *y, int batch, int h,
+                                int wd, int c, int ks, int act, int dtype, void *stream)
 {
-    TRAMBA_CHECK(x && w3 && b3 && w5 && b5 && w7 && b7 && y, "dwms_cl: null tensor");
-    TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0, "dwms_cl: empty shape");
-    TRAMBA_DISPATCH_DTYPE(dtype, T,
-        return launch_dw<T, 7, true>(x, w7, b7, w3, b3, w5, b5, y, batch, h, wd, c, TRAMBA_ACT_GELU,
-                                     (hipStream_t)stream));
+    TRAMBA_CHECK(x && wt && bt && y, "dwconv_cl: null tensor");
+    TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0, "dwconv_cl: empty shape");
+    TRAMBA_CHECK(ks == 3 || ks == 5 || ks == 7, "dwconv_cl: kernel size %d unsupported (3,5,7)", ks);
+    TRAMBA_CHECK(aligned16(x) && aligned16(y) && aligned16(wt) && aligned16(bt), "dwconv_cl: tensors must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    TRAMBA_DISPATCH_DTYPE(dtype, T, {
+        if (ks == 3) return launch_dw<T, 3>(x, wt, bt, y, batch, h, wd, c, act, s);
+        if (ks == 5) return launch_dw<T, 5>(x, wt, bt, y, batch, h, wd, c, act, s);
+        return launch_dw<T, 7>(x, wt, bt, y, batch, h, wd, c, act, s);
+    });
     return TRAMBA_OK;
 }

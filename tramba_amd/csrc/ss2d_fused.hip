@@ -109,10 +109,11 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const float An = Aneg[(long)k * D + cc_];
     const float Dk = Ds[(long)k * D + cc_];
 
-    const T *xb = x + (long)b * L * D + cc_;
+    // wave-uniform bases (SGPR) + 32-bit per-lane element offsets (host guarantees < 2^31 elements)
+    const T *xb = x + (long)b * L * D;
     const float *pb = xdbl + (long)b * L * PC + (long)k * RG;
     const int32_t *tk = table + (long)k * L;
-    TY *yb = ys + ((long)b * K + k) * L * D + cc_;
+    TY *yb = ys + ((long)b * K + k) * L * D;
     float *st = &stage[wv][0][0];
 
     const int span = W * kTP;
@@ -123,20 +124,18 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         return l < L ? tk[l] : 0;
     };
     auto load_rows = [&](int pix, TileOps<NK> &o) {
-        const float *row = pb + (long)pix * PC;
+        const float *row = pb + (unsigned)(pix * PC);
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
             const int r0 = kk * 16 + hi * 8;
             if (rvec) {
-                if (r0 < R) {
-                    const float4 v0 = *reinterpret_cast<const float4 *>(row + r0);
-                    const float4 v1 = *reinterpret_cast<const float4 *>(row + r0 + 4);
-                    o.araw[kk][0] = v0.x; o.araw[kk][1] = v0.y; o.araw[kk][2] = v0.z; o.araw[kk][3] = v0.w;
-                    o.araw[kk][4] = v1.x; o.araw[kk][5] = v1.y; o.araw[kk][6] = v1.z; o.araw[kk][7] = v1.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o.araw[kk][j] = 0.f;
-                }
+                // ranks >= R meet zero dt_w fragments, so those lanes may read any finite in-row
+                // floats: clamp the offset instead of branching (RG >= R + 2 >= 10)
+                const int rr = r0 < R ? r0 : RG - 8;
+                const float4 v0 = *reinterpret_cast<const float4 *>(row + rr);
+                const float4 v1 = *reinterpret_cast<const float4 *>(row + rr + 4);
+                o.araw[kk][0] = v0.x; o.araw[kk][1] = v0.y; o.araw[kk][2] = v0.z; o.araw[kk][3] = v0.w;
+                o.araw[kk][4] = v1.x; o.araw[kk][5] = v1.y; o.araw[kk][6] = v1.z; o.araw[kk][7] = v1.w;
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o.araw[kk][j] = r0 + j < R ? row[r0 + j] : 0.f;
@@ -157,29 +156,33 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pix = __builtin_bit_cast(int, pixf[r]);
-            o.u[r] = Cvt<T>::to_f(xb[(long)pix * D]);
+            o.u[r] = Cvt<T>::to_f(xb[(unsigned)(pix * D + cc_)]);
         }
     };
 
-    TileOps<NK> cur, nxt;
+    // Gather pipeline: tile s computes while tiles s+1 (and s+2 when registers allow, NK <= 2) are
+    // in flight.  fetch(t) needs the index vector of tile t, which is itself loaded one step earlier.
+    constexpr bool DEEP = NK <= 2;
+    constexpr int AHEAD = DEEP ? 2 : 1;
+    TileOps<NK> cur, n1, n2;
     float pixf[16];
-    {   // prologue: tile 0 operands, index vector of tile 1
-        const int i0 = load_idx(0);
-        if (hi == 0) st[r32] = __builtin_bit_cast(float, i0);
+    auto fetch = [&](int idxv, TileOps<NK> &o) {  // idxv: pixel index of MY position in that tile
+        if (hi == 0) st[r32] = __builtin_bit_cast(float, idxv);
         __builtin_amdgcn_wave_barrier();
         read_stage4(0, pixf);
-        load_rows(i0, cur);
-        load_u(pixf, cur);
-    }
-    int idx_n = nsuper > 1 ? load_idx(1) : 0;
+        __builtin_amdgcn_wave_barrier();
+        load_rows(idxv, o);
+        load_u(pixf, o);
+    };
+    fetch(load_idx(0), cur);
+    if (DEEP && nsuper > 1) fetch(load_idx(1), n1);
+    int idx_ahead = nsuper > AHEAD ? load_idx(AHEAD) : 0;   // index vector of tile s + AHEAD
 
     float carry = 0.f;
     for (int s = 0; s < nsuper; ++s) {
         const int l0 = s * span + wv * kTP;
-        const bool more = s + 1 < nsuper;
-        // publish per-position scalars of THIS tile (B, C) and the pixel indices of the NEXT tile
+        // per-position scalars of THIS tile
         if (hi == 0) {
-            st[r32] = __builtin_bit_cast(float, idx_n);
             st[kTP + r32] = cur.bv;
             st[2 * kTP + r32] = cur.cv;
         }
@@ -187,11 +190,9 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         float Bp[16], Cp[16];
         read_stage4(1, Bp);
         read_stage4(2, Cp);
-        if (more) {  // wave-uniform: next tile's gathers fly under this tile's arithmetic
-            read_stage4(0, pixf);
-            load_rows(idx_n, nxt);
-            load_u(pixf, nxt);
-            idx_n = s + 2 < nsuper ? load_idx(s + 2) : 0;
+        if (s + AHEAD < nsuper) {  // wave-uniform
+            if (DEEP) fetch(idx_ahead, n2); else fetch(idx_ahead, n1);
+            idx_ahead = s + AHEAD + 1 < nsuper ? load_idx(s + AHEAD + 1) : 0;
         }
 
         // ---- dt_proj on the matrix core
@@ -256,6 +257,8 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         }
         carry = h;
         // ---- replay and stream out
+        const bool full = l0 + kTP <= L;  // wave-uniform: only the last tile of a sequence is ragged
+        unsigned yoff = (unsigned)((l0 + 4 * hi) * D + cc_);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float hh = fmaf(preA[g], hin, preH[g]);
@@ -263,27 +266,35 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
             for (int q = 0; q < 4; ++q) {
                 const int r = 4 * g + q;
                 hh = fmaf(a[r], hh, bb[r]);
-                const int l = l0 + q + 8 * g + 4 * hi;
-                if (l < L && cok) yb[(long)l * D] = Cvt<TY>::from_f(fmaf(Cp[r], hh, Dk * cur.u[r]));
+                const TY out = Cvt<TY>::from_f(fmaf(Cp[r], hh, Dk * cur.u[r]));
+                const unsigned off = yoff + (unsigned)((q + 8 * g) * D);
+                if (full) {
+                    if (cok) yb[off] = out;
+                } else if (cok && l0 + q + 8 * g + 4 * hi < L) {
+                    yb[off] = out;
+                }
             }
         }
-        if (more) cur = nxt;
+        cur = n1;
+        if (DEEP) n1 = n2;
         __builtin_amdgcn_wave_barrier();
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename TY, typename T, int V>
+// NIT = wave iterations per row (D <= 64*V*NIT); BATCH rows of ys are requested back to back
+// before any is consumed, so a pixel pays ~1 memory latency instead of one per direction.
+template <typename TY, typename T, int V, int NIT>
 __global__ __launch_bounds__(256) void ss2d_merge_norm_cl_kernel(
     const TY *__restrict__ ys, const int32_t *__restrict__ inv_ptr, const int32_t *__restrict__ inv_idx,
     const float *__restrict__ ln_w, const float *__restrict__ ln_b, T *__restrict__ y, long npix, int L,
     int D, int K, float eps, int act)
 {
+    constexpr int BATCH = NIT == 1 ? 4 : (NIT == 2 ? 4 : (NIT == 4 ? 2 : 1));
     const int lane = threadIdx.x & (kWave - 1);
     const long pix = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (pix >= npix) return;
     const int b = (int)(pix / L), p = (int)(pix % L);
-    const int nit = (D + kWave * V - 1) / (kWave * V);
     float acc[kNormMaxIt][V];
 #pragma unroll
     for (int it = 0; it < kNormMaxIt; ++it)
@@ -291,36 +302,46 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_cl_kernel(
         for (int v = 0; v < V; ++v) acc[it][v] = 0.f;
 
     const TY *yb = ys + (long)b * K * L * D;
-    const int e1 = inv_ptr[p + 1];
-    for (int e = inv_ptr[p]; e < e1; ++e) {
-        const TY *row = yb + (long)inv_idx[e] * D;  // entry = k*L + l indexes (K*L, D) rows
+    const int e0 = inv_ptr[p], e1 = inv_ptr[p + 1];
+    for (int e = e0; e < e1; e += BATCH) {
+        const int mine = (lane < BATCH && e + lane < e1) ? inv_idx[e + lane] : 0;
+        float t[BATCH][NIT][V];
 #pragma unroll
-        for (int it = 0; it < kNormMaxIt; ++it) {
-            if (it < nit) {
-                const int c0 = (it * kWave + lane) * V;
-                if (c0 + V <= D) {
-                    float t[V];
-                    load_pack<TY, V>(row + c0, t);
+        for (int j = 0; j < BATCH; ++j) {
+            if (e + j < e1) {  // wave-uniform
+                const TY *row = yb + (long)__builtin_amdgcn_readlane(mine, j) * D;  // entry = k*L + l
 #pragma unroll
-                    for (int v = 0; v < V; ++v) acc[it][v] += t[v];
+                for (int it = 0; it < NIT; ++it) {
+                    const int c0 = (it * kWave + lane) * V;
+                    if (c0 + V <= D) {
+                        load_pack<TY, V>(row + c0, t[j][it]);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) t[j][it][v] = 0.f;
+                    }
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+            if (e + j < e1)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[it][v] += t[j][it][v];
     }
     float mean, rstd;
-    wave_layernorm<V>(acc, nit, D, lane, eps, mean, rstd);
+    wave_layernorm<V>(acc, NIT, D, lane, eps, mean, rstd);
     T *orow = y + pix * D;
 #pragma unroll
-    for (int it = 0; it < kNormMaxIt; ++it) {
-        if (it < nit) {
-            const int c0 = (it * kWave + lane) * V;
-            if (c0 + V <= D) {
-                float o[V];
+    for (int it = 0; it < NIT; ++it) {
+        const int c0 = (it * kWave + lane) * V;
+        if (c0 + V <= D) {
+            float o[V];
 #pragma unroll
-                for (int v = 0; v < V; ++v)
-                    o[v] = apply_act((acc[it][v] - mean) * rstd * ln_w[c0 + v] + ln_b[c0 + v], act);
-                store_pack<T, V>(orow + c0, o);
-            }
+            for (int v = 0; v < V; ++v)
+                o[v] = apply_act((acc[it][v] - mean) * rstd * ln_w[c0 + v] + ln_b[c0 + v], act);
+            store_pack<T, V>(orow + c0, o);
         }
     }
 }
@@ -392,17 +413,25 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
     TRAMBA_CHECK((d + kWave * v - 1) / (kWave * v) <= kNormMaxIt, "ss2d_merge_norm_cl: D=%d too large", d);
     TRAMBA_CHECK(aligned16(ys) && aligned16(y), "ss2d_merge_norm_cl: tensors must be 16-byte aligned");
     dim3 grid((unsigned)((npix + 3) / 4)), block(256);
-#define GO_(TY, T, V_)                                                                                  \
-    hipLaunchKernelGGL((ss2d_merge_norm_cl_kernel<TY, T, V_>), grid, block, 0, s, (const TY *)ys, inv_ptr, \
+    const int nit_need = (d + kWave * v - 1) / (kWave * v);
+    const int nit = nit_need <= 1 ? 1 : (nit_need <= 2 ? 2 : (nit_need <= 4 ? 4 : 8));
+#define GO_(TY, T, V_, N_)                                                                                  \
+    hipLaunchKernelGGL((ss2d_merge_norm_cl_kernel<TY, T, V_, N_>), grid, block, 0, s, (const TY *)ys, inv_ptr, \
                        inv_idx, ln_w, ln_b, (T *)y, npix, l, d, k, eps, act)
+#define BY_N_(TY, T, V_)               \
+    if (nit == 1) GO_(TY, T, V_, 1);   \
+    else if (nit == 2) GO_(TY, T, V_, 2); \
+    else if (nit == 4) GO_(TY, T, V_, 4); \
+    else GO_(TY, T, V_, 8);
 #define BY_V_(TY, T)                   \
-    if (v == 4) GO_(TY, T, 4);         \
-    else if (v == 2) GO_(TY, T, 2);    \
-    else GO_(TY, T, 1);
+    if (v == 4) { BY_N_(TY, T, 4) }    \
+    else if (v == 2) { BY_N_(TY, T, 2) } \
+    else { BY_N_(TY, T, 1) }
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
         if (ys_dtype == TRAMBA_F32) { BY_V_(float, T) } else { BY_V_(T, T) }
     });
 #undef BY_V_
+#undef BY_N_
 #undef GO_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;

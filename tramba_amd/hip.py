@@ -45,8 +45,8 @@ SIGNATURES = {
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_shuffle_norm_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_f, c_int, c_vp]),
+    "tramba_dw_pack": (c_int, [c_vp] * 8 + [c_int] * 2 + [c_vp]),
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
-    "tramba_dwms_cl": (c_int, [c_vp] * 8 + [c_int] * 5 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
 }
@@ -302,23 +302,28 @@ def shuffle_norm_cl(x, w, b, p, eps=1e-5):
     return y
 
 
-def dwconv_cl(x, w, bias, act=ACT_NONE):
-    """x: (B, H, W, C); w: (C, 1, ks, ks) or (C, ks, ks) f32."""
-    _dev(x, w, bias)
+def dw_pack(w, bias=None, w3=None, b3=None, w5=None, b5=None):
+    """Reference-layout depth-wise weights (C,1,ks,ks) -> tap-major (ks*ks, C) f32 + bias (C) f32.
+    With w3/b3/w5/b5 given (ks=7): the folded multi-scale stencil of DWMSMlp."""
+    ts = [_f32(t) for t in (w, bias, w3, b3, w5, b5)]
+    _dev(*ts)
+    c, ks = w.shape[0], w.shape[-1]
+    wt = torch.empty((ks * ks, c), dtype=torch.float32, device=w.device)
+    bt = torch.empty((c,), dtype=torch.float32, device=w.device)
+    _check(lib().tramba_dw_pack(*[_ptr(t) for t in ts], _ptr(wt), _ptr(bt), c, ks, _stream()), "dw_pack")
+    return wt, bt
+
+
+def dwconv_cl(x, wt, bt, act=ACT_NONE):
+    """x: (B, H, W, C); wt: (ks*ks, C) f32 tap-major, bt: (C) f32 (see dw_pack)."""
+    _dev(x, wt, bt)
     bb, h, wd, c = x.shape
-    ks = w.shape[-1]
+    ks = int(round(wt.shape[0] ** 0.5))
+    if wt.shape != (ks * ks, c) or bt.shape != (c,):
+        raise TrambaHipError(f"dwconv_cl: packed weight {tuple(wt.shape)} does not match C={c}")
     y = torch.empty_like(x)
-    _check(lib().tramba_dwconv_cl(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), bb, h, wd, c, ks, act, dt(x), _stream()),
+    _check(lib().tramba_dwconv_cl(_ptr(x), _ptr(wt), _ptr(bt), _ptr(y), bb, h, wd, c, ks, act, dt(x), _stream()),
            "dwconv_cl")
-    return y
-
-
-def dwms_cl(x, w3, b3, w5, b5, w7, b7):
-    _dev(x, w3, b3, w5, b5, w7, b7)
-    bb, h, wd, c = x.shape
-    y = torch.empty_like(x)
-    _check(lib().tramba_dwms_cl(_ptr(x), _ptr(w3), _ptr(b3), _ptr(w5), _ptr(b5), _ptr(w7), _ptr(b7), _ptr(y),
-                                bb, h, wd, c, dt(x), _stream()), "dwms_cl")
     return y
 
 

@@ -66,6 +66,30 @@ def _f32(p):
     return hip._f32(p)
 
 
+class _PackCache:
+    """Derived, kernel-ready copies of parameters (packed stencils, padded projections, -exp(A)),
+    rebuilt only when a source parameter changes (version counter / storage / dtype)."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, name, params, builder):
+        key = tuple((p._version, p.data_ptr(), p.dtype, str(p.device)) for p in params if p is not None)
+        hit = self._store.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, builder())
+            self._store[name] = hit
+        return hit[1]
+
+
+def _cache(module) -> _PackCache:
+    c = module.__dict__.get("_tramba_cache")
+    if c is None:
+        c = module.__dict__["_tramba_cache"] = _PackCache()
+    return c
+
+
 def _act_torch(x, act):
     if act == hip.ACT_GELU:
         return F.gelu(x)
@@ -373,14 +397,16 @@ class SS2D(nn.Module):
                 and _infer(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs))
 
     def _padded_x_proj(self, dtype):
-        """x_proj weight in the (K*RG, D) layout of the fused scan; cached until the parameter changes."""
+        """x_proj weight in the (K*RG, D) layout of the fused scan."""
         p = self.x_proj_weight
-        key = (p._version, p.data_ptr(), dtype, p.device)
-        cache = getattr(self, "_xproj_cache", None)
-        if cache is None or cache[0] != key:
-            cache = (key, hip.pad_x_proj_weight(p.detach().to(dtype)).contiguous())
-            self._xproj_cache = cache
-        return cache[1]
+        return _cache(self).get(("xproj", dtype), (p,), lambda: hip.pad_x_proj_weight(p.detach().to(dtype)).contiguous())
+
+    def _scan_params(self):
+        """fp32 kernel-ready (dt_w, dt_bias, -exp(A_logs), Ds)."""
+        ps = (self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds)
+        return _cache(self).get("scan", ps, lambda: (
+            _f32(self.dt_projs_weight).clone(), _f32(self.dt_projs_bias).reshape(-1).clone(),
+            (-torch.exp(self.A_logs.detach().float())).reshape(-1).contiguous(), _f32(self.Ds).clone()))
 
     def _core_fused_cl(self, x):
         """x (B,H,W,D) after conv+SiLU -> GELU(out_norm(merge(scan(...)))), all HIP."""
@@ -389,10 +415,9 @@ class SS2D(nn.Module):
         order = hip.scan_order(self.scan._tramba_family, h, w, x.device)
         xf = x.view(b, h * w, d)
         xdbl = hip.linear_cl(xf, self._padded_x_proj(x.dtype), out_dtype=torch.float32)  # x_proj once, spatial order
-        a_neg = -torch.exp(self.A_logs.detach().float()).reshape(-1)
+        dt_w, dt_b, a_neg, ds = self._scan_params()
         ys_dtype = torch.float32 if YS_DTYPE == "f32" else x.dtype
-        ys = hip.ss2d_scan_cl(xf, xdbl, order, _f32(self.dt_projs_weight), _f32(self.dt_projs_bias).reshape(-1),
-                              a_neg, _f32(self.Ds), ys_dtype)
+        ys = hip.ss2d_scan_cl(xf, xdbl, order, dt_w, dt_b, a_neg, ds, ys_dtype)
         y = hip.ss2d_merge_norm_cl(ys, order, _f32(self.out_norm.weight), _f32(self.out_norm.bias),
                                    self.out_norm.eps, hip.ACT_GELU, x.dtype)
         return y.view(b, h, w, d)
@@ -421,7 +446,9 @@ class SS2D(nn.Module):
         x = self.in_proj._forward_cl(x)
         if self.with_dconv:
             if _infer(x, self.conv2d.weight):
-                x = hip.dwconv_cl(x, _f32(self.conv2d.weight), _f32(self.conv2d.bias), hip.ACT_SILU)
+                cv = self.conv2d
+                wt, bt = _cache(self).get("dw", (cv.weight, cv.bias), lambda: hip.dw_pack(cv.weight, cv.bias))
+                x = hip.dwconv_cl(x, wt, bt, hip.ACT_SILU)
             else:
                 wc = self.conv2d.weight.to(x.dtype)
                 bc = None if self.conv2d.bias is None else self.conv2d.bias.to(x.dtype)
@@ -483,7 +510,8 @@ class DWConv(nn.Module):
     def _forward_cl(self, x):
         c = self.dw_conv
         if _infer(x, c.weight):
-            return hip.dwconv_cl(x, _f32(c.weight), _f32(c.bias), hip.ACT_NONE)
+            wt, bt = _cache(self).get("dw", (c.weight, c.bias), lambda: hip.dw_pack(c.weight, c.bias))
+            return hip.dwconv_cl(x, wt, bt, hip.ACT_NONE)
         return to_cl(F.conv2d(from_cl(x), c.weight.to(x.dtype), None if c.bias is None else c.bias.to(x.dtype),
                               padding=c.padding, groups=c.groups))
 
@@ -513,8 +541,10 @@ class DWMSMlp(nn.Module):
         h = self.fc1._forward_cl(x)
         c3, c5, c7 = self.dwc3.dw_conv, self.dwc5.dw_conv, self.dwc7.dw_conv
         if _infer(h, c3.weight, c5.weight, c7.weight):
-            g = hip.dwms_cl(h, _f32(c3.weight), _f32(c3.bias), _f32(c5.weight), _f32(c5.bias), _f32(c7.weight),
-                            _f32(c7.bias))
+            wt, bt = _cache(self).get(
+                "dwms", (c3.weight, c3.bias, c5.weight, c5.bias, c7.weight, c7.bias),
+                lambda: hip.dw_pack(c7.weight, c7.bias, c3.weight, c3.bias, c5.weight, c5.bias))
+            g = hip.dwconv_cl(h, wt, bt, hip.ACT_GELU)
         else:
             g = F.gelu(h + self.dwc3._forward_cl(h) + self.dwc5._forward_cl(h) + self.dwc7._forward_cl(h))
         g = self.drop(g)
