@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--train", action="store_true",
+                    help="also time the training step (fwd+bwd+Adam, DP all-reduce when N>1) and report it as 'train'")
+    ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step (config: 8)")
     return ap.parse_args()
 
 
@@ -100,6 +103,44 @@ def boundary_scan_roofline(dtype):
     return {"bound": "hbm", "kernel": "selective_scan_fwd_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
             "shape": [nb, kd, l], "launches": n, "avg_us": round(ms / n * 1e3, 2)}
+
+
+def bench_train(args, world, rank, dtype):
+    """BASELINE configs[2]/[3]: fwd + bwd (BCE+IoU on 4 outputs) + two-group Adam, batch 8 per GPU,
+    gradients all-reduced over RCCL in 32 MB buckets overlapped with backward when world > 1."""
+    import tramba_amd as ta
+    from tramba_amd import parallel, train
+    torch.manual_seed(1026)
+    model = ta.bulid_model(use_pretrain=False, img_size=args.img).cuda().train()
+    model.compute_dtype = None if dtype == torch.float32 else dtype
+    if world > 1:
+        parallel.broadcast_parameters(model, src=0)
+    red = parallel.GradBucketReducer(model)
+    opt = train.get_opt(1e-4, model)
+    b = args.train_batch
+    x = torch.randn(b, 3, args.img, args.img, generator=torch.Generator().manual_seed(100 + rank)).cuda()
+    y = (torch.rand(b, 1, args.img, args.img, generator=torch.Generator().manual_seed(200 + rank)) > 0.7).float().cuda()
+    steps, warm = max(3, args.steps // 4), 2
+    for _ in range(warm):
+        train.train_step(model, opt, x, y, reducer=red)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        train.train_step(model, opt, x, y, reducer=red)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    return {"metric": "images/sec fwd+bwd+Adam Tramba-V 384x384", "value": round(world * b * steps / dt, 2),
+            "unit": "img/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2), "batch_per_gpu": b,
+            "grad_bytes_per_step": red.bytes_per_step(), "stochastic_depth": "on (0.6 enc / 0.2 dec)",
+            "dtype": args.dtype + " activations, fp32 master weights"}
 
 
 def main():
@@ -177,6 +218,9 @@ def main():
         roof_b = boundary_scan_roofline(dtype)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.img)
+    train_obj = None
+    if args.train:
+        train_obj = bench_train(args, world, rank, dtype)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -192,6 +236,8 @@ def main():
                        "launch": "hipGraph replay" if graph is not None else "eager"},
             "roofline": roof, "roofline_boundary": roof_b, "cpu_baseline": cpu,
         }
+        if train_obj is not None:
+            line["train"] = train_obj
         print(json.dumps(line), flush=True)
 
 

@@ -1,0 +1,143 @@
+"""CPU tests of the data-parallel step (world_size 2, gloo) and of the train-step host logic.
+The reducer is device-agnostic, so it is exercised here with a small stock-torch model; the HIP
+model itself needs a GPU (tests/test_gpu_*.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from oracle import ops as oo
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _toy():
+    torch.manual_seed(7)
+    return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.GELU(), nn.Conv2d(8, 8, 3, padding=1), nn.GELU(),
+                         nn.Conv2d(8, 1, 1))
+
+
+class _Wrap(nn.Module):
+    """gives the toy net the model contract of the path: a list of logits, 'encoder' in some names"""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = _toy()
+        self.decoder = nn.Conv2d(1, 1, 1)
+
+    def forward(self, x):
+        y = self.encoder(x)
+        return [nn.functional.avg_pool2d(y, 2), self.decoder(y)]
+
+
+def _data(n):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, 3, 16, 16, generator=g)
+    m = (torch.rand(n, 1, 16, 16, generator=g) > 0.7).float()
+    return x, m
+
+
+def _worker(rank, world, port, out_dir, steps, bucket_mb):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tramba_amd import parallel, train
+    model = _Wrap()
+    if rank != 0:  # replicas must not depend on identical local seeds
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    parallel.broadcast_parameters(model, src=0)
+    red = parallel.GradBucketReducer(model, bucket_mb=bucket_mb)
+    opt = train.get_opt(1e-2, model)
+    x, m = _data(4 * world)
+    xs, ms = x[rank::world], m[rank::world]
+    losses = []
+    for _ in range(steps):
+        losses.append(float(train.train_step(model, opt, xs, ms, reducer=red)))
+    if rank == 0:
+        torch.save({"sd": model.state_dict(), "losses": losses, "nbuckets": len(red.buckets),
+                    "bytes": red.bytes_per_step()}, os.path.join(out_dir, "r0.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_mb", [32.0, 0.0005])
+def test_dp2_matches_single_process(tmp_path, bucket_mb):
+    """2 ranks x 4 images with bucketed all-reduce == 1 process with the mean of the two shard losses."""
+    from tramba_amd import train
+    steps, world = 3, 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), steps, bucket_mb), nprocs=world, join=True)
+    got = torch.load(os.path.join(tmp_path, "r0.pt"))
+    assert got["nbuckets"] == (1 if bucket_mb > 1 else got["nbuckets"]) and got["nbuckets"] >= 1
+    if bucket_mb < 1:
+        assert got["nbuckets"] > 1  # the multi-bucket / overlap path really ran
+    model = _Wrap()
+    opt = train.get_opt(1e-2, model)
+    x, m = _data(4 * world)
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        loss = sum(train.tramba_loss(model(x[r::world]), m[r::world]) for r in range(world)) / world
+        loss.backward()
+        opt.step()
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(got["sd"][k].numpy(), v.numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+    assert got["bytes"] == sum(p.numel() * 4 for p in model.parameters())
+
+
+def test_loss_matches_oracle_and_reference_known_answer(golden_meta):
+    import synth
+    from tramba_amd import train
+    pred = synth.synth_input("g7_pred", (2, 1, 24, 24), scale=2.0)
+    mask = (synth.synth_input("g7_mask", (2, 1, 24, 24)) > 0.3).float()
+    assert abs(float(train.iou_loss(pred, mask)) - golden_meta["G7"]["iou_loss"]) < 1e-6
+    small = torch.nn.functional.avg_pool2d(pred, 2)
+    a = train.tramba_loss([small, pred], mask)
+    b = oo.tramba_loss([small, pred], mask)
+    assert abs(float(a) - float(b)) < 1e-6
+
+
+def test_optimizer_groups_and_lr_schedule():
+    from tramba_amd import train
+    model = _Wrap()
+    opt = train.get_opt(1e-4, model)
+    n_enc = sum(1 for n, _ in model.named_parameters() if "encoder" in n)
+    assert len(opt.param_groups[0]["params"]) == n_enc and opt.param_groups[0]["lr"] == pytest.approx(1e-5)
+    assert opt.param_groups[1]["lr"] == pytest.approx(1e-4)
+    assert train.adjust_learning_rate(opt, 3, [60], 1e-4, [0.2]) == pytest.approx(1e-4)
+    assert train.adjust_learning_rate(opt, 60, [60], 1e-4, [0.2]) == pytest.approx(2e-5)
+    assert opt.param_groups[0]["lr"] == pytest.approx(2e-6)
+
+
+def test_compat_shims_import():
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tramba_amd", "compat")
+    sys.path.insert(0, compat)
+    try:
+        for mod in ("get_model", "Trambav6", "Trambav6_enc", "Models", "Models.vmamba", "Models.SS2D.csms6s",
+                    "Models.freq_mamba", "Models.DCT_2D", "Models.modules", "Models.mamba_init", "utils", "utils.loss",
+                    "utils.lr"):
+            sys.modules.pop(mod, None)
+        import get_model
+        import Trambav6
+        import Trambav6_enc
+        from Models.SS2D.csms6s import CrossScan_Line, SelectiveScanOflex, selective_scan_cuda_oflex  # noqa: F401
+        from Models.vmamba import SS2D, VSSMEncoder  # noqa: F401
+        from Models.freq_mamba import FreqBlockv6  # noqa: F401
+        from utils.loss import iou_loss  # noqa: F401
+        assert callable(get_model.build) and callable(Trambav6.bulid_model) and callable(Trambav6_enc.bulid_model)
+    finally:
+        sys.path.remove(compat)
+        for mod in ("get_model", "Trambav6", "Trambav6_enc", "Models", "Models.vmamba", "Models.SS2D",
+                    "Models.SS2D.csms6s", "Models.freq_mamba", "Models.DCT_2D", "Models.modules", "Models.mamba_init",
+                    "utils", "utils.loss", "utils.lr"):
+            sys.modules.pop(mod, None)
