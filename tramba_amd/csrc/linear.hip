@@ -156,73 +156,87 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
     // register pipeline: stage i holds the operands of tile kt+1+i (PF tiles in flight: short-M GEMMs
     // run ~1 block per CU, so the K loop itself must cover the HBM/L2 latency)
     struct Stage { frag8_t a[A_PER_T], b[B_PER_T]; };
+    // Loads are UNCONDITIONAL from clamped (always valid) addresses; out-of-range rows / K chunks are
+    // zeroed when the stage is written to LDS.  (Predicated loads become exec-masked branches, after
+    // which hipcc's wait insertion falls back to vmcnt(0) and the register pipeline collapses.)
+    const int kmax = ((K - 1) / 8) * 8;  // start of the last whole 16-byte chunk of a row
     auto gload = [&](int kt, Stage &st) {
-        const int k0 = kt * kBK;
+        const int k0 = (kt < nk ? kt : nk - 1) * kBK;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             const int q = tid + i * 256, row = q >> 3, c = q & 7;
-            const long gr = m0 + row;
-            frag8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kt < nk && gr < M && k0 + c * 8 < K) v = *reinterpret_cast<const frag8_t *>(x + gr * K + k0 + c * 8);
-            st.a[i] = v;
+            const long gr = m0 + row < M ? m0 + row : M - 1;
+            const int kc = k0 + c * 8 <= kmax ? k0 + c * 8 : kmax;
+            st.a[i] = *reinterpret_cast<const frag8_t *>(x + gr * K + kc);
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
             const int q = tid + i * 256, row = q >> 3, c = q & 7;
-            const int gn = n0 + row;
-            frag8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kt < nk && gn < N && k0 + c * 8 < K) v = *reinterpret_cast<const frag8_t *>(w + (long)gn * K + k0 + c * 8);
-            st.b[i] = v;
+            const int gn = n0 + row < N ? n0 + row : N - 1;
+            const int kc = k0 + c * 8 <= kmax ? k0 + c * 8 : kmax;
+            st.b[i] = *reinterpret_cast<const frag8_t *>(w + (long)gn * K + kc);
         }
     };
-    auto lstore = [&](int buf, const Stage &st) {
+    auto lstore = [&](int kt, const Stage &st) {
+        const int buf = kt & 1, k0 = kt * kBK;
         unsigned char *As = lds + buf * TILE_BYTES, *Bs = As + BM * kBK * 2;
+        const frag8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             const int q = tid + i * 256, row = q >> 3, c = q & 7;
-            *reinterpret_cast<frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16) = st.a[i];
+            const bool ok = m0 + row < M && k0 + c * 8 < K;
+            *reinterpret_cast<frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16) = ok ? st.a[i] : zero;
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
             const int q = tid + i * 256, row = q >> 3, c = q & 7;
-            *reinterpret_cast<frag8_t *>(Bs + row * 128 + swz_chunk(row, c) * 16) = st.b[i];
+            const bool ok = n0 + row < N && k0 + c * 8 < K;
+            *reinterpret_cast<frag8_t *>(Bs + row * 128 + swz_chunk(row, c) * 16) = ok ? st.b[i] : zero;
         }
     };
 
-    Stage pipe[PF], incoming;
-    gload(0, incoming);
-    lstore(0, incoming);
+    // Static ring of NS = PF+1 register stages: tile t lives in pipe[t % NS].  The K loop is unrolled
+    // by NS so every stage index is a compile-time constant -- no register rotation (moving a register
+    // with a load in flight forces s_waitcnt vmcnt(0) and drains the pipeline) and hipcc can emit
+    // counted vmcnt waits.
+    constexpr int NS = PF + 1;
+    Stage pipe[NS];
+    gload(0, pipe[0]);
+    lstore(0, pipe[0]);
 #pragma unroll
-    for (int i = 0; i < PF; ++i) gload(1 + i, pipe[i]);
+    for (int i = 1; i < NS; ++i) gload(i, pipe[i]);
     __syncthreads();
     const int r32 = lane & 31, hi = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        gload(kt + 1 + PF, incoming);
-        const unsigned char *As = lds + (kt & 1) * TILE_BYTES, *Bs = As + BM * kBK * 2;
+    for (int kt0 = 0; kt0 < nk; kt0 += NS) {
 #pragma unroll
-        for (int kk = 0; kk < kBK / 16; ++kk) {
-            frag8_t a[TM], b[TN];
-            const int c = kk * 2 + hi;
+        for (int st = 0; st < NS; ++st) {
+            const int kt = kt0 + st;
+            if (kt < nk) {  // block-uniform
+                gload(kt + NS, pipe[st]);  // stage st held tile kt, already in LDS
+                const unsigned char *As = lds + (kt & 1) * TILE_BYTES, *Bs = As + BM * kBK * 2;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * (BM / 2) + i * 32 + r32;
-                a[i] = *reinterpret_cast<const frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16);
+                for (int kk = 0; kk < kBK / 16; ++kk) {
+                    frag8_t a[TM], b[TN];
+                    const int c = kk * 2 + hi;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = wm * (BM / 2) + i * 32 + r32;
+                        a[i] = *reinterpret_cast<const frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int row = wn * (BN / 2) + j * 32 + r32;
+                        b[j] = *reinterpret_cast<const frag8_t *>(Bs + row * 128 + swz_chunk(row, c) * 16);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+                }
+                if (kt + 1 < nk) lstore(kt + 1, pipe[(st + 1) % NS]);
+                __syncthreads();
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn * (BN / 2) + j * 32 + r32;
-                b[j] = *reinterpret_cast<const frag8_t *>(Bs + row * 128 + swz_chunk(row, c) * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
         }
-        if (kt + 1 < nk) lstore((kt + 1) & 1, pipe[0]);
-#pragma unroll
-        for (int i = 0; i + 1 < PF; ++i) pipe[i] = pipe[i + 1];
-        pipe[PF - 1] = incoming;
-        __syncthreads();
     }
 
     // ---- epilogue through LDS: wave-private (BM/2) x (BN/2) fp32 tile, row stride WN floats

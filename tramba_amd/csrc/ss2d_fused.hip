@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         }
     }
     const float bias = dt_bias[(long)k * D + cc_];
-    const float An = Aneg[(long)k * D + cc_];
+    const float A2 = Aneg[(long)k * D + cc_] * 1.44269504088896f;  // A * log2(e): a = exp2(dt * A2)
     const float Dk = Ds[(long)k * D + cc_];
 
     // wave-uniform bases (SGPR) + 32-bit per-lane element offsets (host guarantees < 2^31 elements)
@@ -119,9 +119,9 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const int span = W * kTP;
     const int nsuper = (L + span - 1) / span;
 
-    auto load_idx = [&](int s) -> int {
+    auto load_idx = [&](int s) -> int {  // unconditional (clamped): predicated loads serialise the pipeline
         const int l = s * span + wv * kTP + r32;
-        return l < L ? tk[l] : 0;
+        return tk[l < L ? l : L - 1];
     };
     auto load_rows = [&](int pix, TileOps<NK> &o) {
         const float *row = pb + (unsigned)(pix * PC);
@@ -160,11 +160,13 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         }
     };
 
-    // Gather pipeline: tile s computes while tiles s+1 (and s+2 when registers allow, NK <= 2) are
-    // in flight.  fetch(t) needs the index vector of tile t, which is itself loaded one step earlier.
-    constexpr bool DEEP = NK <= 2;
-    constexpr int AHEAD = DEEP ? 2 : 1;
-    TileOps<NK> cur, n1, n2;
+    // Gather pipeline: tile s computes while tiles s+1 (and s+2 when registers allow, NK <= 2) are in
+    // flight.  The operand stages form a STATIC ring (tile t lives in ops[t % NS]) and the tile loop is
+    // unrolled by NS: rotating registers that have loads in flight, or predicating the loads, makes
+    // hipcc wait vmcnt(0) every tile.  Loads past the end of the sequence are clamped, not skipped.
+    constexpr int AHEAD = NK <= 2 ? 2 : 1;
+    constexpr int NS = AHEAD + 1;
+    TileOps<NK> ops[NS];
     float pixf[16];
     auto fetch = [&](int idxv, TileOps<NK> &o) {  // idxv: pixel index of MY position in that tile
         if (hi == 0) st[r32] = __builtin_bit_cast(float, idxv);
@@ -174,12 +176,19 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         load_rows(idxv, o);
         load_u(pixf, o);
     };
-    fetch(load_idx(0), cur);
-    if (DEEP && nsuper > 1) fetch(load_idx(1), n1);
-    int idx_ahead = nsuper > AHEAD ? load_idx(AHEAD) : 0;   // index vector of tile s + AHEAD
+    const int last = nsuper - 1;
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) fetch(load_idx(t < last ? t : last), ops[t]);
+    int idx_ahead = load_idx(AHEAD < last ? AHEAD : last);   // index vector of tile s + AHEAD
 
+    const bool cfull = blockIdx.x * kTP + kTP <= D;  // block-uniform: no channel masking needed
     float carry = 0.f;
-    for (int s = 0; s < nsuper; ++s) {
+    for (int s0 = 0; s0 < nsuper; s0 += NS) {
+#pragma unroll
+      for (int sti = 0; sti < NS; ++sti) {
+        const int s = s0 + sti;
+        if (s >= nsuper) break;  // block-uniform
+        TileOps<NK> &cur = ops[sti];
         const int l0 = s * span + wv * kTP;
         // per-position scalars of THIS tile
         if (hi == 0) {
@@ -190,9 +199,10 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         float Bp[16], Cp[16];
         read_stage4(1, Bp);
         read_stage4(2, Cp);
-        if (s + AHEAD < nsuper) {  // wave-uniform
-            if (DEEP) fetch(idx_ahead, n2); else fetch(idx_ahead, n1);
-            idx_ahead = s + AHEAD + 1 < nsuper ? load_idx(s + AHEAD + 1) : 0;
+        {   // tile s + AHEAD goes into the stage tile s - 1 just vacated
+            fetch(idx_ahead, ops[(sti + AHEAD) % NS]);
+            const int sn = s + AHEAD + 1;
+            idx_ahead = load_idx(sn < last ? sn : last);
         }
 
         // ---- dt_proj on the matrix core
@@ -210,13 +220,19 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
             }
         }
         // ---- per-element terms
+        // softplus(x) = ln2 * log2(1 + exp2(x*log2e)), evaluated on min(x, 60) and max-ed with x: equal to
+        // the reference's thresholded form (x > 20 -> x) to below fp32 resolution, 3 transcendentals
+        // per element in total with a = exp2(dt * A*log2e).
+        const bool ragged = l0 + kTP > L;  // wave-uniform: only the last tile of a sequence
         float a[16], bb[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int pos = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float dt = (l0 + pos < L) ? softplus20(acc[r] + bias) : 0.f;
-            a[r] = __expf(dt * An);
-            bb[r] = dt * Bp[r] * cur.u[r];
+            const float xr = acc[r] + bias;
+            const float z = __builtin_amdgcn_exp2f(fminf(xr, 60.f) * 1.44269504088896f);
+            float dt = fmaxf(xr, __builtin_amdgcn_logf(1.f + z) * 0.693147180559945f);
+            if (ragged && l0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) dt = 0.f;
+            a[r] = __builtin_amdgcn_exp2f(dt * A2);
+            bb[r] = dt * (Bp[r] * cur.u[r]);
         }
         // ---- 4 runs of 4 consecutive positions per lane; runs of the two half-waves interleave
         float sa[4], sh[4];
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         }
         carry = h;
         // ---- replay and stream out
-        const bool full = l0 + kTP <= L;  // wave-uniform: only the last tile of a sequence is ragged
+        const bool full = cfull && l0 + kTP <= L;  // wave-uniform: ragged only at the sequence / channel edge
         unsigned yoff = (unsigned)((l0 + 4 * hi) * D + cc_);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -269,15 +285,14 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
                 const TY out = Cvt<TY>::from_f(fmaf(Cp[r], hh, Dk * cur.u[r]));
                 const unsigned off = yoff + (unsigned)((q + 8 * g) * D);
                 if (full) {
-                    if (cok) yb[off] = out;
+                    yb[off] = out;
                 } else if (cok && l0 + q + 8 * g + 4 * hi < L) {
                     yb[off] = out;
                 }
             }
         }
-        cur = n1;
-        if (DEEP) n1 = n2;
         __builtin_amdgcn_wave_barrier();
+      }
     }
 }
 
