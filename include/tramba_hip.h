@@ -27,6 +27,8 @@
  *   tramba_dw_pack              weight re-layout + DWMSMlp fold (h+dw3+dw5+dw7, vmamba.py:624)
  *   tramba_dct_split_cl         DCT2D.forward                   Models/DCT_2D.py:12-29
  *   tramba_linear_cl            Linear2d.forward (1x1 conv)     Models/modules.py:10-13
+ *   tramba_conv3x3s2_cl /       patch_embed + downsample convs  Models/vmamba.py:454,481-486
+ *   tramba_stem_conv_ln_gelu
  *
  * "_cl" = channels-last: activations are (B, H*W, C) row-major, C contiguous.
  */
@@ -153,6 +155,18 @@ int tramba_dct_split_cl(const void *x, const float *wx, const float *wy, float *
  * last.  MFMA path for f16/bf16. */
 int tramba_linear_cl(const void *x, const void *w, const float *bias, const void *residual, void *y,
                      int64_t m, int n, int k, int act, int dtype, int out_dtype, void *stream);
+
+/* ------------------------------------------------------------------ dense convs of the VMamba stem */
+/* Implicit-GEMM 3x3 / stride 2 / pad 1 convolution on a channels-last map (patch_embed[5] and the three
+ * downsample convs, Models/vmamba.py:454,486): x (B, Hin, Win, Cin) -> y (B, ceil(Hin/2), ceil(Win/2), Cout).
+ * w is K-major (Cout, 3, 3, Cin) = reference weight.permute(0,2,3,1), same dtype as x; Cin % 64 == 0. */
+int tramba_conv3x3s2_cl(const void *x, const void *w, const float *bias, void *y, int batch, int hin,
+                        int win, int cin, int cout, int dtype, void *stream);
+/* patch_embed[0..4] fused (vmamba.py:481-485): conv 3x3/s2/p1 (3 -> 64) + bias + LayerNorm2d(64) + GELU.
+ * img (B, 3, H, W) NCHW in f32 or `dtype`; w (64, 3, 3, 3) f32 reference layout; y (B, H/2, W/2, 64). */
+int tramba_stem_conv_ln_gelu(const void *img, const float *w, const float *bias, const float *ln_w,
+                             const float *ln_b, void *y, int batch, int h, int wd, float eps,
+                             int img_dtype, int dtype, void *stream);
 
 #ifdef __cplusplus
 }

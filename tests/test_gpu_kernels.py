@@ -206,3 +206,35 @@ def test_ss2d_fused_core(dtype, fam, cfg):
         out = H.ss2d_merge_norm_cl(ys, order, lw.to(dev), lb.to(dev), 1e-5, 2, dtype)
         tol = 2e-4 if dtype == torch.float32 else 4e-2
         np.testing.assert_allclose(out.view(b, h, h, d).cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(2, 12, 64, 40), (1, 24, 128, 256), (1, 13, 64, 64), (1, 48, 256, 130)])
+def test_conv3x3s2_cl(dtype, cfg):
+    """implicit-GEMM 3x3 / stride 2 / pad 1 conv (patch_embed[5], downsample) against F.conv2d in fp64."""
+    b, h, cin, cout = cfg
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(b, h, h, cin, generator=g).to(dtype)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).to(dtype)
+    bias = torch.randn(cout, generator=g)
+    want = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), stride=2, padding=1).permute(0, 2, 3, 1)
+    wk = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    got = hip().conv3x3s2_cl(x.to(DEV), wk.to(DEV), bias.to(DEV))
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 24), (1, 37), (1, 96)])
+def test_stem_conv_ln_gelu(dtype, cfg):
+    """fused patch_embed[0..4]: conv 3->64 s2 + LayerNorm2d + GELU, NCHW fp32 image in."""
+    b, h = cfg
+    g = torch.Generator().manual_seed(h)
+    img = torch.randn(b, 3, h, h, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 27 ** -0.5
+    bias, lw, lb = 0.1 * torch.randn(64, generator=g), 1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    y = F.conv2d(img.double(), w.double(), bias.double(), stride=2, padding=1)
+    want = F.gelu(oo.layernorm2d(y, lw.double(), lb.double())).permute(0, 2, 3, 1)
+    got = hip().stem_conv_ln_gelu(img.to(DEV), w.to(DEV), bias.to(DEV), lw.to(DEV), lb.to(DEV), 1e-5, dtype)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)

@@ -44,18 +44,25 @@ __device__ __forceinline__ void dct_rows(const TI *__restrict__ in, long in_stri
     }
 }
 
+// One block = one input row i (pass 1) / one output column u (pass 2); its 4 waves split the
+// outputs of that row in quarters, so every wave runs a 4x shorter FMA chain and the grid has 4x
+// the waves (the one-wave-per-row form left most of the chip idle at n = 96).
 template <typename T>
 __global__ __launch_bounds__(256) void dct_pass1_kernel(const T *__restrict__ x, const float *__restrict__ wx,
                                                        float *__restrict__ tmp, int n, int C)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int i = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (i >= n) return;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.y;
     const int b = blockIdx.z;
     const int c = blockIdx.x * kWave + lane;
     const bool cok = c < C;
+    const int per = ((n + 3) / 4 + kUT - 1) / kUT * kUT;   // outputs per wave, multiple of the register tile
+    const int o0 = wv * per;
+    if (o0 >= n) return;
+    const int cnt = o0 + per <= n ? per : n - o0;
     const long base = (((long)b * n + i) * n) * C + (cok ? c : 0);
-    dct_rows<T, float>(x + base, C, wx, n, 0, n, tmp + base, C, cok);
+    dct_rows<T, float>(x + base, C, wx, n, o0, cnt, tmp + base + (long)o0 * C, C, cok);
 }
 
 template <typename T>
@@ -64,16 +71,20 @@ __global__ __launch_bounds__(256) void dct_pass2_kernel(const float *__restrict_
                                                        T *__restrict__ low, int n, int C)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int u = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (u >= n) return;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = blockIdx.y;
     const int b = blockIdx.z;
     const int c = blockIdx.x * kWave + lane;
     const bool cok = c < C;
     const int hn = n / 2;
     const bool hi = u >= hn;
+    const int per = ((hn + 3) / 4 + kUT - 1) / kUT * kUT;
+    const int o0 = wv * per;
+    if (o0 >= hn) return;
+    const int cnt = o0 + per <= hn ? per : hn - o0;
     const float *in = tmp + ((long)b * n * n + u) * C + (cok ? c : 0);   // T[b, i, u, c], stride n*C over i
-    T *out = (hi ? high : low) + (((long)b * hn) * hn + (hi ? u - hn : u)) * C + (cok ? c : 0);
-    dct_rows<float, T>(in, (long)n * C, wy, n, hi ? hn : 0, hn, out, (long)hn * C, cok);
+    T *out = (hi ? high : low) + (((long)b * hn + o0) * hn + (hi ? u - hn : u)) * C + (cok ? c : 0);
+    dct_rows<float, T>(in, (long)n * C, wy, n, (hi ? hn : 0) + o0, cnt, out, (long)hn * C, cok);
 }
 
 }  // namespace tramba
@@ -88,7 +99,8 @@ extern "C" int tramba_dct_split_cl(const void *x, const float *wx, const float *
     TRAMBA_CHECK(n % kJT == 0, "dct_split_cl: n=%d must be a multiple of %d", n, kJT);
     TRAMBA_CHECK(batch <= 65535, "dct_split_cl: batch exceeds grid limits");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((c + kWave - 1) / kWave, (n + 3) / 4, batch), block(256);
+    TRAMBA_CHECK(n <= 65535, "dct_split_cl: n exceeds grid limits");
+    dim3 grid((c + kWave - 1) / kWave, n, batch), block(256);
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
         hipLaunchKernelGGL(dct_pass1_kernel<T>, grid, block, 0, s, (const T *)x, wx, tmp, n, c);
         hipLaunchKernelGGL(dct_pass2_kernel<T>, grid, block, 0, s, (const float *)tmp, wy, (T *)high, (T *)low, n, c);

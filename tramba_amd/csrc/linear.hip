@@ -12,6 +12,9 @@
 // network are short-K: K = 128..4096, most GEMMs are HBM/L2-bound on the M x N output, so the
 // fused epilogue matters more than LDS staging; an LDS-staged variant is the next step).
 // Epilogue fused: + bias, activation, + residual, cast.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace tramba {
@@ -123,13 +126,24 @@ __global__ __launch_bounds__(256) void linear16_kernel(const T *__restrict__ x, 
 //   has one COLUMN per lane, which would store 2-byte scalars at a row stride).
 constexpr int kBK = 64;
 
-__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ (row & 7); }
+// 16-byte chunk swizzle of a 128-byte LDS row.  ds_read_b128 is served in 16-lane groups
+// {0-3,12-15,20-27} / {4-11,16-19,28-31} (+32): rows of equal parity in a group must land on
+// different 16-byte slots -> key on (row >> 1), not on row.
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <typename T, typename TO, int BM, int BN, int PF>
+// Implicit-GEMM geometry of a 3x3 / stride-2 / pad-1 convolution on a channels-last map: row m of the
+// GEMM is output pixel (b, ho, wo), column k = (ky*3 + kx)*Cin + ci.  Cin % 64 == 0, so every 64-deep
+// K step lies inside ONE tap: the A tile of a step is 64 contiguous channels of one (shifted) input
+// pixel per row -- the same 16-byte chunk loads as the plain GEMM, with a per-row base address.
+struct ConvGeom {
+    int hin, win, cin, hout, wout;
+};
+
+template <typename T, typename TO, int BM, int BN, int PF, bool CONV>
 __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__ x, const T *__restrict__ w,
                                                           const float *__restrict__ bias,
                                                           const T *__restrict__ res, TO *__restrict__ y, long M,
-                                                          int N, int K, int act)
+                                                          int N, int K, int act, ConvGeom cg)
 {
     constexpr int TM = BM / 64, TN = BN / 64;           // 32x32 tiles per wave in m / n
     constexpr int A_CHUNKS = BM * (kBK / 8), B_CHUNKS = BN * (kBK / 8);
@@ -160,14 +174,42 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
     // zeroed when the stage is written to LDS.  (Predicated loads become exec-masked branches, after
     // which hipcc's wait insertion falls back to vmcnt(0) and the register pipeline collapses.)
     const int kmax = ((K - 1) / 8) * 8;  // start of the last whole 16-byte chunk of a row
+    // conv: per-row output pixel decoded once (rows of a thread do not change over the K loop)
+    int cb[A_PER_T], chi[A_PER_T], cwi[A_PER_T];
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            const int row = (tid + i * 256) >> 3;
+            const long gr = m0 + row < M ? m0 + row : M - 1;
+            const int wo = (int)(gr % cg.wout);
+            const long t = gr / cg.wout;
+            chi[i] = 2 * (int)(t % cg.hout) - 1;
+            cwi[i] = 2 * wo - 1;
+            cb[i] = (int)(t / cg.hout);
+        }
+    }
+    auto conv_src = [&](int kt, int i, bool &inside) -> long {  // element offset of the 64-channel run
+        const int k0 = kt * kBK;
+        const int tap = k0 / cg.cin, ci = k0 - tap * cg.cin;  // block-uniform
+        const int hy = chi[i] + tap / 3, wx = cwi[i] + tap % 3;
+        inside = hy >= 0 && hy < cg.hin && wx >= 0 && wx < cg.win;
+        const int hc = hy < 0 ? 0 : (hy >= cg.hin ? cg.hin - 1 : hy), wc = wx < 0 ? 0 : (wx >= cg.win ? cg.win - 1 : wx);
+        return (((long)cb[i] * cg.hin + hc) * cg.win + wc) * cg.cin + ci;
+    };
     auto gload = [&](int kt, Stage &st) {
-        const int k0 = (kt < nk ? kt : nk - 1) * kBK;
+        const int ktc = kt < nk ? kt : nk - 1;
+        const int k0 = ktc * kBK;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             const int q = tid + i * 256, row = q >> 3, c = q & 7;
-            const long gr = m0 + row < M ? m0 + row : M - 1;
-            const int kc = k0 + c * 8 <= kmax ? k0 + c * 8 : kmax;
-            st.a[i] = *reinterpret_cast<const frag8_t *>(x + gr * K + kc);
+            if (CONV) {
+                bool inside;
+                st.a[i] = *reinterpret_cast<const frag8_t *>(x + conv_src(ktc, i, inside) + c * 8);
+            } else {
+                const long gr = m0 + row < M ? m0 + row : M - 1;
+                const int kc = k0 + c * 8 <= kmax ? k0 + c * 8 : kmax;
+                st.a[i] = *reinterpret_cast<const frag8_t *>(x + gr * K + kc);
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
@@ -184,7 +226,12 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             const int q = tid + i * 256, row = q >> 3, c = q & 7;
-            const bool ok = m0 + row < M && k0 + c * 8 < K;
+            bool ok = m0 + row < M && k0 + c * 8 < K;
+            if (CONV) {
+                bool inside;
+                conv_src(kt, i, inside);
+                ok = ok && inside;  // zero padding of the convolution
+            }
             *reinterpret_cast<frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16) = ok ? st.a[i] : zero;
         }
 #pragma unroll
@@ -290,20 +337,26 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
     }
 }
 
-template <typename T, typename TO>
+// Tile choice: 64x64 (3 K-tiles in flight) wins on every GEMM of this model (M = 576..36864, N <= 4096,
+// K <= 4096: short-M or short-K, measured in scripts/bench_gemm.py); 128x128 only pays once both the tile
+// count and K are large.  TRAMBA_GEMM_TILE=128x128 forces it (tuning aid).
+template <typename T, typename TO, bool CONV = false>
 static void launch_tiled(const void *x, const void *w, const float *bias, const void *res, void *y, long m, int n,
-                         int k, int act, hipStream_t s)
+                         int k, int act, hipStream_t s, ConvGeom cg = ConvGeom{0, 0, 0, 0, 0})
 {
-    // big tiles when they still fill the 256 CUs, small tiles otherwise (short-M stages)
+    static const bool force_big = [] {
+        const char *e = getenv("TRAMBA_GEMM_TILE");
+        return e && strcmp(e, "128x128") == 0;
+    }();
     const long big = ((m + 127) / 128) * ((n + 127) / 128);
-    if (big >= 384) {
+    if (force_big || (big >= 2048 && k >= 1024)) {
         dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
-        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
-                           (const T *)res, (TO *)y, m, n, k, act);
+        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2, CONV>), grid, block, 0, s, (const T *)x,
+                           (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);
     } else {
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
-        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 64, 64, 3>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
-                           (const T *)res, (TO *)y, m, n, k, act);
+        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 64, 64, 3, CONV>), grid, block, 0, s, (const T *)x,
+                           (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);
     }
 }
 
@@ -403,6 +456,26 @@ extern "C" int tramba_linear_cl(const void *x, const void *w, const float *bias,
         set_error("linear_cl: bad dtype %d", dtype);
         return TRAMBA_ERR_ARG;
     }
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_conv3x3s2_cl(const void *x, const void *w, const float *bias, void *y, int batch, int hin,
+                                   int win, int cin, int cout, int dtype, void *stream)
+{
+    TRAMBA_CHECK(x && w && y, "conv3x3s2_cl: null tensor");
+    TRAMBA_CHECK(batch > 0 && hin > 0 && win > 0 && cin > 0 && cout > 0, "conv3x3s2_cl: empty shape");
+    TRAMBA_CHECK(cin % 64 == 0, "conv3x3s2_cl: Cin=%d must be a multiple of 64", cin);
+    TRAMBA_CHECK(dtype == TRAMBA_BF16 || dtype == TRAMBA_F16, "conv3x3s2_cl: bf16/f16 only (fp32 convs run on MIOpen)");
+    TRAMBA_CHECK(aligned16(x) && aligned16(w) && aligned16(y), "conv3x3s2_cl: tensors must be 16-byte aligned");
+    ConvGeom cg{hin, win, cin, (hin + 1) / 2, (win + 1) / 2};
+    const long m = (long)batch * cg.hout * cg.wout;
+    TRAMBA_CHECK((m + 63) / 64 <= 65535, "conv3x3s2_cl: too many output pixels");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TRAMBA_BF16)
+        launch_tiled<__hip_bfloat16, __hip_bfloat16, true>(x, w, bias, nullptr, y, m, cout, 9 * cin, TRAMBA_ACT_NONE, s, cg);
+    else
+        launch_tiled<__half, __half, true>(x, w, bias, nullptr, y, m, cout, 9 * cin, TRAMBA_ACT_NONE, s, cg);
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }

@@ -49,6 +49,8 @@ SIGNATURES = {
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_conv3x3s2_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
+    "tramba_stem_conv_ln_gelu": (c_int, [c_vp] * 6 + [c_int] * 3 + [c_f, c_int, c_int, c_vp]),
 }
 
 _lib = None
@@ -353,4 +355,29 @@ def linear_cl(x, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
         raise TrambaHipError("linear_cl: weight dtype/shape mismatch")
     _check(lib().tramba_linear_cl(_ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), m, n, k, act, dt(x),
                                   dt(y), _stream()), "linear_cl")
+    return y
+
+
+def conv3x3s2_cl(x, w_kmajor, bias):
+    """x: (B, H, W, Cin) bf16/f16; w_kmajor: (Cout, 9*Cin) = weight.permute(0,2,3,1), same dtype."""
+    _dev(x, w_kmajor, bias)
+    bb, h, wd, cin = x.shape
+    cout = w_kmajor.shape[0]
+    if w_kmajor.dtype != x.dtype or w_kmajor.shape[1] != 9 * cin:
+        raise TrambaHipError("conv3x3s2_cl: weight dtype/shape mismatch")
+    y = torch.empty((bb, (h + 1) // 2, (wd + 1) // 2, cout), dtype=x.dtype, device=x.device)
+    _check(lib().tramba_conv3x3s2_cl(_ptr(x), _ptr(w_kmajor), _ptr(bias), _ptr(y), bb, h, wd, cin, cout, dt(x),
+                                     _stream()), "conv3x3s2_cl")
+    return y
+
+
+def stem_conv_ln_gelu(img, w, bias, ln_w, ln_b, eps, out_dtype):
+    """img: (B, 3, H, W) NCHW f32 or out_dtype -> (B, H/2, W/2, 64) out_dtype."""
+    _dev(img, w, bias, ln_w, ln_b)
+    bb, c3, h, wd = img.shape
+    if c3 != 3 or tuple(w.shape) != (64, 3, 3, 3):
+        raise TrambaHipError("stem_conv_ln_gelu: expects a 3 -> 64 channel 3x3 stem")
+    y = torch.empty((bb, (h + 1) // 2, (wd + 1) // 2, 64), dtype=out_dtype, device=img.device)
+    _check(lib().tramba_stem_conv_ln_gelu(_ptr(img), _ptr(w), _ptr(bias), _ptr(ln_w), _ptr(ln_b), _ptr(y), bb, h, wd,
+                                          eps, _DT[img.dtype], _DT[out_dtype], _stream()), "stem_conv_ln_gelu")
     return y

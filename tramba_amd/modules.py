@@ -665,7 +665,14 @@ def _init_weights(m: nn.Module):
 
 
 def _conv_cl(conv: nn.Conv2d, x_cl):
-    """A regular (non depth-wise) strided conv on a channels-last activation (MIOpen NHWC)."""
+    """A dense 3x3 / stride-2 conv on a channels-last activation: implicit GEMM on the MFMA tile kernel
+    for 16-bit inference, MIOpen (NHWC) otherwise (fp32 validation mode, training)."""
+    if (_infer(x_cl, conv.weight) and x_cl.dtype != torch.float32 and conv.kernel_size == (3, 3)
+            and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.in_channels % 64 == 0):
+        wk = _cache(conv).get(("kmajor", x_cl.dtype), (conv.weight,),
+                              lambda: conv.weight.detach().permute(0, 2, 3, 1).reshape(conv.out_channels, -1)
+                              .to(x_cl.dtype).contiguous())
+        return hip.conv3x3s2_cl(x_cl, wk, _f32(conv.bias))
     x = from_cl(x_cl)
     w = conv.weight.to(x.dtype).contiguous(memory_format=torch.channels_last)
     b = None if conv.bias is None else conv.bias.to(x.dtype)
@@ -711,8 +718,14 @@ class VSSMEncoder(nn.Module):
         """x_img: NCHW image batch.  Returns [image, s1, s2, s3, s4] with s* channels-last (B,H,W,C)."""
         feats = [x_img]
         pe = self.patch_embed
-        x = _conv_cl(pe[0], to_cl(x_img))
-        x = pe[2]._forward_cl(x, act=hip.ACT_GELU)
+        if (_infer(x_img, pe[0].weight) and pe[0].in_channels == 3 and pe[0].out_channels == 64
+                and pe[0].kernel_size == (3, 3) and pe[0].stride == (2, 2) and x_img.is_contiguous()):
+            act_dtype = pe[5].weight.dtype if pe[5].weight.dtype != torch.float32 else x_img.dtype
+            x = hip.stem_conv_ln_gelu(x_img, _f32(pe[0].weight), _f32(pe[0].bias), _f32(pe[2].weight),
+                                      _f32(pe[2].bias), pe[2].eps, act_dtype)
+        else:
+            x = _conv_cl(pe[0], to_cl(x_img))
+            x = pe[2]._forward_cl(x, act=hip.ACT_GELU)
         x = _conv_cl(pe[5], x)
         x = pe[7]._forward_cl(x)
         for s, layer in enumerate(self.layers):
