@@ -98,13 +98,14 @@ int tramba_selective_scan_fwd(const void *u, const void *delta, const float *A, 
                               float *ckpt, int batch, int kd, int k, int n, int l, int io_dtype,
                               int out_dtype, int delta_softplus, void *stream);
 /* du, ddelta: (B, KD, L) io_dtype; dA (KD,N), dD, ddelta_bias (KD): f32, ACCUMULATED into
- * (caller zeroes);  dB, dC: (B, K, N, L) f32, accumulated into (caller zeroes). */
+ * (caller zeroes);  dB, dC: (ncopy, B, K, N, L) f32, accumulated into (caller zeroes) -- the rows of a
+ * direction group spread their atomic adds over `ncopy` private copies which the caller sums. */
 int tramba_selective_scan_bwd(const void *u, const void *delta, const float *A, const void *Bm,
                               const void *Cm, const float *D, const float *delta_bias,
                               const float *dout, const float *ckpt, void *du, void *ddelta,
                               float *dA, float *dB, float *dC, float *dD, float *ddelta_bias,
                               int batch, int kd, int k, int n, int l, int io_dtype,
-                              int delta_softplus, void *stream);
+                              int delta_softplus, int ncopy, void *stream);
 
 /* ------------------------------------------------------------------ L1: scan-order gather / merge, NCHW */
 /* xs[b,k,c,l] = x[b,c,table[k,l]];  x: (B, C, L), xs: (B, K, C, L);  table: DEVICE int32 (K, L). */

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_ker
     const float *__restrict__ dbias, const float *__restrict__ dout, const float *__restrict__ ckpt,
     T *__restrict__ du, T *__restrict__ ddelta, float *__restrict__ dA, float *__restrict__ dB,
     float *__restrict__ dC, float *__restrict__ dD, float *__restrict__ ddbias, int rows_total, int kd,
-    int K, int L, int nchunk, int softplus, int vec_ok)
+    int K, int L, int nchunk, int softplus, int vec_ok, int ncopy, long copy_stride)
 {
     constexpr int RPW = kWave / LPR;
     const int lane = threadIdx.x & (kWave - 1);
@@ -231,6 +231,9 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_ker
     const long bc = ((long)b * K + k) * L;
     const T *Br = Bm + bc;
     const T *Cr = Cm + bc;
+    // dB/dC are shared by the KD/K rows of a group: spread the adds over `ncopy` private copies
+    // (summed by the caller) so that KD/K/ncopy, not KD/K, rows contend for one address
+    const long pc = (long)(d % ncopy) * copy_stride;
     const float An = A[d];
     const float bias = dbias ? dbias[d] : 0.f;
     const float skip = Dskip ? Dskip[d] : 0.f;
@@ -322,8 +325,8 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_ker
             accD = fmaf(go[j], cu[j], accD);
             accBias += odd[j];
             if (ok && row_ok) {
-                atomicAdd(dB + bc + l0 + j, g * dt[j] * cu[j]);
-                atomicAdd(dC + bc + l0 + j, go[j] * hcur[j]);
+                atomicAdd(dB + pc + bc + l0 + j, g * dt[j] * cu[j]);
+                atomicAdd(dC + pc + bc + l0 + j, go[j] * hcur[j]);
             }
         }
         if (row_ok) {
@@ -428,12 +431,13 @@ extern "C" int tramba_selective_scan_bwd(const void *u, const void *delta, const
                                          const float *dout, const float *ckpt, void *du, void *ddelta,
                                          float *dA, float *dB, float *dC, float *dD, float *ddelta_bias,
                                          int batch, int kd, int k, int n, int l, int io_dtype,
-                                         int delta_softplus, void *stream)
+                                         int delta_softplus, int ncopy, void *stream)
 {
     TRAMBA_CHECK(u && delta && A && Bm && Cm && dout && ckpt && du && ddelta && dA && dB && dC,
                  "selective_scan_bwd: null tensor");
     TRAMBA_CHECK(batch > 0 && kd > 0 && k > 0 && l > 0, "selective_scan_bwd: empty shape");
     TRAMBA_CHECK(kd % k == 0, "selective_scan_bwd: KD=%d is not a multiple of K=%d", kd, k);
+    TRAMBA_CHECK(ncopy >= 1, "selective_scan_bwd: ncopy must be >= 1");
     if (n != 1) {
         set_error("selective_scan_bwd: d_state=%d unsupported (Tramba uses 1)", n);
         return TRAMBA_ERR_UNSUPPORTED;
@@ -451,7 +455,8 @@ extern "C" int tramba_selective_scan_bwd(const void *u, const void *delta, const
 #define LAUNCH_(T, LPR_)                                                                                    \
     hipLaunchKernelGGL((selective_scan_bwd_kernel<T, LPR_>), grid, block, 0, s, (const T *)u, (const T *)delta, \
                        A, (const T *)Bm, (const T *)Cm, D, delta_bias, dout, ckpt, (T *)du, (T *)ddelta, dA, dB, \
-                       dC, dD, ddelta_bias, (int)rows, kd, k, l, nchunk, delta_softplus, vec_ok)
+                       dC, dD, ddelta_bias, (int)rows, kd, k, l, nchunk, delta_softplus, vec_ok, ncopy,          \
+                       (long)batch * k * n * l)
     TRAMBA_DISPATCH_DTYPE(io_dtype, T, {
         if (lpr == 16) LAUNCH_(T, 16);
         else if (lpr == 32) LAUNCH_(T, 32);

@@ -37,7 +37,7 @@ SIGNATURES = {
     "tramba_scan_table_inverse": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "tramba_selective_scan_nchunk": (c_int, [c_int, c_int]),
     "tramba_selective_scan_fwd": (c_int, [c_vp] * 9 + [c_int] * 8 + [c_vp]),
-    "tramba_selective_scan_bwd": (c_int, [c_vp] * 16 + [c_int] * 7 + [c_vp]),
+    "tramba_selective_scan_bwd": (c_int, [c_vp] * 16 + [c_int] * 8 + [c_vp]),
     "tramba_cross_scan": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_cross_merge": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_ss2d_group_stride": (c_int, [c_int]),
@@ -209,15 +209,16 @@ def selective_scan_bwd(u, delta, A, B, C, D, delta_bias, dout, ckpt, delta_softp
     dout = dout.float().contiguous()
     du, ddelta = torch.empty_like(u), torch.empty_like(delta)
     dA = torch.zeros((kd, n), dtype=torch.float32, device=u.device)
-    dB = torch.zeros((nb, k, n, l), dtype=torch.float32, device=u.device)
+    ncopy = max(1, min(16, (kd // k) // 8))  # private dB/dC copies: <= 1/8 of a group's rows per address
+    dB = torch.zeros((ncopy, nb, k, n, l), dtype=torch.float32, device=u.device)
     dC = torch.zeros_like(dB)
     dD = torch.zeros(kd, dtype=torch.float32, device=u.device) if D is not None else None
     dbias = torch.zeros(kd, dtype=torch.float32, device=u.device) if delta_bias is not None else None
     _check(lib().tramba_selective_scan_bwd(
         _ptr(u), _ptr(delta), _ptr(A32), _ptr(B), _ptr(C), _ptr(D32), _ptr(b32), _ptr(dout), _ptr(ckpt),
         _ptr(du), _ptr(ddelta), _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(dbias),
-        nb, kd, k, n, l, dt(u), int(delta_softplus), _stream()), "selective_scan_bwd")
-    return du, ddelta, dA, dB, dC, dD, dbias
+        nb, kd, k, n, l, dt(u), int(delta_softplus), ncopy, _stream()), "selective_scan_bwd")
+    return du, ddelta, dA, dB.sum(0), dC.sum(0), dD, dbias
 
 
 def cross_scan(x, order: ScanOrder):

@@ -98,6 +98,36 @@ def _act_torch(x, act):
     return x
 
 
+class _DepthwiseConvNative(torch.autograd.Function):
+    """Depth-wise conv for the TRAINING path with autograd: PyTorch's native depth-wise kernels, forward and
+    backward, with MIOpen bypassed (its channels-last grouped-conv kernels are >10x slower on these shapes,
+    scripts/probe_dw.py).  The inference path uses tramba_dwconv_cl instead."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, padding):
+        ctx.save_for_backward(x, w)
+        ctx.padding, ctx.has_bias = padding, b is not None
+        with torch.backends.cudnn.flags(enabled=False):
+            return F.conv2d(x, w, b, padding=padding, groups=w.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        with torch.backends.cudnn.flags(enabled=False):
+            gx, gw, gb = torch.ops.aten.convolution_backward(
+                gy, x, w, [w.shape[0]] if ctx.has_bias else None, [1, 1], list(ctx.padding), [1, 1], False, [0, 0],
+                w.shape[0], [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias])
+        return gx, gw, gb, None
+
+
+def _dwconv_train_cl(x_cl, conv: nn.Conv2d):
+    """(B,H,W,C) -> (B,H,W,C) through the native NCHW depth-wise kernels."""
+    x = from_cl(x_cl).contiguous()
+    w = conv.weight.to(x.dtype)
+    b = None if conv.bias is None else conv.bias.to(x.dtype)
+    return to_cl(_DepthwiseConvNative.apply(x, w, b, tuple(conv.padding)))
+
+
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm.models.layers.DropPath semantics)."""
 
@@ -429,10 +459,10 @@ class SS2D(nn.Module):
         l = h * w
         xn = from_cl(x).contiguous()  # (B,D,H,W), NCHW contiguous as the plugin API expects
         xs = self.scan.apply(xn)  # (B,K,D,L)
-        wx = self.x_proj_weight.to(xs.dtype)
-        x_dbl = F.conv1d(xs.view(b, -1, l), wx.view(-1, d, 1), groups=k)
-        dts, bs, cs = torch.split(x_dbl.view(b, k, -1, l), [r, n, n], dim=2)
-        dts = F.conv1d(dts.contiguous().view(b, -1, l), self.dt_projs_weight.to(xs.dtype).view(k * d, -1, 1), groups=k)
+        # the reference's two grouped conv1d (vmamba.py:233-236) as batched matmuls over the K groups
+        x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, self.x_proj_weight.to(xs.dtype))
+        dts, bs, cs = torch.split(x_dbl, [r, n, n], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight.to(xs.dtype))
         a_neg = -torch.exp(self.A_logs.float())
         ys = SelectiveScanOflex.apply(
             xs.view(b, -1, l), dts.contiguous().view(b, -1, l), a_neg, bs.contiguous().view(b, k, n, l),
@@ -450,9 +480,7 @@ class SS2D(nn.Module):
                 wt, bt = _cache(self).get("dw", (cv.weight, cv.bias), lambda: hip.dw_pack(cv.weight, cv.bias))
                 x = hip.dwconv_cl(x, wt, bt, hip.ACT_SILU)
             else:
-                wc = self.conv2d.weight.to(x.dtype)
-                bc = None if self.conv2d.bias is None else self.conv2d.bias.to(x.dtype)
-                x = to_cl(F.silu(F.conv2d(from_cl(x), wc, bc, padding=self.conv2d.padding, groups=wc.shape[0])))
+                x = F.silu(_dwconv_train_cl(x, self.conv2d))
         else:
             x = F.silu(x)
         y = self._core_fused_cl(x) if self._fused_ok(x) else self._core_plugin_cl(x)
@@ -512,8 +540,7 @@ class DWConv(nn.Module):
         if _infer(x, c.weight):
             wt, bt = _cache(self).get("dw", (c.weight, c.bias), lambda: hip.dw_pack(c.weight, c.bias))
             return hip.dwconv_cl(x, wt, bt, hip.ACT_NONE)
-        return to_cl(F.conv2d(from_cl(x), c.weight.to(x.dtype), None if c.bias is None else c.bias.to(x.dtype),
-                              padding=c.padding, groups=c.groups))
+        return _dwconv_train_cl(x, c)
 
     def forward(self, x):
         _need_device(x)
