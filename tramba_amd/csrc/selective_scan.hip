@@ -32,10 +32,45 @@ __host__ __device__ inline int lanes_per_row(int l)
     return need <= 16 ? 16 : (need <= 32 ? 32 : 64);
 }
 
+// DPP data movement (gfx9 family): a VALU-rate cross-lane read, no LDS crossbar round trip.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
+
+// one step of the (decay, state) scan: lanes that receive a valid source combine, the others see the
+// identity (1, 0) through the `old` operand
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_scan_step(float &a, float &h)
+{
+    const float ap = dpp_move<CTRL, ROW_MASK>(1.f, a);
+    const float hp = dpp_move<CTRL, ROW_MASK>(0.f, h);
+    h = fmaf(a, hp, h);
+    a *= ap;
+}
+
+// inclusive scan over all 64 lanes: row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast15 into
+// rows 1 and 3, then row_bcast31 into rows 2 and 3
+__device__ __forceinline__ void wave_scan_dpp(float &a, float &h)
+{
+    dpp_scan_step<0x111, 0xf>(a, h);
+    dpp_scan_step<0x112, 0xf>(a, h);
+    dpp_scan_step<0x114, 0xf>(a, h);
+    dpp_scan_step<0x118, 0xf>(a, h);
+    dpp_scan_step<0x142, 0xa>(a, h);
+    dpp_scan_step<0x143, 0xc>(a, h);
+}
+
 // inclusive scan of (a, h) pairs over the LPR lanes that own one row
 template <int LPR>
 __device__ __forceinline__ void row_scan(float &a, float &h, int sub)
 {
+    if constexpr (LPR == 64) {
+        wave_scan_dpp(a, h);
+        return;
+    }
 #pragma unroll
     for (int o = 1; o < LPR; o <<= 1) {
         const float ap = __shfl_up(a, o, LPR);
@@ -47,13 +82,23 @@ __device__ __forceinline__ void row_scan(float &a, float &h, int sub)
     }
 }
 
-template <typename T, typename TO, int LPR, int N>
+// softplus with the reference's threshold semantics, lean form: ln2*log2(1 + exp2(min(x,60)*log2e))
+// max-ed with x (equal to "x > 20 -> x" to below fp32 resolution), 2 transcendentals.
+__device__ __forceinline__ float softplus_lean(float x)
+{
+    const float z = __builtin_amdgcn_exp2f(fminf(x, 60.f) * 1.44269504088896f);
+    return fmaxf(x, __builtin_amdgcn_logf(1.f + z) * 0.693147180559945f);
+}
+
+// VEC: L % 8 == 0 and 16-byte aligned tensors (every shape of the model) -> 16-byte accesses only.
+template <typename T, typename TO, int LPR, int N, bool VEC>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_fwd_kernel(
     const T *__restrict__ u, const T *__restrict__ delta, const float *__restrict__ A,
     const T *__restrict__ Bm, const T *__restrict__ Cm, const float *__restrict__ Dskip,
     const float *__restrict__ dbias, TO *__restrict__ out, float *__restrict__ ckpt, int rows_total,
-    int kd, int K, int L, int nchunk, int softplus, int vec_ok)
+    int kd, int K, int L, int nchunk, int softplus)
 {
+    constexpr bool vec_ok = VEC;
     constexpr int RPW = kWave / LPR;  // rows per wave
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -70,9 +115,9 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_fwd_ker
     const T *Br = Bm + ((long)b * K + k) * N * L;
     const T *Cr = Cm + ((long)b * K + k) * N * L;
 
-    float An[N];
+    float A2[N];  // A * log2(e): decay = exp2(dt * A2)
 #pragma unroll
-    for (int n = 0; n < N; ++n) An[n] = A[(long)d * N + n];
+    for (int n = 0; n < N; ++n) A2[n] = A[(long)d * N + n] * 1.44269504088896f;
     const float bias = dbias ? dbias[d] : 0.f;
     const float skip = Dskip ? Dskip[d] : 0.f;
 
@@ -80,99 +125,117 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_fwd_ker
 #pragma unroll
     for (int n = 0; n < N; ++n) carry[n] = 0.f;
 
-    float fu[kE], fd[kE], fB[N][kE], fC[N][kE];
-
-    auto fetch = [&](int chunk, float (&xu)[kE], float (&xd)[kE], float (&xB)[N][kE], float (&xC)[N][kE]) {
-        const int l0 = chunk * (LPR * kE) + sub * kE;
-        if (vec_ok && l0 + kE <= L) {
-            load_pack<T, kE>(ur + l0, xu);
-            load_pack<T, kE>(dr + l0, xd);
+    // Operand pipeline: a static ring of NS stages holding the RAW packed loads (converted on use), the
+    // chunk loop unrolled by NS so stage indices are compile-time; loads are unconditional from clamped
+    // offsets (masking happens in the arithmetic).  Two chunks stay in flight under the current one.
+    constexpr int NS = (N == 1 && VEC) ? 3 : 2;
+    struct Stage {
+        Pack<T, kE> u, d, B[N], C[N];
+    };
+    Stage ring[NS];
+    const int lmax = L >= kE ? L - kE : 0;
+    auto fetch = [&](int chunk, Stage &st) {
+        int l0 = (chunk < nchunk ? chunk : nchunk - 1) * (LPR * kE) + sub * kE;
+        if (l0 > lmax) l0 = lmax;  // lanes past the row end re-read the tail; their results are masked
+        if constexpr (VEC) {
+            st.u = *reinterpret_cast<const Pack<T, kE> *>(ur + l0);
+            st.d = *reinterpret_cast<const Pack<T, kE> *>(dr + l0);
 #pragma unroll
             for (int n = 0; n < N; ++n) {
-                load_pack<T, kE>(Br + (long)n * L + l0, xB[n]);
-                load_pack<T, kE>(Cr + (long)n * L + l0, xC[n]);
+                st.B[n] = *reinterpret_cast<const Pack<T, kE> *>(Br + (long)n * L + l0);
+                st.C[n] = *reinterpret_cast<const Pack<T, kE> *>(Cr + (long)n * L + l0);
             }
-        } else {
+        } else {  // unaligned / ragged rows: element loads, clamped per element
+            const int lb = chunk * (LPR * kE) + sub * kE;
 #pragma unroll
             for (int j = 0; j < kE; ++j) {
-                const bool ok = l0 + j < L;
-                xu[j] = ok ? Cvt<T>::to_f(ur[l0 + j]) : 0.f;
-                xd[j] = ok ? Cvt<T>::to_f(dr[l0 + j]) : 0.f;
+                const int l = lb + j < L ? lb + j : L - 1;
+                st.u.v[j] = ur[l];
+                st.d.v[j] = dr[l];
 #pragma unroll
                 for (int n = 0; n < N; ++n) {
-                    xB[n][j] = ok ? Cvt<T>::to_f(Br[(long)n * L + l0 + j]) : 0.f;
-                    xC[n][j] = ok ? Cvt<T>::to_f(Cr[(long)n * L + l0 + j]) : 0.f;
+                    st.B[n].v[j] = Br[(long)n * L + l];
+                    st.C[n].v[j] = Cr[(long)n * L + l];
                 }
             }
         }
     };
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) fetch(i, ring[i]);
 
-    fetch(0, fu, fd, fB, fC);
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        float cu[kE], cd[kE], cB[N][kE], cC[N][kE];
+    for (int c0 = 0; c0 < nchunk; c0 += NS) {
 #pragma unroll
-        for (int j = 0; j < kE; ++j) {
-            cu[j] = fu[j];
-            cd[j] = fd[j];
-#pragma unroll
-            for (int n = 0; n < N; ++n) {
-                cB[n][j] = fB[n][j];
-                cC[n][j] = fC[n][j];
-            }
-        }
-        if (chunk + 1 < nchunk) fetch(chunk + 1, fu, fd, fB, fC);
-
-        const int l0 = chunk * (LPR * kE) + sub * kE;
-        float dt[kE];
-#pragma unroll
-        for (int j = 0; j < kE; ++j) {
-            float x = cd[j] + bias;
-            dt[j] = softplus ? softplus20(x) : x;
-            if (l0 + j >= L) dt[j] = 0.f;  // identity element: a = 1, b = 0
-        }
-        float y[kE];
-#pragma unroll
-        for (int j = 0; j < kE; ++j) y[j] = skip * cu[j];
-
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-            float a[kE], bb[kE];
-            float pa = 1.f, ph = 0.f;
+        for (int si = 0; si < NS; ++si) {
+            const int chunk = c0 + si;
+            if (chunk >= nchunk) break;  // wave-uniform
+            fetch(chunk + NS - 1, ring[(si + NS - 1) % NS]);
+            const Stage &st = ring[si];
+            const int l0 = chunk * (LPR * kE) + sub * kE;
+            // only the last chunk of a row can be ragged (wave-uniform test): dt = 0 is the identity (a=1, b=0)
+            const bool ragged = (chunk + 1) * (LPR * kE) > L;
+            float cu[kE], dt[kE];
 #pragma unroll
             for (int j = 0; j < kE; ++j) {
-                a[j] = __expf(dt[j] * An[n]);
-                bb[j] = dt[j] * cB[n][j] * cu[j];
-                ph = fmaf(a[j], ph, bb[j]);
-                pa *= a[j];
+                cu[j] = Cvt<T>::to_f(st.u.v[j]);
+                const float x = Cvt<T>::to_f(st.d.v[j]) + bias;
+                dt[j] = softplus ? softplus_lean(x) : x;
             }
-            row_scan<LPR>(pa, ph, sub);
-            // exclusive prefix for this lane, then fold in the chunk carry
-            float ea = __shfl_up(pa, 1, LPR), eh = __shfl_up(ph, 1, LPR);
-            if (sub == 0) { ea = 1.f; eh = 0.f; }
-            float h = fmaf(ea, carry[n], eh);
-            // new chunk carry = inclusive prefix of the row's last lane applied to the old carry
-            const float la = __shfl(pa, LPR - 1, LPR), lh = __shfl(ph, LPR - 1, LPR);
-            carry[n] = fmaf(la, carry[n], lh);
-#pragma unroll
-            for (int j = 0; j < kE; ++j) {
-                h = fmaf(a[j], h, bb[j]);
-                y[j] = fmaf(cC[n][j], h, y[j]);
-            }
-            if (ckpt && row_ok && sub == 0) ckpt[(rrow * nchunk + chunk) * N + n] = carry[n];
-        }
-
-        if (row_ok) {
-            if (vec_ok && l0 + kE <= L) {
-                store_pack<TO, kE>(yr + l0, y);
-            } else {
+            if (ragged) {
 #pragma unroll
                 for (int j = 0; j < kE; ++j)
-                    if (l0 + j < L) yr[l0 + j] = Cvt<TO>::from_f(y[j]);
+                    if (l0 + j >= L) dt[j] = 0.f;
+            }
+            float y[kE];
+#pragma unroll
+            for (int j = 0; j < kE; ++j) y[j] = skip * cu[j];
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                float a[kE], bb[kE];
+                float pa = 1.f, ph = 0.f;
+#pragma unroll
+                for (int j = 0; j < kE; ++j) {
+                    a[j] = __builtin_amdgcn_exp2f(dt[j] * A2[n]);
+                    bb[j] = dt[j] * (Cvt<T>::to_f(st.B[n].v[j]) * cu[j]);
+                    ph = fmaf(a[j], ph, bb[j]);
+                    pa *= a[j];
+                }
+                row_scan<LPR>(pa, ph, sub);
+                // exclusive prefix for this lane, then fold in the chunk carry
+                float ea, eh, la, lh;
+                if constexpr (LPR == 64) {
+                    ea = dpp_move<0x138, 0xf>(1.f, pa);  // wave_shr:1, lane 0 keeps the identity
+                    eh = dpp_move<0x138, 0xf>(0.f, ph);
+                    la = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pa), 63));
+                    lh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ph), 63));
+                } else {
+                    ea = __shfl_up(pa, 1, LPR);
+                    eh = __shfl_up(ph, 1, LPR);
+                    if (sub == 0) { ea = 1.f; eh = 0.f; }
+                    la = __shfl(pa, LPR - 1, LPR);
+                    lh = __shfl(ph, LPR - 1, LPR);
+                }
+                float h = fmaf(ea, carry[n], eh);
+                // new chunk carry = inclusive prefix of the row's last lane applied to the old carry
+                carry[n] = fmaf(la, carry[n], lh);
+#pragma unroll
+                for (int j = 0; j < kE; ++j) {
+                    h = fmaf(a[j], h, bb[j]);
+                    y[j] = fmaf(Cvt<T>::to_f(st.C[n].v[j]), h, y[j]);
+                }
+                if (ckpt && row_ok && sub == 0) ckpt[(rrow * nchunk + chunk) * N + n] = carry[n];
+            }
+            if (row_ok) {
+                if (vec_ok) {
+                    if (l0 + kE <= L) store_pack<TO, kE>(yr + l0, y);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kE; ++j)
+                        if (l0 + j < L) yr[l0 + j] = Cvt<TO>::from_f(y[j]);
+                }
             }
         }
     }
 }
-
 
 // ------------------------------------------------------------------------------------ backward
 // Adjoint of the recurrence (N = 1).  With g_l = dLoss/dh_l:
@@ -367,13 +430,19 @@ static int launch_fwd(const void *u, const void *delta, const float *A, const vo
     const int vec_ok = (L % kE == 0) && aligned16(u) && aligned16(delta) && aligned16(Bm) &&
                        aligned16(Cm) && aligned16(out);
     dim3 grid((unsigned)blocks), block(kWavesPerBlock * kWave);
-#define LAUNCH_(LPR_)                                                                              \
-    hipLaunchKernelGGL((selective_scan_fwd_kernel<T, TO, LPR_, N>), grid, block, 0, s, (const T *)u, \
-                       (const T *)delta, A, (const T *)Bm, (const T *)Cm, D, bias, (TO *)out, ckpt,  \
-                       (int)rows, kd, K, L, nchunk, softplus, vec_ok)
-    if (lpr == 16) LAUNCH_(16);
-    else if (lpr == 32) LAUNCH_(32);
-    else LAUNCH_(64);
+#define LAUNCH_(LPR_, VEC_)                                                                             \
+    hipLaunchKernelGGL((selective_scan_fwd_kernel<T, TO, LPR_, N, VEC_>), grid, block, 0, s, (const T *)u, \
+                       (const T *)delta, A, (const T *)Bm, (const T *)Cm, D, bias, (TO *)out, ckpt,        \
+                       (int)rows, kd, K, L, nchunk, softplus)
+    if (vec_ok) {
+        if (lpr == 16) LAUNCH_(16, true);
+        else if (lpr == 32) LAUNCH_(32, true);
+        else LAUNCH_(64, true);
+    } else {
+        if (lpr == 16) LAUNCH_(16, false);
+        else if (lpr == 32) LAUNCH_(32, false);
+        else LAUNCH_(64, false);
+    }
 #undef LAUNCH_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
