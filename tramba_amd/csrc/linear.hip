@@ -254,36 +254,46 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
     for (int i = 1; i < NS; ++i) gload(i, pipe[i]);
     __syncthreads();
     const int r32 = lane & 31, hi = lane >> 5;
-    for (int kt0 = 0; kt0 < nk; kt0 += NS) {
+    // One K step, no control flow inside (a per-step `if` makes hipcc merge wait-count states
+    // conservatively: vmcnt(7) instead of vmcnt(15), i.e. half the tiles in flight).  Steps past the
+    // real K range run on zero tiles: loads are clamped, lstore masks k >= K to zero.
+    auto kstep = [&](int kt, Stage &load_into, const Stage &store_from) {
+        gload(kt + NS, load_into);  // this stage held tile kt, already in LDS
+        const unsigned char *As = lds + (kt & 1) * TILE_BYTES, *Bs = As + BM * kBK * 2;
 #pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            const int kt = kt0 + st;
-            if (kt < nk) {  // block-uniform
-                gload(kt + NS, pipe[st]);  // stage st held tile kt, already in LDS
-                const unsigned char *As = lds + (kt & 1) * TILE_BYTES, *Bs = As + BM * kBK * 2;
+        for (int kk = 0; kk < kBK / 16; ++kk) {
+            frag8_t a[TM], b[TN];
+            const int c = kk * 2 + hi;
 #pragma unroll
-                for (int kk = 0; kk < kBK / 16; ++kk) {
-                    frag8_t a[TM], b[TN];
-                    const int c = kk * 2 + hi;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const int row = wm * (BM / 2) + i * 32 + r32;
-                        a[i] = *reinterpret_cast<const frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16);
-                    }
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int row = wn * (BN / 2) + j * 32 + r32;
-                        b[j] = *reinterpret_cast<const frag8_t *>(Bs + row * 128 + swz_chunk(row, c) * 16);
-                    }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
-                }
-                if (kt + 1 < nk) lstore(kt + 1, pipe[(st + 1) % NS]);
-                __syncthreads();
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * (BM / 2) + i * 32 + r32;
+                a[i] = *reinterpret_cast<const frag8_t *>(As + row * 128 + swz_chunk(row, c) * 16);
             }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * (BN / 2) + j * 32 + r32;
+                b[j] = *reinterpret_cast<const frag8_t *>(Bs + row * 128 + swz_chunk(row, c) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
         }
+        lstore(kt + 1, store_from);
+        __syncthreads();
+    };
+    // hipcc drains vmcnt(0) at the top of every loop trip (conservative merge over the back edge): full
+    // trips cover 4*NS steps, the remainder runs in groups of NS steps.
+    const int nkp = (nk + NS - 1) / NS * NS;
+    constexpr int UNR = 4 * NS;
+    int kt0 = 0;
+    for (; kt0 + UNR <= nkp; kt0 += UNR) {
+#pragma unroll
+        for (int ui = 0; ui < UNR; ++ui) kstep(kt0 + ui, pipe[ui % NS], pipe[(ui + 1) % NS]);
+    }
+    for (; kt0 < nkp; kt0 += NS) {
+#pragma unroll
+        for (int ui = 0; ui < NS; ++ui) kstep(kt0 + ui, pipe[ui % NS], pipe[(ui + 1) % NS]);
     }
 
     // ---- epilogue through LDS: wave-private (BM/2) x (BN/2) fp32 tile, row stride WN floats
