@@ -236,3 +236,23 @@ def test_tramba_v_train_step(dtype):
     l3 = float(train.train_step(m, opt, x, y, reducer=red))
     assert np.isfinite([l2, l3]).all()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_tramba_v_768_fp16_long_sequence_against_oracle():
+    """BASELINE config 5: 768x768 fp16, feature sizes 192/96/48/24 (L up to 36 864; 192 is OFF the
+    reference's tables: window 16, dilation 4 by the documented rule).  Compared with the fp32 oracle."""
+    import tramba_amd as ta
+    m = _load_synth(ta.bulid_model(deep_supervision=True, use_pretrain=False, img_size=768))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x = synth.synth_input("c5", (1, 3, 768, 768))
+    with torch.no_grad():
+        want = om.tramba_v(sd, x)
+        got32 = m(x.to(DEV))
+        m16 = ta.prepare_inference(m, torch.float16)
+        got16 = m16(x.to(DEV))
+    assert [tuple(o.shape) for o in got32] == [(1, 1, 48, 48), (1, 1, 96, 96), (1, 1, 192, 192), (1, 1, 768, 768)]
+    for g, w in zip(got32, want):
+        np.testing.assert_allclose(g.cpu().numpy(), w.numpy(), rtol=5e-3, atol=2e-3)
+    gt = (synth.synth_input("c5_gt", (768, 768)) > 0.5).numpy()
+    mae = lambda o: oo.mae_metric(torch.sigmoid(o[-1])[0, 0].float().cpu().numpy(), gt)
+    assert abs(mae(got16) - mae(want)) < 5e-4
