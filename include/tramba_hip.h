@@ -123,9 +123,14 @@ int tramba_cross_merge(const void *ys, const int32_t *inv_ptr, const int32_t *in
  * table (K, L) int32 device; dt_w (K, D, R) f32; dt_bias (K*D) f32; A (K*D) f32 (= -exp(A_logs));
  * Ds (K*D) f32.   ys: (B, K, L, D) ys_dtype in SEQUENCE order.                                   */
 int tramba_ss2d_group_stride(int r);
+/* workspace (device memory, 16-byte aligned, >= tramba_ss2d_scan_workspace() bytes) selects the
+ * wave-segment form: segment reduce -> carry scan -> segment replay, every wave independent.  With
+ * workspace == NULL the chained single-pass kernel (one workgroup per sequence) runs instead. */
+size_t tramba_ss2d_scan_workspace(int batch, int l, int d, int k);
 int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
-                        const float *dt_bias, const float *A, const float *Ds, void *ys, int batch,
-                        int l, int d, int k, int r, int dtype, int ys_dtype, void *stream);
+                        const float *dt_bias, const float *A, const float *Ds, void *ys, void *workspace,
+                        size_t workspace_bytes, int batch, int l, int d, int k, int r, int dtype,
+                        int ys_dtype, void *stream);
 /* y[b,p,:] = act(LayerNorm_D(sum_{e in inv[p]} ys[b, e/L, e%L, :]));  y: (B, L, D) dtype. */
 int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr, const int32_t *inv_idx,
                               const float *ln_w, const float *ln_b, void *y, int batch, int l, int d,

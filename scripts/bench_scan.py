@@ -29,15 +29,15 @@ def run(name, reps=20, b=4, dtype=torch.bfloat16):
     a = -torch.ones(k * d, device=dev)
     ds = torch.ones(k * d, device=dev)
     lw, lb = torch.ones(d, device=dev), torch.zeros(d, device=dev)
-    for ys_dtype in (torch.float32, dtype):
+    for ys_dtype, seg in ((torch.float32, False), (torch.float32, True), (dtype, True)):
         for _ in range(3):
-            ys = hip.ss2d_scan_cl(x, xdbl, order, dt_w, dt_b, a, ds, ys_dtype)
+            ys = hip.ss2d_scan_cl(x, xdbl, order, dt_w, dt_b, a, ds, ys_dtype, segmented=seg)
             y = hip.ss2d_merge_norm_cl(ys, order, lw, lb, 1e-5, 2, dtype)
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
         for _ in range(reps):
-            ys = hip.ss2d_scan_cl(x, xdbl, order, dt_w, dt_b, a, ds, ys_dtype)
+            ys = hip.ss2d_scan_cl(x, xdbl, order, dt_w, dt_b, a, ds, ys_dtype, segmented=seg)
         ev[1].record()
         for _ in range(reps):
             y = hip.ss2d_merge_norm_cl(ys, order, lw, lb, 1e-5, 2, dtype)
@@ -45,7 +45,7 @@ def run(name, reps=20, b=4, dtype=torch.bfloat16):
         torch.cuda.synchronize()
         ts, tm = ev[0].elapsed_time(ev[1]) / reps * 1e3, ev[1].elapsed_time(ev[2]) / reps * 1e3
         elems = b * k * l * d
-        print(f"{name:7s} ys={str(ys_dtype)[6:]:8s} scan {ts:8.1f} us ({elems / ts / 1e3:7.2f} Gelem/s)  merge {tm:7.1f} us", flush=True)
+        print(f"{name:7s} {'segmented' if seg else 'chained  '} ys={str(ys_dtype)[6:]:8s} scan {ts:8.1f} us ({elems / ts / 1e3:7.2f} Gelem/s)  merge {tm:7.1f} us", flush=True)
 
 
 if __name__ == "__main__":

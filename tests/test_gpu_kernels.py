@@ -179,7 +179,7 @@ def test_linear_cl(dtype, mnk):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("fam", ["raster", "helix", "window", "dilation"])
-@pytest.mark.parametrize("cfg", [(2, 12, 32, 2), (1, 24, 64, 4), (1, 16, 40, 3), (1, 48, 128, 8), (1, 12, 96, 40), (1, 24, 32, 64)])
+@pytest.mark.parametrize("cfg", [(2, 12, 32, 2), (1, 24, 64, 4), (1, 16, 40, 3), (1, 48, 128, 8), (1, 12, 96, 40), (1, 24, 32, 64), (2, 96, 64, 8)])
 def test_ss2d_fused_core(dtype, fam, cfg):
     """fused channels-last scan + merge/LayerNorm/GELU against the oracle's NCHW composition."""
     b, h, d, r = cfg
@@ -201,11 +201,12 @@ def test_ss2d_fused_core(dtype, fam, cfg):
     xc = x.permute(0, 2, 3, 1).contiguous().view(b, h * h, d).to(dev)
     xdbl = H.linear_cl(xc, H.pad_x_proj_weight(wx.to(dev)), out_dtype=torch.float32)
     for ys_dtype in ([torch.float32] if dtype == torch.float32 else [torch.float32, dtype]):
-        ys = H.ss2d_scan_cl(xc, xdbl, order, wdt.to(dev), dtb.reshape(-1).to(dev), (-torch.exp(a_logs)).reshape(-1).to(dev),
-                            ds.to(dev), ys_dtype)
-        out = H.ss2d_merge_norm_cl(ys, order, lw.to(dev), lb.to(dev), 1e-5, 2, dtype)
-        tol = 2e-4 if dtype == torch.float32 else 4e-2
-        np.testing.assert_allclose(out.view(b, h, h, d).cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
+        for segmented in (True, False):  # library-chosen form with workspace / chained form without
+            ys = H.ss2d_scan_cl(xc, xdbl, order, wdt.to(dev), dtb.reshape(-1).to(dev),
+                                (-torch.exp(a_logs)).reshape(-1).to(dev), ds.to(dev), ys_dtype, segmented=segmented)
+            out = H.ss2d_merge_norm_cl(ys, order, lw.to(dev), lb.to(dev), 1e-5, 2, dtype)
+            tol = 2e-4 if dtype == torch.float32 else 4e-2
+            np.testing.assert_allclose(out.view(b, h, h, d).cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -31,6 +31,9 @@
 // ss2d_merge_norm_cl: one wave per pixel sums the rows listed by the inverse table
 //   (deterministic, atomic-free even for the many-to-one Helix lines), applies out_norm
 //   (LayerNorm over D, two-pass fp32) and the following GELU, writes the activation dtype.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "norm.h"
 
@@ -297,6 +300,261 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wave-segment form of the same scan (used when a workspace is supplied): NO barriers and no
+// per-sequence chain.  A sequence of one (b, k, 32-channel tile) is cut into NSEG segments of NT
+// tiles; every WAVE owns one segment and walks its tiles alone.
+//   PASS 0  reduces the segment to its (decay, state) pair            -> agg   (B,K,NSEG,D) float2
+//   carry   a tiny kernel scans the NSEG pairs of each channel         -> carry (B,K,NSEG,D) float
+//   PASS 1  recomputes the segment from its carry-in and streams y out
+// The per-element terms are evaluated twice (~1.6x the arithmetic of the chained kernel), but the
+// launch has B*K*(D/32)*NSEG independent waves instead of B*K*(D/32) serial chains of 8 waves, so the
+// whole chip is busy: 2-3x faster on this model's shapes.  Segments of one sequence are independent,
+// tiles past a segment's end are computed on the identity (dt = 0) and never stored.
+struct SegPlan {
+    int ntiles, nt, nseg;
+};
+
+__host__ inline SegPlan seg_plan(int l, long rowtiles)
+{
+    SegPlan p;
+    p.ntiles = (l + kTP - 1) / kTP;
+    long want = 4096 / (rowtiles > 0 ? rowtiles : 1);
+    if (want < 1) want = 1;
+    int nt = (int)((p.ntiles + want - 1) / want);
+    nt = (nt + 2) / 3 * 3;  // multiple of the operand ring (no wasted padding tiles)
+    if (p.ntiles <= 6) nt = (p.ntiles + 2) / 3 * 3;  // short sequences: one segment, single pass
+    p.nt = nt;
+    p.nseg = (p.ntiles + nt - 1) / nt;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void ss2d_seg_carry_kernel(const float2 *__restrict__ agg, float *__restrict__ carry,
+                                                            long nchain, int nseg, int D)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (b*K + k) * D + c
+    if (i >= nchain) return;
+    const long bk = i / D;
+    const int c = (int)(i % D);
+    float run = 0.f;
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+        const long o = (bk * nseg + sgm) * D + c;
+        const float2 ah = agg[o];
+        carry[o] = run;
+        run = fmaf(ah.x, run, ah.y);
+    }
+}
+
+template <typename T, typename TY, int NK, bool SPLIT, int PASS>
+__global__ __launch_bounds__(256) void ss2d_seg_kernel(
+    const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
+    const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
+    const float *__restrict__ Ds, TY *__restrict__ ys, float2 *__restrict__ agg, const float *__restrict__ carry,
+    int L, int D, int K, int R, int CT, int NT, int NSEG, long nwaves)
+{
+    __shared__ __attribute__((aligned(16))) float stage[4][3][kTP];  // per wave: pixel idx, B, C per position
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long gid = (long)blockIdx.x * 4 + wv;
+    if (gid >= nwaves) return;  // wave-uniform, the kernel has no barriers
+    const int sgm = (int)(gid % NSEG);
+    long rt = gid / NSEG;
+    const int ctile = (int)(rt % CT);
+    rt /= CT;
+    const int k = (int)(rt % K), b = (int)(rt / K);
+
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int c = ctile * kTP + r32;
+    const bool cok = c < D;
+    const int cc_ = cok ? c : D - 1;
+    const int RG = xdbl_group_stride(R);
+    const int PC = K * RG;
+    const bool rvec = (R & 7) == 0;
+
+    frag8_t wh[NK], wl[NK];
+    {
+        const float *wrow = dt_w + ((long)k * D + cc_) * R;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = kk * 16 + hi * 8 + j;
+                t[j] = r < R ? wrow[r] : 0.f;
+            }
+            pack_frag<SPLIT>(t, wh[kk], wl[kk]);
+        }
+    }
+    const float bias = dt_bias[(long)k * D + cc_];
+    const float A2 = Aneg[(long)k * D + cc_] * 1.44269504088896f;
+    const float Dk = Ds[(long)k * D + cc_];
+
+    const T *xb = x + (long)b * L * D;
+    const float *pb = xdbl + (long)b * L * PC + (long)k * RG;
+    const int32_t *tk = table + (long)k * L;
+    TY *yb = ys + ((long)b * K + k) * L * D;
+    float *st = &stage[wv][0][0];
+
+    const int t0 = sgm * NT;                                  // first tile of my segment
+    const int lend = (t0 + NT) * kTP < L ? (t0 + NT) * kTP : L;  // my segment is [t0*32, lend)
+    const int tlast = (L - 1) / kTP;                          // loads are clamped to the last real tile
+
+    auto load_idx = [&](int t) -> int {
+        const int l = (t < tlast ? t : tlast) * kTP + r32;
+        return tk[l < L ? l : L - 1];
+    };
+    auto load_rows = [&](int pix, TileOps<NK> &o) {
+        const float *row = pb + (unsigned)(pix * PC);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int r0 = kk * 16 + hi * 8;
+            if (rvec) {
+                const int rr = r0 < R ? r0 : RG - 8;
+                const float4 v0 = *reinterpret_cast<const float4 *>(row + rr);
+                const float4 v1 = *reinterpret_cast<const float4 *>(row + rr + 4);
+                o.araw[kk][0] = v0.x; o.araw[kk][1] = v0.y; o.araw[kk][2] = v0.z; o.araw[kk][3] = v0.w;
+                o.araw[kk][4] = v1.x; o.araw[kk][5] = v1.y; o.araw[kk][6] = v1.z; o.araw[kk][7] = v1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o.araw[kk][j] = r0 + j < R ? row[r0 + j] : 0.f;
+            }
+        }
+        o.bv = row[R];
+        o.cv = row[R + 1];
+    };
+    auto read_stage4 = [&](int which, float (&out)[16]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4 *>(st + which * kTP + 8 * g + 4 * hi);
+            out[4 * g + 0] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
+        }
+    };
+    auto load_u = [&](const float (&pixf)[16], TileOps<NK> &o) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pix = __builtin_bit_cast(int, pixf[r]);
+            o.u[r] = Cvt<T>::to_f(xb[(unsigned)(pix * D + cc_)]);
+        }
+    };
+    constexpr int AHEAD = NK <= 2 ? 2 : 1;
+    constexpr int NS = AHEAD + 1;
+    TileOps<NK> ops[NS];
+    float pixf[16];
+    auto fetch = [&](int idxv, TileOps<NK> &o) {
+        if (hi == 0) st[r32] = __builtin_bit_cast(float, idxv);
+        __builtin_amdgcn_wave_barrier();
+        read_stage4(0, pixf);
+        __builtin_amdgcn_wave_barrier();
+        load_rows(idxv, o);
+        load_u(pixf, o);
+    };
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) fetch(load_idx(t0 + t), ops[t]);
+    int idx_ahead = load_idx(t0 + AHEAD);
+
+    float runA = 1.f, runH = 0.f;  // PASS 0: aggregate of the segment so far
+    float hin = 0.f;               // PASS 1: state entering the current tile
+    if (PASS == 1 && carry) hin = carry[(((long)b * K + k) * NSEG + sgm) * D + cc_];
+    const bool cfull = ctile * kTP + kTP <= D;
+
+    const int ntp = (NT + NS - 1) / NS * NS;  // whole ring trips; padding tiles run on the identity
+    for (int i0 = 0; i0 < ntp; i0 += NS) {
+#pragma unroll
+      for (int sti = 0; sti < NS; ++sti) {
+        const int t = t0 + i0 + sti;
+        TileOps<NK> &cur = ops[sti];
+        const int l0 = t * kTP;
+        if (hi == 0) {
+            st[kTP + r32] = cur.bv;
+            st[2 * kTP + r32] = cur.cv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float Bp[16], Cp[16];
+        read_stage4(1, Bp);
+        if (PASS == 1) read_stage4(2, Cp);
+        fetch(idx_ahead, ops[(sti + AHEAD) % NS]);
+        idx_ahead = load_idx(t + AHEAD + 1);
+
+        acc16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            frag8_t ah, al;
+            pack_frag<SPLIT>(cur.araw[kk], ah, al);
+            acc = mfma_bf16(ah, wh[kk], acc);
+            if (SPLIT) {
+                acc = mfma_bf16(ah, wl[kk], acc);
+                acc = mfma_bf16(al, wh[kk], acc);
+            }
+        }
+        const bool ragged = l0 + kTP > lend;  // wave-uniform: segment / sequence end inside or before this tile
+        float a[16], bb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float xr = acc[r] + bias;
+            const float z = __builtin_amdgcn_exp2f(fminf(xr, 60.f) * 1.44269504088896f);
+            float dt = fmaxf(xr, __builtin_amdgcn_logf(1.f + z) * 0.693147180559945f);
+            if (ragged && l0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= lend) dt = 0.f;
+            a[r] = __builtin_amdgcn_exp2f(dt * A2);
+            bb[r] = dt * (Bp[r] * cur.u[r]);
+        }
+        float sa[4], sh[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float pa = 1.f, ph = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ph = fmaf(a[4 * g + q], ph, bb[4 * g + q]);
+                pa *= a[4 * g + q];
+            }
+            sa[g] = pa;
+            sh[g] = ph;
+        }
+        float preA[4], preH[4];
+        float tA = 1.f, tH = 0.f;  // aggregate of this tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float oa = __shfl_xor(sa[g], 32, 64), oh = __shfl_xor(sh[g], 32, 64);
+            const float ea = hi ? oa : sa[g], eh = hi ? oh : sh[g];
+            const float fa = hi ? sa[g] : oa, fh = hi ? sh[g] : oh;
+            const float midH = fmaf(ea, tH, eh), midA = ea * tA;
+            preA[g] = hi ? midA : tA;
+            preH[g] = hi ? midH : tH;
+            tH = fmaf(fa, midH, fh);
+            tA = fa * midA;
+        }
+        if (PASS == 0) {
+            runH = fmaf(tA, runH, tH);
+            runA *= tA;
+        } else {
+            const bool full = cfull && l0 + kTP <= lend;
+            unsigned yoff = (unsigned)((l0 + 4 * hi) * D + cc_);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float hh = fmaf(preA[g], hin, preH[g]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * g + q;
+                    hh = fmaf(a[r], hh, bb[r]);
+                    const TY out = Cvt<TY>::from_f(fmaf(Cp[r], hh, Dk * cur.u[r]));
+                    const unsigned off = yoff + (unsigned)((q + 8 * g) * D);
+                    if (full) {
+                        yb[off] = out;
+                    } else if (cok && l0 + q + 8 * g + 4 * hi < lend) {
+                        yb[off] = out;
+                    }
+                }
+            }
+            hin = fmaf(tA, hin, tH);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (PASS == 0 && hi == 0 && cok) agg[(((long)b * K + k) * NSEG + sgm) * D + c] = make_float2(runA, runH);
+}
+
+// ---------------------------------------------------------------------------------------------
 // NIT = wave iterations per row (D <= 64*V*NIT); BATCH rows of ys are requested back to back
 // before any is consumed, so a pixel pays ~1 memory latency instead of one per direction.
 template <typename TY, typename T, int V, int NIT>
@@ -365,10 +623,19 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_cl_kernel(
 
 using namespace tramba;
 
+extern "C" size_t tramba_ss2d_scan_workspace(int batch, int l, int d, int k)
+{
+    if (batch <= 0 || l <= 0 || d <= 0 || k <= 0) return 0;
+    const SegPlan p = seg_plan(l, (long)batch * k * ((d + kTP - 1) / kTP));
+    if (p.nseg <= 1) return 16;  // single pass, nothing to exchange (non-zero: "use the segment kernel")
+    return (size_t)batch * k * p.nseg * d * (sizeof(float2) + sizeof(float));
+}
+
 extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32_t *table,
                                    const float *dt_w, const float *dt_bias, const float *A,
-                                   const float *Ds, void *ys, int batch, int l, int d, int k, int r,
-                                   int dtype, int ys_dtype, void *stream)
+                                   const float *Ds, void *ys, void *workspace, size_t workspace_bytes,
+                                   int batch, int l, int d, int k, int r, int dtype, int ys_dtype,
+                                   void *stream)
 {
     TRAMBA_CHECK(x && xdbl && table && dt_w && dt_bias && A && Ds && ys, "ss2d_scan_cl: null tensor");
     TRAMBA_CHECK(batch > 0 && l > 0 && d > 0 && k > 0 && r > 0, "ss2d_scan_cl: empty shape");
@@ -378,37 +645,82 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     TRAMBA_CHECK(aligned16(xdbl), "ss2d_scan_cl: xdbl must be 16-byte aligned");
     TRAMBA_CHECK((double)batch * k * l * (double)d < 2.0e9, "ss2d_scan_cl: tensor too large for this build");
     hipStream_t s = (hipStream_t)stream;
-    int W = (l + kTP - 1) / kTP;
-    if (W > kMaxW) W = kMaxW;
     const int nk = (r + 15) / 16;
     const int rg = xdbl_group_stride(r);
-    dim3 grid((d + kTP - 1) / kTP, k, batch), block(W * kWave);
-    // algorithmic bytes of this kernel: x read once, the low-rank x_proj rows, ys written
+    // algorithmic bytes of this op: x read once, the low-rank x_proj rows, ys written
     ProfScope prof(TRAMBA_PROF_SCAN_FUSED, s,
                    (double)batch * l * d * dtype_size(dtype) + (double)batch * l * k * rg * 4.0 +
                        (double)batch * k * l * (double)d * dtype_size(ys_dtype));
+#define BY_NK_(MAC, T, TY, SP_)             \
+    switch (nk) {                           \
+    case 1: MAC(T, TY, 1, SP_); break;      \
+    case 2: MAC(T, TY, 2, SP_); break;      \
+    case 3: MAC(T, TY, 3, SP_); break;      \
+    default: MAC(T, TY, 4, SP_); break;     \
+    }
+#define BY_DTYPE_(MAC)                                                                                          \
+    if (dtype == TRAMBA_F32) {                                                                                  \
+        BY_NK_(MAC, float, float, true)                                                                         \
+    } else if (dtype == TRAMBA_BF16) {                                                                          \
+        if (ys_dtype == TRAMBA_F32) { BY_NK_(MAC, __hip_bfloat16, float, false) }                               \
+        else { BY_NK_(MAC, __hip_bfloat16, __hip_bfloat16, false) }                                             \
+    } else if (dtype == TRAMBA_F16) {                                                                           \
+        if (ys_dtype == TRAMBA_F32) { BY_NK_(MAC, __half, float, false) } else { BY_NK_(MAC, __half, __half, false) } \
+    } else {                                                                                                    \
+        set_error("ss2d_scan_cl: bad dtype %d", dtype);                                                         \
+        return TRAMBA_ERR_ARG;                                                                                  \
+    }
+
+    const int ct = (d + kTP - 1) / kTP;
+    const SegPlan p = seg_plan(l, (long)batch * k * ct);
+    // Form selection (measured, scripts/bench_scan.py): the kernels are VALU-throughput bound once the chip
+    // is full, so the segment form (1.6x the arithmetic) only wins where the chained form leaves CUs idle:
+    // a single-segment sequence (no recompute at all, no barriers), or <= 128 sequences of >= 64 tiles.
+    // TRAMBA_SCAN_FORM=segment|chain overrides (tuning / tests).
+    static const int forced = [] {
+        const char *e = getenv("TRAMBA_SCAN_FORM");
+        return !e ? 0 : (strcmp(e, "segment") == 0 ? 1 : (strcmp(e, "chain") == 0 ? 2 : 0));
+    }();
+    const bool seg_wins = p.nseg == 1 || ((long)batch * k * ct <= 128 && p.ntiles >= 64);
+    const bool use_seg = workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) &&
+                         (forced == 1 || (forced == 0 && seg_wins));
+    if (use_seg) {
+        // ---- wave-segment form: pass 0 -> carry scan -> pass 1 (single pass when one segment suffices)
+        TRAMBA_CHECK(aligned16(workspace), "ss2d_scan_cl: workspace must be 16-byte aligned");
+        const long nwaves = (long)batch * k * ct * p.nseg;
+        float2 *agg = reinterpret_cast<float2 *>(workspace);
+        float *carry = reinterpret_cast<float *>(agg + (size_t)batch * k * p.nseg * d);
+        dim3 grid((unsigned)((nwaves + 3) / 4)), block(256);
+#define SEG0_(T, TY, NK_, SP_)                                                                                   \
+    hipLaunchKernelGGL((ss2d_seg_kernel<T, TY, NK_, SP_, 0>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, \
+                       dt_bias, A, Ds, (TY *)ys, agg, (const float *)nullptr, l, d, k, r, ct, p.nt, p.nseg, nwaves)
+#define SEG1_(T, TY, NK_, SP_)                                                                                   \
+    hipLaunchKernelGGL((ss2d_seg_kernel<T, TY, NK_, SP_, 1>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, \
+                       dt_bias, A, Ds, (TY *)ys, agg, (const float *)(p.nseg > 1 ? carry : nullptr), l, d, k, r, \
+                       ct, p.nt, p.nseg, nwaves)
+        if (p.nseg > 1) {
+            BY_DTYPE_(SEG0_)
+            const long nchain = (long)batch * k * d;
+            hipLaunchKernelGGL(ss2d_seg_carry_kernel, dim3((unsigned)((nchain + 255) / 256)), dim3(256), 0, s, agg,
+                               carry, nchain, p.nseg, d);
+        }
+        BY_DTYPE_(SEG1_)
+#undef SEG0_
+#undef SEG1_
+        TRAMBA_LAUNCH_CHECK();
+        return TRAMBA_OK;
+    }
+    // ---- chained form (no workspace): one workgroup of W waves per sequence
+    int W = (l + kTP - 1) / kTP;
+    if (W > kMaxW) W = kMaxW;
+    dim3 grid(ct, k, batch), block(W * kWave);
 #define GO_(T, TY, NK_, SP_)                                                                               \
     hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK_, SP_>), grid, block, 0, s, (const T *)x, xdbl, table, \
                        dt_w, dt_bias, A, Ds, (TY *)ys, l, d, k, r, W)
-#define BY_NK_(T, TY, SP_)                  \
-    switch (nk) {                           \
-    case 1: GO_(T, TY, 1, SP_); break;      \
-    case 2: GO_(T, TY, 2, SP_); break;      \
-    case 3: GO_(T, TY, 3, SP_); break;      \
-    default: GO_(T, TY, 4, SP_); break;     \
-    }
-    if (dtype == TRAMBA_F32) {
-        BY_NK_(float, float, true)
-    } else if (dtype == TRAMBA_BF16) {
-        if (ys_dtype == TRAMBA_F32) { BY_NK_(__hip_bfloat16, float, false) } else { BY_NK_(__hip_bfloat16, __hip_bfloat16, false) }
-    } else if (dtype == TRAMBA_F16) {
-        if (ys_dtype == TRAMBA_F32) { BY_NK_(__half, float, false) } else { BY_NK_(__half, __half, false) }
-    } else {
-        set_error("ss2d_scan_cl: bad dtype %d", dtype);
-        return TRAMBA_ERR_ARG;
-    }
-#undef BY_NK_
+    BY_DTYPE_(GO_)
 #undef GO_
+#undef BY_DTYPE_
+#undef BY_NK_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }

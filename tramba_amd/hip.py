@@ -41,7 +41,8 @@ SIGNATURES = {
     "tramba_cross_scan": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_cross_merge": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_ss2d_group_stride": (c_int, [c_int]),
-    "tramba_ss2d_scan_cl": (c_int, [c_vp] * 8 + [c_int] * 7 + [c_vp]),
+    "tramba_ss2d_scan_workspace": (ctypes.c_size_t, [c_int] * 4),
+    "tramba_ss2d_scan_cl": (c_int, [c_vp] * 9 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_shuffle_norm_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_f, c_int, c_vp]),
@@ -259,8 +260,21 @@ def pad_x_proj_weight(x_proj_weight: torch.Tensor) -> torch.Tensor:
     return w.reshape(k * rg, d)
 
 
-def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch.float32):
-    """x: (B, L, D); xdbl: (B, L, K*RG) f32 -> ys (B, K, L, D)."""
+_scan_ws = {}
+
+
+def _scan_workspace(device, nbytes):
+    """Per-device scratch for the wave-segment scan (grown on demand, reused by every launch: launches
+    on one stream are ordered, and graph capture sees a stable address)."""
+    ws = _scan_ws.get(str(device))
+    if ws is None or ws.numel() < nbytes:
+        ws = _scan_ws[str(device)] = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
+    return ws
+
+
+def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch.float32, segmented=True):
+    """x: (B, L, D); xdbl: (B, L, K*RG) f32 -> ys (B, K, L, D).  With `segmented` a workspace is passed and
+    the library picks the wave-segment or the chained form per shape (TRAMBA_SCAN_FORM forces one)."""
     _dev(x, xdbl, dt_w, dt_bias, A, Ds)
     b, l, d = x.shape
     k, r = order.k, dt_w.shape[-1]
@@ -269,8 +283,13 @@ def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch
     if l != order.l or dt_w.shape != (k, d, r) or A.numel() != k * d or Ds.numel() != k * d or dt_bias.numel() != k * d:
         raise TrambaHipError("ss2d_scan_cl: parameter shapes do not match (K, D, R)")
     ys = torch.empty((b, k, l, d), dtype=ys_dtype, device=x.device)
+    ws, ws_bytes = None, 0
+    if segmented:
+        ws_bytes = lib().tramba_ss2d_scan_workspace(b, l, d, k)
+        ws = _scan_workspace(x.device, ws_bytes)
     _check(lib().tramba_ss2d_scan_cl(_ptr(x), _ptr(xdbl), _ptr(order.table), _ptr(dt_w), _ptr(dt_bias), _ptr(A),
-                                     _ptr(Ds), _ptr(ys), b, l, d, k, r, dt(x), dt(ys), _stream()), "ss2d_scan_cl")
+                                     _ptr(Ds), _ptr(ys), _ptr(ws), ws_bytes, b, l, d, k, r, dt(x), dt(ys), _stream()),
+           "ss2d_scan_cl")
     return ys
 
 
