@@ -301,6 +301,12 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_ker
     const float bias = dbias ? dbias[d] : 0.f;
     const float skip = Dskip ? Dskip[d] : 0.f;
 
+    // dB/dC contributions leave through LDS so that every atomic wave-instruction adds 64 CONSECUTIVE
+    // floats (256 contiguous bytes): in registers lane i holds elements 8i..8i+7, which as atomics would be
+    // 64 scattered 4-byte adds per instruction (an order of magnitude slower, MI355X global float atomics)
+    __shared__ float tr[kWavesPerBlock][2][kWave * kE];
+    float *trB = tr[threadIdx.x >> 6][0], *trC = tr[threadIdx.x >> 6][1];
+
     float g_carry = 0.f;   // g of the first element of the chunk to the right
     float a_carry = 1.f;   // a of that element
     float accA = 0.f, accD = 0.f, accBias = 0.f;
@@ -387,11 +393,25 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_ker
             accA = fmaf(g * hprev[j], a[j] * dt[j], accA);
             accD = fmaf(go[j], cu[j], accD);
             accBias += odd[j];
-            if (ok && row_ok) {
-                atomicAdd(dB + pc + bc + l0 + j, g * dt[j] * cu[j]);
-                atomicAdd(dC + pc + bc + l0 + j, go[j] * hcur[j]);
+            trB[lane * kE + j] = ok ? g * dt[j] * cu[j] : 0.f;
+            trC[lane * kE + j] = ok ? go[j] * hcur[j] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (row_ok) {
+            // lane i, step j -> element (lane/LPR)*LPR*kE + j*LPR + sub of the wave's staging area, i.e.
+            // position chunk*LPR*kE + j*LPR + sub of the row: consecutive lanes, consecutive addresses
+            const int rbase = (lane / LPR) * (LPR * kE);
+#pragma unroll
+            for (int j = 0; j < kE; ++j) {
+                const int e = j * LPR + sub;
+                const int l = chunk * (LPR * kE) + e;
+                if (l < L) {
+                    atomicAdd(dB + pc + bc + l, trB[rbase + e]);
+                    atomicAdd(dC + pc + bc + l, trC[rbase + e]);
+                }
             }
         }
+        __builtin_amdgcn_wave_barrier();
         if (row_ok) {
             if (vec_ok && l0 + kE <= L) {
                 store_pack<T, kE>(du + rrow * L + l0, odu);

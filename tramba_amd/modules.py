@@ -98,26 +98,28 @@ def _act_torch(x, act):
     return x
 
 
-class _DepthwiseConvNative(torch.autograd.Function):
-    """Depth-wise conv for the TRAINING path with autograd: PyTorch's native depth-wise kernels, forward and
-    backward, with MIOpen bypassed (its channels-last grouped-conv kernels are >10x slower on these shapes,
-    scripts/probe_dw.py).  The inference path uses tramba_dwconv_cl instead."""
+class _ConvNative(torch.autograd.Function):
+    """Convolutions of the TRAINING path with autograd: PyTorch's native kernels (depth-wise kernels /
+    im2col + GEMM), forward and backward, with MIOpen bypassed -- its channels-last grouped-conv and
+    bwd-weight kernels are 10-100x slower on these shapes (scripts/probe_dw.py, profiles/).  The inference
+    path uses tramba_dwconv_cl / tramba_conv3x3s2_cl instead."""
 
     @staticmethod
-    def forward(ctx, x, w, b, padding):
+    def forward(ctx, x, w, b, stride, padding, groups):
         ctx.save_for_backward(x, w)
-        ctx.padding, ctx.has_bias = padding, b is not None
+        ctx.cfg = (tuple(stride), tuple(padding), groups, b is not None)
         with torch.backends.cudnn.flags(enabled=False):
-            return F.conv2d(x, w, b, padding=padding, groups=w.shape[0])
+            return F.conv2d(x, w, b, stride=stride, padding=padding, groups=groups)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
+        stride, padding, groups, has_bias = ctx.cfg
         with torch.backends.cudnn.flags(enabled=False):
             gx, gw, gb = torch.ops.aten.convolution_backward(
-                gy, x, w, [w.shape[0]] if ctx.has_bias else None, [1, 1], list(ctx.padding), [1, 1], False, [0, 0],
-                w.shape[0], [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias])
-        return gx, gw, gb, None
+                gy.contiguous(), x, w, [w.shape[0]] if has_bias else None, list(stride), list(padding), [1, 1], False,
+                [0, 0], groups, [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias])
+        return gx, gw, gb, None, None, None
 
 
 def _dwconv_train_cl(x_cl, conv: nn.Conv2d):
@@ -125,7 +127,7 @@ def _dwconv_train_cl(x_cl, conv: nn.Conv2d):
     x = from_cl(x_cl).contiguous()
     w = conv.weight.to(x.dtype)
     b = None if conv.bias is None else conv.bias.to(x.dtype)
-    return to_cl(_DepthwiseConvNative.apply(x, w, b, tuple(conv.padding)))
+    return to_cl(_ConvNative.apply(x, w, b, (1, 1), tuple(conv.padding), w.shape[0]))
 
 
 class DropPath(nn.Module):
@@ -701,8 +703,10 @@ def _conv_cl(conv: nn.Conv2d, x_cl):
                               .to(x_cl.dtype).contiguous())
         return hip.conv3x3s2_cl(x_cl, wk, _f32(conv.bias))
     x = from_cl(x_cl)
-    w = conv.weight.to(x.dtype).contiguous(memory_format=torch.channels_last)
     b = None if conv.bias is None else conv.bias.to(x.dtype)
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return to_cl(_ConvNative.apply(x.contiguous(), conv.weight.to(x.dtype), b, conv.stride, conv.padding, 1))
+    w = conv.weight.to(x.dtype).contiguous(memory_format=torch.channels_last)
     return to_cl(F.conv2d(x, w, b, stride=conv.stride, padding=conv.padding))
 
 
