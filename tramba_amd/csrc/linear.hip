@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
     constexpr int A_CHUNKS = BM * (kBK / 8), B_CHUNKS = BN * (kBK / 8);
     constexpr int A_PER_T = A_CHUNKS / 256, B_PER_T = B_CHUNKS / 256;
     constexpr int TILE_BYTES = (BM + BN) * kBK * 2;
-    constexpr int EPI_BYTES = 4 * (BM / 2) * (BN / 2) * 4;
+    constexpr int EPI_BYTES = BM * BN * 4;
     constexpr int LDS_BYTES = 2 * TILE_BYTES > EPI_BYTES ? 2 * TILE_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -296,47 +296,56 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
         for (int ui = 0; ui < NS; ++ui) kstep(kt0 + ui, pipe[ui % NS], pipe[(ui + 1) % NS]);
     }
 
-    // ---- epilogue through LDS: wave-private (BM/2) x (BN/2) fp32 tile, row stride WN floats
+    // ---- epilogue through LDS, block-wide: the four waves drop their accumulators into one BM x BN fp32
+    // tile, then all 256 threads stream it out as 16-byte stores covering whole rows (a wave-private
+    // 32-column epilogue wrote 64-byte half lines with 8-byte stores: ~1 TB/s on the output-bound layers)
     constexpr int WM = BM / 2, WN = BN / 2;
-    float *ep = reinterpret_cast<float *>(lds) + wave * WM * WN;
+    float *ep = reinterpret_cast<float *>(lds);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                ep[row * WN + j * 32 + r32] = acc[i][j][r];
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                ep[row * BN + wn * WN + j * 32 + r32] = acc[i][j][r];
             }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tile is wave-private, no barrier needed
-    constexpr int LPRW = WN / 4;          // lanes per row, 4 columns each
-    constexpr int RPI = 64 / LPRW;        // rows per wave iteration
-    const int cl = (lane % LPRW) * 4, rl = lane / LPRW;
-    const int gcol = n0 + wn * WN + cl;
+    __syncthreads();
+    constexpr int CPL = 8;                 // columns per lane: 16 bytes of a 16-bit output row
+    constexpr int LPRW = BN / CPL;         // lanes per row
+    constexpr int RPI = 256 / LPRW;        // rows per pass of the block
+    const int cl = (tid % LPRW) * CPL, rl = tid / LPRW;
+    const int gcol = n0 + cl;
 #pragma unroll
-    for (int it = 0; it < WM / RPI; ++it) {
+    for (int it = 0; it < BM / RPI; ++it) {
         const int row = it * RPI + rl;
-        const long grow = m0 + wm * WM + row;
+        const long grow = m0 + row;
         if (grow >= M || gcol >= N) continue;
-        float4 v = *reinterpret_cast<const float4 *>(ep + row * WN + cl);
-        float o[4] = {v.x, v.y, v.z, v.w};
-        if (gcol + 4 <= N && (N & 3) == 0) {
+        float o[CPL];
+        {
+            const float4 v0 = *reinterpret_cast<const float4 *>(ep + row * BN + cl);
+            const float4 v1 = *reinterpret_cast<const float4 *>(ep + row * BN + cl + 4);
+            o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+        }
+        if (gcol + CPL <= N && (N & 7) == 0) {
             if (bias) {
-                const float4 bv = *reinterpret_cast<const float4 *>(bias + gcol);
-                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+                float bv[CPL];
+                load_pack<float, CPL>(bias + gcol, bv);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) o[q] += bv[q];
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = apply_act(o[q], act);
+            for (int q = 0; q < CPL; ++q) o[q] = apply_act(o[q], act);
             if (res) {
-                float rv[4];
-                load_pack<T, 4>(res + grow * N + gcol, rv);
+                float rv[CPL];
+                load_pack<T, CPL>(res + grow * N + gcol, rv);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] += rv[q];
+                for (int q = 0; q < CPL; ++q) o[q] += rv[q];
             }
-            store_pack<TO, 4>(y + grow * N + gcol, o);
+            store_pack<TO, CPL>(y + grow * N + gcol, o);
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < CPL; ++q) {
                 if (gcol + q < N) {
                     float t = apply_act(o[q] + (bias ? bias[gcol + q] : 0.f), act);
                     if (res) t += Cvt<T>::to_f(res[grow * N + gcol + q]);
@@ -362,6 +371,10 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
     if (force_big || (big >= 2048 && k >= 1024)) {
         dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
         hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2, CONV>), grid, block, 0, s, (const T *)x,
+                           (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);
+    } else if (k <= 128) {  // 1-2 K steps: a 2-stage ring, no padded dummy steps
+        dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
+        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 64, 64, 1, CONV>), grid, block, 0, s, (const T *)x,
                            (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);
     } else {
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
