@@ -12,6 +12,7 @@ from tramba_amd import hip  # noqa: E402
 SHAPES = {  # name: (family, H, D, R)
     "enc0": ("raster", 96, 256, 8), "helix0": ("helix", 96, 256, 8), "enc1": ("raster", 48, 512, 16),
     "enc2": ("raster", 24, 1024, 32), "enc3": ("raster", 12, 2048, 64), "win1": ("window", 48, 512, 16),
+    "helix1": ("helix", 48, 512, 16), "helix2": ("helix", 24, 1024, 32), "dil2": ("dilation", 24, 1024, 32),
 }
 
 

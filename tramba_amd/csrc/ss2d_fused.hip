@@ -48,6 +48,7 @@ typedef __attribute__((ext_vector_type(16))) float acc16_t;
 constexpr int kTP = 32;  // positions per tile (one MFMA tile)
 
 __host__ __device__ inline int xdbl_group_stride(int r) { return (r + 2 + 3) & ~3; }
+inline double rg_bytes(int r) { return 4.0 * xdbl_group_stride(r); }
 
 // split 8 floats into bf16 hi (+ bf16 lo = rounding residual) fragments
 template <bool SPLIT>
@@ -66,6 +67,55 @@ __device__ __forceinline__ acc16_t mfma_bf16(frag8_t a, frag8_t b, acc16_t c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ---- buffer (SRD) accessors.  Every gather / store of the scan goes through a wave-uniform buffer
+// descriptor + a 32-bit per-lane BYTE offset: no 64-bit address arithmetic in the VALU (the kernels are
+// VALU-bound), row strides ride in the scalar `soffset`, and an element outside the tensor is given an
+// out-of-range vector offset which the hardware range check drops: no branches around the stores.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+constexpr unsigned kOutOfRange = 0x80000000u;  // >= any num_records the host admits: access dropped
+
+template <typename T> __device__ __forceinline__ float buf_load_elem(__amdgpu_buffer_rsrc_t r, unsigned voff);
+template <> __device__ __forceinline__ float buf_load_elem<float>(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+template <> __device__ __forceinline__ float buf_load_elem<__hip_bfloat16>(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    const unsigned short v = __builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0);
+    return __builtin_bit_cast(float, (unsigned)v << 16);
+}
+template <> __device__ __forceinline__ float buf_load_elem<__half>(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    const unsigned short v = __builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0);
+    return (float)__builtin_bit_cast(_Float16, v);
+}
+template <typename TY>
+__device__ __forceinline__ void buf_store_elem(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v);
+template <>
+__device__ __forceinline__ void buf_store_elem<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+template <>
+__device__ __forceinline__ void buf_store_elem<__hip_bfloat16>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff,
+                                                               float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, __float2bfloat16(v)), r, voff, soff, 0);
+}
+template <>
+__device__ __forceinline__ void buf_store_elem<__half>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), r, voff, soff, 0);
+}
+
 template <int NK>
 struct TileOps {
     float araw[NK][8];  // x_dbl row of MY position (lane & 31), ranks 16kk + 8hi .. +7
@@ -73,145 +123,140 @@ struct TileOps {
     float u[16];        // x of my 16 (position, channel) elements
 };
 
-template <typename T, typename TY, int NK, bool SPLIT>
-__global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
-    const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
-    const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
-    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W)
-{
-    __shared__ float agg[2][kMaxW][2][kTP];
-    __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];  // per wave: pixel idx, B, C per position
+// One wave's view of a (direction, 32-channel tile): loop-invariant operands + the per-tile steps shared by
+// the chained and the wave-segment kernels.  Lane (r32, hi): channel r32 of the tile; as a POSITION owner
+// (gathers, staging) position r32; as an ELEMENT owner the 16 positions POS(r) = (r&3) + 8(r>>2) + 4hi.
+//
+// Arithmetic per element (the kernels are VALU-bound, so every instruction here was counted):
+//   x' = (dt_raw + bias) * log2(e)   straight out of the MFMA: log2(e) is folded into the dt_w fragments and
+//                                    the accumulator starts at bias * log2(e)
+//   t  = max(x', log2(1 + exp2(min(x', 86))))          = softplus(dt_raw + bias) * log2(e)
+//        (the reference's threshold form, x > 20 -> x, equals this to below fp32 resolution)
+//   a  = exp2(t * A)                                   = exp(dt * A)
+//   bb = t * (B*ln2 * u)                               = dt * B * u      (ln2 folded into the staged B)
+// i.e. 3 transcendentals + min, max and 4 packed-able mul/add per element.  Positions past the end of the
+// sequence start the accumulator at -1e30 instead: t = 0 exactly, hence a = 1, bb = 0 (the identity).
+template <typename T, int NK, bool SPLIT>
+struct ScanWave {
+    frag8_t wh[NK], wl[NK];  // dt_w[k][channel][16kk + 8hi + j] * log2(e), bf16 hi (+ lo residual)
+    float bias2, An, Dk;
+    unsigned roff[NK];       // byte offset of my 8-rank run inside an x_dbl group (clamped, see fetch)
+    unsigned bcoff;          // byte offset of (B, C) inside the group
+    unsigned cx;             // byte offset of my channel inside an x row
+    unsigned xrow, prow;     // bytes per x row / per x_dbl row
+    int hi, r32, R;
+    bool rvec;               // every 8-rank run is whole and 16-byte aligned
+    float *st;               // this wave's LDS stage: [0] x-row byte offsets, [1] B*ln2, [2] C per position
 
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r32 = lane & 31, hi = lane >> 5;
-    const int k = blockIdx.y, b = blockIdx.z;
-    const int c = blockIdx.x * kTP + r32;
-    const bool cok = c < D;
-    const int cc_ = cok ? c : D - 1;
-    const int RG = xdbl_group_stride(R);
-    const int PC = K * RG;
-    const bool rvec = (R & 7) == 0;  // every 8-rank run is whole and 16-byte aligned
-
-    // loop-invariant B operand: dt_w[k][channel][16kk + 8hi + j]
-    frag8_t wh[NK], wl[NK];
+    __device__ __forceinline__ void init(const float *dt_w, const float *dt_bias, const float *Aneg, const float *Ds,
+                                         long kd, int R_, int RG, int PC, int D, int lane, int cc_, float *st_)
     {
-        const float *wrow = dt_w + ((long)k * D + cc_) * R;
+        r32 = lane & 31;
+        hi = lane >> 5;
+        R = R_;
+        st = st_;
+        rvec = (R & 7) == 0;
+        const float *wrow = dt_w + kd * R;
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
             float t[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = kk * 16 + hi * 8 + j;
-                t[j] = r < R ? wrow[r] : 0.f;
+                t[j] = r < R ? wrow[r] * 1.44269504088896f : 0.f;
             }
             pack_frag<SPLIT>(t, wh[kk], wl[kk]);
-        }
-    }
-    const float bias = dt_bias[(long)k * D + cc_];
-    const float A2 = Aneg[(long)k * D + cc_] * 1.44269504088896f;  // A * log2(e): a = exp2(dt * A2)
-    const float Dk = Ds[(long)k * D + cc_];
-
-    // wave-uniform bases (SGPR) + 32-bit per-lane element offsets (host guarantees < 2^31 elements)
-    const T *xb = x + (long)b * L * D;
-    const float *pb = xdbl + (long)b * L * PC + (long)k * RG;
-    const int32_t *tk = table + (long)k * L;
-    TY *yb = ys + ((long)b * K + k) * L * D;
-    float *st = &stage[wv][0][0];
-
-    const int span = W * kTP;
-    const int nsuper = (L + span - 1) / span;
-
-    auto load_idx = [&](int s) -> int {  // unconditional (clamped): predicated loads serialise the pipeline
-        const int l = s * span + wv * kTP + r32;
-        return tk[l < L ? l : L - 1];
-    };
-    auto load_rows = [&](int pix, TileOps<NK> &o) {
-        const float *row = pb + (unsigned)(pix * PC);
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
+            // ranks >= R meet zero dt_w fragments, so those lanes may read any finite in-row floats:
+            // clamp the offset instead of predicating the load (RG >= R + 2 >= 10 when rvec)
             const int r0 = kk * 16 + hi * 8;
-            if (rvec) {
-                // ranks >= R meet zero dt_w fragments, so those lanes may read any finite in-row
-                // floats: clamp the offset instead of branching (RG >= R + 2 >= 10)
-                const int rr = r0 < R ? r0 : RG - 8;
-                const float4 v0 = *reinterpret_cast<const float4 *>(row + rr);
-                const float4 v1 = *reinterpret_cast<const float4 *>(row + rr + 4);
-                o.araw[kk][0] = v0.x; o.araw[kk][1] = v0.y; o.araw[kk][2] = v0.z; o.araw[kk][3] = v0.w;
-                o.araw[kk][4] = v1.x; o.araw[kk][5] = v1.y; o.araw[kk][6] = v1.z; o.araw[kk][7] = v1.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o.araw[kk][j] = r0 + j < R ? row[r0 + j] : 0.f;
-            }
+            roff[kk] = (unsigned)((r0 < R ? r0 : RG - 8) * 4);
         }
-        o.bv = row[R];
-        o.cv = row[R + 1];
-    };
-    // my 16 elements sit at positions POS(r) = (r&3) + 8(r>>2) + 4hi of the tile
-    auto read_stage4 = [&](int which, float (&out)[16]) {
+        bias2 = dt_bias[kd] * 1.44269504088896f;
+        An = Aneg[kd];
+        Dk = Ds[kd];
+        bcoff = (unsigned)(R * 4);
+        cx = (unsigned)(cc_ * (int)sizeof(T));
+        xrow = (unsigned)(D * (int)sizeof(T));
+        prow = (unsigned)(PC * 4);
+    }
+
+    // my 16 elements' values of a per-position array
+    __device__ __forceinline__ void read_stage4(int which, float (&out)[16]) const
+    {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 v = *reinterpret_cast<const float4 *>(st + which * kTP + 8 * g + 4 * hi);
             out[4 * g + 0] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
         }
-    };
-    auto load_u = [&](const float (&pixf)[16], TileOps<NK> &o) {
+    }
+
+    // issue every gather of one tile; idxv = pixel index of MY position in that tile (always a valid pixel)
+    __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rp, int idxv,
+                                          TileOps<NK> &o) const
+    {
+        if (hi == 0) st[r32] = __builtin_bit_cast(float, (unsigned)idxv * xrow);
+        __builtin_amdgcn_wave_barrier();
+        float xo[16];
+        read_stage4(0, xo);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned pr = (unsigned)idxv * prow;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pix = __builtin_bit_cast(int, pixf[r]);
-            o.u[r] = Cvt<T>::to_f(xb[(unsigned)(pix * D + cc_)]);
+        for (int kk = 0; kk < NK; ++kk) {
+            if (rvec) {
+                // (bit_cast the WHOLE vector: hipcc miscompiles __builtin_bit_cast(float, vec[j]) to element 0)
+                const v4f v0 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rp, pr + roff[kk], 0, 0));
+                const v4f v1 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rp, pr + roff[kk] + 16, 0, 0));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o.araw[kk][j] = v0[j];
+                    o.araw[kk][4 + j] = v1[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = kk * 16 + hi * 8 + j;  // clamped: a rank >= R meets a zero weight
+                    o.araw[kk][j] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(rp, pr + (unsigned)((r < R ? r : R - 1) * 4), 0, 0));
+                }
+            }
         }
-    };
-
-    // Gather pipeline: tile s computes while tiles s+1 (and s+2 when registers allow, NK <= 2) are in
-    // flight.  The operand stages form a STATIC ring (tile t lives in ops[t % NS]) and the tile loop is
-    // unrolled by NS: rotating registers that have loads in flight, or predicating the loads, makes
-    // hipcc wait vmcnt(0) every tile.  Loads past the end of the sequence are clamped, not skipped.
-    constexpr int AHEAD = NK <= 2 ? 2 : 1;
-    constexpr int NS = AHEAD + 1;
-    TileOps<NK> ops[NS];
-    float pixf[16];
-    auto fetch = [&](int idxv, TileOps<NK> &o) {  // idxv: pixel index of MY position in that tile
-        if (hi == 0) st[r32] = __builtin_bit_cast(float, idxv);
-        __builtin_amdgcn_wave_barrier();
-        read_stage4(0, pixf);
-        __builtin_amdgcn_wave_barrier();
-        load_rows(idxv, o);
-        load_u(pixf, o);
-    };
-    const int last = nsuper - 1;
+        if (rvec) {
+            const v2f bc = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rp, pr + bcoff, 0, 0));
+            o.bv = bc.x;
+            o.cv = bc.y;
+        } else {
+            o.bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, pr + bcoff, 0, 0));
+            o.cv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, pr + bcoff + 4, 0, 0));
+        }
 #pragma unroll
-    for (int t = 0; t < AHEAD; ++t) fetch(load_idx(t < last ? t : last), ops[t]);
-    int idx_ahead = load_idx(AHEAD < last ? AHEAD : last);   // index vector of tile s + AHEAD
+        for (int r = 0; r < 16; ++r) o.u[r] = buf_load_elem<T>(rx, __builtin_bit_cast(unsigned, xo[r]) + cx);
+    }
 
-    const bool cfull = blockIdx.x * kTP + kTP <= D;  // block-uniform: no channel masking needed
-    float carry = 0.f;
-    for (int s0 = 0; s0 < nsuper; s0 += NS) {
-#pragma unroll
-      for (int sti = 0; sti < NS; ++sti) {
-        const int s = s0 + sti;
-        if (s >= nsuper) break;  // block-uniform
-        TileOps<NK> &cur = ops[sti];
-        const int l0 = s * span + wv * kTP;
-        // per-position scalars of THIS tile
+    // publish B*ln2 and C of the current tile's positions, read back my 16 of each
+    __device__ __forceinline__ void stage_bc(const TileOps<NK> &cur, float (&Bp)[16], float (&Cp)[16], bool want_c) const
+    {
         if (hi == 0) {
-            st[kTP + r32] = cur.bv;
+            st[kTP + r32] = cur.bv * 0.693147180559945f;
             st[2 * kTP + r32] = cur.cv;
         }
         __builtin_amdgcn_wave_barrier();
-        float Bp[16], Cp[16];
         read_stage4(1, Bp);
-        read_stage4(2, Cp);
-        {   // tile s + AHEAD goes into the stage tile s - 1 just vacated
-            fetch(idx_ahead, ops[(sti + AHEAD) % NS]);
-            const int sn = s + AHEAD + 1;
-            idx_ahead = load_idx(sn < last ? sn : last);
-        }
+        if (want_c) read_stage4(2, Cp);
+    }
 
-        // ---- dt_proj on the matrix core
+    // dt_proj on the matrix core + per-element decay / input terms.  nvalid = positions of this tile
+    // inside the sequence (>= 32: all of them)
+    __device__ __forceinline__ void terms(const TileOps<NK> &cur, const float (&Bp)[16], int nvalid, float (&a)[16],
+                                          float (&bb)[16]) const
+    {
         acc16_t acc;
+        if (nvalid < kTP) {  // wave-uniform: only the last tile of a sequence / segment
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = (r & 3) + 8 * (r >> 2) + 4 * hi < nvalid ? bias2 : -1.0e30f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bias2;
+        }
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
             frag8_t ah, al;
@@ -222,47 +267,156 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
                 acc = mfma_bf16(al, wh[kk], acc);
             }
         }
-        // ---- per-element terms
-        // softplus(x) = ln2 * log2(1 + exp2(x*log2e)), evaluated on min(x, 60) and max-ed with x: equal to
-        // the reference's thresholded form (x > 20 -> x) to below fp32 resolution, 3 transcendentals
-        // per element in total with a = exp2(dt * A*log2e).
-        const bool ragged = l0 + kTP > L;  // wave-uniform: only the last tile of a sequence
-        float a[16], bb[16];
+        const v2f one = {1.f, 1.f}, av = {An, An};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float xr = acc[r] + bias;
-            const float z = __builtin_amdgcn_exp2f(fminf(xr, 60.f) * 1.44269504088896f);
-            float dt = fmaxf(xr, __builtin_amdgcn_logf(1.f + z) * 0.693147180559945f);
-            if (ragged && l0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) dt = 0.f;
-            a[r] = __builtin_amdgcn_exp2f(dt * A2);
-            bb[r] = dt * (Bp[r] * cur.u[r]);
+        for (int r = 0; r < 16; r += 2) {
+            const v2f xr = {acc[r], acc[r + 1]};
+            v2f z = {__builtin_amdgcn_exp2f(fminf(xr.x, 86.f)), __builtin_amdgcn_exp2f(fminf(xr.y, 86.f))};
+            z = z + one;
+            const v2f t = {fmaxf(xr.x, __builtin_amdgcn_logf(z.x)), fmaxf(xr.y, __builtin_amdgcn_logf(z.y))};
+            const v2f e = t * av;
+            a[r] = __builtin_amdgcn_exp2f(e.x);
+            a[r + 1] = __builtin_amdgcn_exp2f(e.y);
+            const v2f bu = v2f{Bp[r], Bp[r + 1]} * v2f{cur.u[r], cur.u[r + 1]};
+            const v2f bt = t * bu;
+            bb[r] = bt.x;
+            bb[r + 1] = bt.y;
         }
-        // ---- 4 runs of 4 consecutive positions per lane; runs of the two half-waves interleave
+    }
+
+    // (decay, state) prefix entering each of my 4 runs, relative to the tile start, and the tile aggregate.
+    // Runs of 4 consecutive positions; runs of the two half-waves interleave (lower half first).
+    __device__ __forceinline__ void prefix(const float (&a)[16], const float (&bb)[16], float (&preA)[4],
+                                           float (&preH)[4], float &tA, float &tH) const
+    {
         float sa[4], sh[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float pa = 1.f, ph = 0.f;
+            float pa = a[4 * g], ph = bb[4 * g];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 1; q < 4; ++q) {
                 ph = fmaf(a[4 * g + q], ph, bb[4 * g + q]);
                 pa *= a[4 * g + q];
             }
             sa[g] = pa;
             sh[g] = ph;
         }
-        float preA[4], preH[4];   // prefix (relative to the tile start) entering MY run g
-        float runA = 1.f, runH = 0.f;
+        tA = 1.f;
+        tH = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float oa = __shfl_xor(sa[g], 32, 64), oh = __shfl_xor(sh[g], 32, 64);
             const float ea = hi ? oa : sa[g], eh = hi ? oh : sh[g];   // run 2g   (lower half-wave)
             const float fa = hi ? sa[g] : oa, fh = hi ? sh[g] : oh;   // run 2g+1 (upper half-wave)
-            const float midH = fmaf(ea, runH, eh), midA = ea * runA;
-            preA[g] = hi ? midA : runA;
-            preH[g] = hi ? midH : runH;
-            runH = fmaf(fa, midH, fh);
-            runA = fa * midA;
+            const float midH = fmaf(ea, tH, eh), midA = ea * tA;
+            preA[g] = hi ? midA : tA;
+            preH[g] = hi ? midH : tH;
+            tH = fmaf(fa, midH, fh);
+            tA = fa * midA;
         }
+    }
+
+    // replay my 16 steps from the state entering the tile and stream y = C h + D u out.
+    // yv: byte offset of (first position of the tile + 4hi, my channel); row strides ride in the scalar
+    // soffset.  MASKED (ragged tile / channel edge, wave-uniform choice): an element outside the tensor gets
+    // the out-of-range VECTOR offset, which the range check drops whatever the scalar offset is.
+    template <typename TY, bool MASKED>
+    __device__ __forceinline__ void replay(__amdgpu_buffer_rsrc_t ry, unsigned yv, unsigned yrow, const TileOps<NK> &cur,
+                                           const float (&a)[16], const float (&bb)[16], const float (&Cp)[16],
+                                           const float (&preA)[4], const float (&preH)[4], float hin, bool cok,
+                                           int nvalid) const
+    {
+        const v2f dv = {Dk, Dk};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float hh = fmaf(preA[g], hin, preH[g]);
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+                const int r = 4 * g + q;
+                const float h0 = fmaf(a[r], hh, bb[r]);
+                const float h1 = fmaf(a[r + 1], h0, bb[r + 1]);
+                hh = h1;
+                const v2f o = v2f{Cp[r], Cp[r + 1]} * v2f{h0, h1} + dv * v2f{cur.u[r], cur.u[r + 1]};
+                const int p0 = q + 8 * g + 4 * hi;  // position of element r inside the tile
+                const unsigned v0 = !MASKED || (cok && p0 < nvalid) ? yv : kOutOfRange;
+                const unsigned v1 = !MASKED || (cok && p0 + 1 < nvalid) ? yv : kOutOfRange;
+                buf_store_elem<TY>(ry, v0, (unsigned)(q + 8 * g) * yrow, o.x);
+                buf_store_elem<TY>(ry, v1, (unsigned)(q + 1 + 8 * g) * yrow, o.y);
+            }
+        }
+    }
+};
+
+template <typename T, typename TY, int NK, bool SPLIT>
+__global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
+    const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
+    const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
+    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W)
+{
+    __shared__ float agg[2][kMaxW][2][kTP];
+    __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int c = blockIdx.x * kTP + r32;
+    const bool cok = c < D;
+    const int cc_ = cok ? c : D - 1;
+    const int RG = xdbl_group_stride(R);
+    const int PC = K * RG;
+
+    ScanWave<T, NK, SPLIT> w;
+    w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + cc_, R, RG, PC, D, lane, cc_, &stage[wv][0][0]);
+
+    // wave-uniform descriptors (host guarantees every extent < 2^31 bytes)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
+    const __amdgpu_buffer_rsrc_t rp =
+        make_rsrc(xdbl + (long)b * L * PC + (long)k * RG, ((unsigned)(L - 1) * PC + RG) * 4u);
+    const unsigned yrow = (unsigned)D * (unsigned)sizeof(TY);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(ys + ((long)b * K + k) * L * D, (unsigned)L * yrow);
+    const int32_t *tk = table + (long)k * L;
+
+    const int span = W * kTP;
+    const int nsuper = (L + span - 1) / span;
+    const int last = nsuper - 1;
+
+    auto load_idx = [&](int s) -> int {  // unconditional (clamped): predicated loads serialise the pipeline
+        const int l = (s < last ? s : last) * span + wv * kTP + r32;
+        return tk[l < L ? l : L - 1];
+    };
+
+    // Gather pipeline: tile s computes while tiles s+1 (and s+2 when registers allow, NK <= 2) are in
+    // flight.  The operand stages form a STATIC ring (tile t lives in ops[t % NS]) and the tile loop is
+    // unrolled by NS: rotating registers that have loads in flight, or predicating the loads, makes
+    // hipcc wait vmcnt(0) every tile.  Loads past the end of the sequence are clamped, not skipped.
+    constexpr int AHEAD = NK <= 2 ? 2 : 1;
+    constexpr int NS = AHEAD + 1;
+    TileOps<NK> ops[NS];
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) w.fetch(rx, rp, load_idx(t), ops[t]);
+    int idx_ahead = load_idx(AHEAD);   // index vector of tile s + AHEAD
+
+    const bool cfull = blockIdx.x * kTP + kTP <= D;  // block-uniform: no channel masking needed
+    float carry = 0.f;
+    for (int s0 = 0; s0 < nsuper; s0 += NS) {
+#pragma unroll
+      for (int sti = 0; sti < NS; ++sti) {
+        const int s = s0 + sti;
+        if (s >= nsuper) break;  // block-uniform
+        TileOps<NK> &cur = ops[sti];
+        const int l0 = s * span + wv * kTP;
+        float Bp[16], Cp[16];
+        w.stage_bc(cur, Bp, Cp, true);
+        // tile s + AHEAD goes into the stage tile s - 1 just vacated
+        w.fetch(rx, rp, idx_ahead, ops[(sti + AHEAD) % NS]);
+        idx_ahead = load_idx(s + AHEAD + 1);
+
+        float a[16], bb[16], preA[4], preH[4], runA, runH;
+        w.terms(cur, Bp, L - l0, a, bb);
+        w.prefix(a, bb, preA, preH, runA, runH);
+
+        // ---- one barrier per super-chunk: fold the preceding waves' (decay, state) pairs
         const int buf = s & 1;
         if (hi == 0) {
             agg[buf][wv][0][r32] = runA;
@@ -275,24 +429,11 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
             h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
         }
         carry = h;
-        // ---- replay and stream out
-        const bool full = cfull && l0 + kTP <= L;  // wave-uniform: ragged only at the sequence / channel edge
-        unsigned yoff = (unsigned)((l0 + 4 * hi) * D + cc_);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float hh = fmaf(preA[g], hin, preH[g]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 4 * g + q;
-                hh = fmaf(a[r], hh, bb[r]);
-                const TY out = Cvt<TY>::from_f(fmaf(Cp[r], hh, Dk * cur.u[r]));
-                const unsigned off = yoff + (unsigned)((q + 8 * g) * D);
-                if (full) {
-                    yb[off] = out;
-                } else if (cok && l0 + q + 8 * g + 4 * hi < L) {
-                    yb[off] = out;
-                }
-            }
+        const unsigned yv = (unsigned)((l0 + 4 * hi) * D + cc_) * (unsigned)sizeof(TY);
+        if (cfull && l0 + kTP <= L) {  // wave-uniform: ragged only at the sequence / channel edge
+            w.template replay<TY, false>(ry, yv, yrow, cur, a, bb, Cp, preA, preH, hin, true, kTP);
+        } else {
+            w.template replay<TY, true>(ry, yv, yrow, cur, a, bb, Cp, preA, preH, hin, cok, L - l0);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -351,7 +492,7 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
     const float *__restrict__ Ds, TY *__restrict__ ys, float2 *__restrict__ agg, const float *__restrict__ carry,
     int L, int D, int K, int R, int CT, int NT, int NSEG, long nwaves)
 {
-    __shared__ __attribute__((aligned(16))) float stage[4][3][kTP];  // per wave: pixel idx, B, C per position
+    __shared__ __attribute__((aligned(16))) float stage[4][3][kTP];
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -369,31 +510,16 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
     const int cc_ = cok ? c : D - 1;
     const int RG = xdbl_group_stride(R);
     const int PC = K * RG;
-    const bool rvec = (R & 7) == 0;
 
-    frag8_t wh[NK], wl[NK];
-    {
-        const float *wrow = dt_w + ((long)k * D + cc_) * R;
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-            float t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = kk * 16 + hi * 8 + j;
-                t[j] = r < R ? wrow[r] : 0.f;
-            }
-            pack_frag<SPLIT>(t, wh[kk], wl[kk]);
-        }
-    }
-    const float bias = dt_bias[(long)k * D + cc_];
-    const float A2 = Aneg[(long)k * D + cc_] * 1.44269504088896f;
-    const float Dk = Ds[(long)k * D + cc_];
+    ScanWave<T, NK, SPLIT> w;
+    w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + cc_, R, RG, PC, D, lane, cc_, &stage[wv][0][0]);
 
-    const T *xb = x + (long)b * L * D;
-    const float *pb = xdbl + (long)b * L * PC + (long)k * RG;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
+    const __amdgpu_buffer_rsrc_t rp =
+        make_rsrc(xdbl + (long)b * L * PC + (long)k * RG, ((unsigned)(L - 1) * PC + RG) * 4u);
+    const unsigned yrow = (unsigned)D * (unsigned)sizeof(TY);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(ys + ((long)b * K + k) * L * D, (unsigned)L * yrow);
     const int32_t *tk = table + (long)k * L;
-    TY *yb = ys + ((long)b * K + k) * L * D;
-    float *st = &stage[wv][0][0];
 
     const int t0 = sgm * NT;                                  // first tile of my segment
     const int lend = (t0 + NT) * kTP < L ? (t0 + NT) * kTP : L;  // my segment is [t0*32, lend)
@@ -403,53 +529,11 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
         const int l = (t < tlast ? t : tlast) * kTP + r32;
         return tk[l < L ? l : L - 1];
     };
-    auto load_rows = [&](int pix, TileOps<NK> &o) {
-        const float *row = pb + (unsigned)(pix * PC);
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-            const int r0 = kk * 16 + hi * 8;
-            if (rvec) {
-                const int rr = r0 < R ? r0 : RG - 8;
-                const float4 v0 = *reinterpret_cast<const float4 *>(row + rr);
-                const float4 v1 = *reinterpret_cast<const float4 *>(row + rr + 4);
-                o.araw[kk][0] = v0.x; o.araw[kk][1] = v0.y; o.araw[kk][2] = v0.z; o.araw[kk][3] = v0.w;
-                o.araw[kk][4] = v1.x; o.araw[kk][5] = v1.y; o.araw[kk][6] = v1.z; o.araw[kk][7] = v1.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o.araw[kk][j] = r0 + j < R ? row[r0 + j] : 0.f;
-            }
-        }
-        o.bv = row[R];
-        o.cv = row[R + 1];
-    };
-    auto read_stage4 = [&](int which, float (&out)[16]) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4 *>(st + which * kTP + 8 * g + 4 * hi);
-            out[4 * g + 0] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
-        }
-    };
-    auto load_u = [&](const float (&pixf)[16], TileOps<NK> &o) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pix = __builtin_bit_cast(int, pixf[r]);
-            o.u[r] = Cvt<T>::to_f(xb[(unsigned)(pix * D + cc_)]);
-        }
-    };
     constexpr int AHEAD = NK <= 2 ? 2 : 1;
     constexpr int NS = AHEAD + 1;
     TileOps<NK> ops[NS];
-    float pixf[16];
-    auto fetch = [&](int idxv, TileOps<NK> &o) {
-        if (hi == 0) st[r32] = __builtin_bit_cast(float, idxv);
-        __builtin_amdgcn_wave_barrier();
-        read_stage4(0, pixf);
-        __builtin_amdgcn_wave_barrier();
-        load_rows(idxv, o);
-        load_u(pixf, o);
-    };
 #pragma unroll
-    for (int t = 0; t < AHEAD; ++t) fetch(load_idx(t0 + t), ops[t]);
+    for (int t = 0; t < AHEAD; ++t) w.fetch(rx, rp, load_idx(t0 + t), ops[t]);
     int idx_ahead = load_idx(t0 + AHEAD);
 
     float runA = 1.f, runH = 0.f;  // PASS 0: aggregate of the segment so far
@@ -464,87 +548,23 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
         const int t = t0 + i0 + sti;
         TileOps<NK> &cur = ops[sti];
         const int l0 = t * kTP;
-        if (hi == 0) {
-            st[kTP + r32] = cur.bv;
-            st[2 * kTP + r32] = cur.cv;
-        }
-        __builtin_amdgcn_wave_barrier();
         float Bp[16], Cp[16];
-        read_stage4(1, Bp);
-        if (PASS == 1) read_stage4(2, Cp);
-        fetch(idx_ahead, ops[(sti + AHEAD) % NS]);
+        w.stage_bc(cur, Bp, Cp, PASS == 1);
+        w.fetch(rx, rp, idx_ahead, ops[(sti + AHEAD) % NS]);
         idx_ahead = load_idx(t + AHEAD + 1);
 
-        acc16_t acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-            frag8_t ah, al;
-            pack_frag<SPLIT>(cur.araw[kk], ah, al);
-            acc = mfma_bf16(ah, wh[kk], acc);
-            if (SPLIT) {
-                acc = mfma_bf16(ah, wl[kk], acc);
-                acc = mfma_bf16(al, wh[kk], acc);
-            }
-        }
-        const bool ragged = l0 + kTP > lend;  // wave-uniform: segment / sequence end inside or before this tile
-        float a[16], bb[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float xr = acc[r] + bias;
-            const float z = __builtin_amdgcn_exp2f(fminf(xr, 60.f) * 1.44269504088896f);
-            float dt = fmaxf(xr, __builtin_amdgcn_logf(1.f + z) * 0.693147180559945f);
-            if (ragged && l0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= lend) dt = 0.f;
-            a[r] = __builtin_amdgcn_exp2f(dt * A2);
-            bb[r] = dt * (Bp[r] * cur.u[r]);
-        }
-        float sa[4], sh[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float pa = 1.f, ph = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ph = fmaf(a[4 * g + q], ph, bb[4 * g + q]);
-                pa *= a[4 * g + q];
-            }
-            sa[g] = pa;
-            sh[g] = ph;
-        }
-        float preA[4], preH[4];
-        float tA = 1.f, tH = 0.f;  // aggregate of this tile
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float oa = __shfl_xor(sa[g], 32, 64), oh = __shfl_xor(sh[g], 32, 64);
-            const float ea = hi ? oa : sa[g], eh = hi ? oh : sh[g];
-            const float fa = hi ? sa[g] : oa, fh = hi ? sh[g] : oh;
-            const float midH = fmaf(ea, tH, eh), midA = ea * tA;
-            preA[g] = hi ? midA : tA;
-            preH[g] = hi ? midH : tH;
-            tH = fmaf(fa, midH, fh);
-            tA = fa * midA;
-        }
+        float a[16], bb[16], preA[4], preH[4], tA, tH;
+        w.terms(cur, Bp, lend - l0, a, bb);   // positions at or past the segment end are the identity
+        w.prefix(a, bb, preA, preH, tA, tH);
         if (PASS == 0) {
             runH = fmaf(tA, runH, tH);
             runA *= tA;
         } else {
-            const bool full = cfull && l0 + kTP <= lend;
-            unsigned yoff = (unsigned)((l0 + 4 * hi) * D + cc_);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float hh = fmaf(preA[g], hin, preH[g]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = 4 * g + q;
-                    hh = fmaf(a[r], hh, bb[r]);
-                    const TY out = Cvt<TY>::from_f(fmaf(Cp[r], hh, Dk * cur.u[r]));
-                    const unsigned off = yoff + (unsigned)((q + 8 * g) * D);
-                    if (full) {
-                        yb[off] = out;
-                    } else if (cok && l0 + q + 8 * g + 4 * hi < lend) {
-                        yb[off] = out;
-                    }
-                }
+            const unsigned yv = (unsigned)((l0 + 4 * hi) * D + cc_) * (unsigned)sizeof(TY);
+            if (cfull && l0 + kTP <= lend) {  // wave-uniform
+                w.template replay<TY, false>(ry, yv, yrow, cur, a, bb, Cp, preA, preH, hin, true, kTP);
+            } else {
+                w.template replay<TY, true>(ry, yv, yrow, cur, a, bb, Cp, preA, preH, hin, cok, lend - l0);
             }
             hin = fmaf(tA, hin, tH);
         }
@@ -644,6 +664,9 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     TRAMBA_CHECK(ys_dtype == TRAMBA_F32 || ys_dtype == dtype, "ss2d_scan_cl: ys must be f32 or the input dtype");
     TRAMBA_CHECK(aligned16(xdbl), "ss2d_scan_cl: xdbl must be 16-byte aligned");
     TRAMBA_CHECK((double)batch * k * l * (double)d < 2.0e9, "ss2d_scan_cl: tensor too large for this build");
+    // 32-bit byte offsets inside one image / one (b, k) sequence (buffer descriptors), incl. the padding tiles
+    TRAMBA_CHECK(((double)l + 1024.0) * d * 4.0 < 2147483648.0 && (double)l * k * rg_bytes(r) < 2147483648.0,
+                 "ss2d_scan_cl: L*D too large for 32-bit offsets");
     hipStream_t s = (hipStream_t)stream;
     const int nk = (r + 15) / 16;
     const int rg = xdbl_group_stride(r);
