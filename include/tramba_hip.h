@@ -118,8 +118,8 @@ int tramba_cross_merge(const void *ys, const int32_t *inv_ptr, const int32_t *in
 /* ------------------------------------------------------------------ fused SS2D core, channels-last */
 /* x:    (B, L, D)           dtype   -- conv+SiLU output, spatial order
  * xdbl: (B, L, K*RG)        f32     -- x_proj output in SPATIAL order: per group k
- *                                      [dt_0..dt_{R-1}, B, C, pad]   (d_state N = 1 only);
- *                                      RG = tramba_ss2d_group_stride(R) = (R+2) rounded up to 4
+ *                                      [dt_0..dt_{R-1}, 0-pad to R8, B, C, 0, 0]  (d_state N = 1 only);
+ *                                      R8 = R rounded up to 8, RG = tramba_ss2d_group_stride(R) = R8 + 4
  * table (K, L) int32 device; dt_w (K, D, R) f32; dt_bias (K*D) f32; A (K*D) f32 (= -exp(A_logs));
  * Ds (K*D) f32.   ys: (B, K, L, D) ys_dtype in SEQUENCE order.                                   */
 int tramba_ss2d_group_stride(int r);

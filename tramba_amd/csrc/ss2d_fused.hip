@@ -34,6 +34,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "norm.h"
 
@@ -47,7 +49,10 @@ typedef __attribute__((ext_vector_type(16))) float acc16_t;
 
 constexpr int kTP = 32;  // positions per tile (one MFMA tile)
 
-__host__ __device__ inline int xdbl_group_stride(int r) { return (r + 2 + 3) & ~3; }
+// x_dbl group of one direction: [dt ranks 0..R-1, zero pad to R8 = 8*ceil(R/8) | B, C, 2 pad] -- every 8-rank run
+// is a whole 16-byte-aligned pair of 16-byte loads and (B, C) one aligned 8-byte load, for any R.
+__host__ __device__ inline int xdbl_rank_pad(int r) { return (r + 7) & ~7; }
+__host__ __device__ inline int xdbl_group_stride(int r) { return xdbl_rank_pad(r) + 4; }
 inline double rg_bytes(int r) { return 4.0 * xdbl_group_stride(r); }
 
 // split 8 floats into bf16 hi (+ bf16 lo = rounding residual) fragments
@@ -82,20 +87,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
 }
 constexpr unsigned kOutOfRange = 0x80000000u;  // >= any num_records the host admits: access dropped
 
-template <typename T> __device__ __forceinline__ float buf_load_elem(__amdgpu_buffer_rsrc_t r, unsigned voff);
-template <> __device__ __forceinline__ float buf_load_elem<float>(__amdgpu_buffer_rsrc_t r, unsigned voff)
+template <typename T> struct RawOf { typedef unsigned short type; };
+template <> struct RawOf<float> { typedef unsigned type; };
+
+// An activation element is loaded as RAW bits and converted where it is consumed: a conversion written at the
+// load site makes hipcc wait for the just-issued gather (the whole memory latency, every tile).
+template <typename T> __device__ __forceinline__ typename RawOf<T>::type buf_load_raw(__amdgpu_buffer_rsrc_t r, unsigned voff);
+template <> __device__ __forceinline__ unsigned buf_load_raw<float>(__amdgpu_buffer_rsrc_t r, unsigned voff)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+    return __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
 }
-template <> __device__ __forceinline__ float buf_load_elem<__hip_bfloat16>(__amdgpu_buffer_rsrc_t r, unsigned voff)
+template <> __device__ __forceinline__ unsigned short buf_load_raw<__hip_bfloat16>(__amdgpu_buffer_rsrc_t r, unsigned voff)
 {
-    const unsigned short v = __builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0);
-    return __builtin_bit_cast(float, (unsigned)v << 16);
+    return __builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0);
 }
-template <> __device__ __forceinline__ float buf_load_elem<__half>(__amdgpu_buffer_rsrc_t r, unsigned voff)
+template <> __device__ __forceinline__ unsigned short buf_load_raw<__half>(__amdgpu_buffer_rsrc_t r, unsigned voff)
 {
-    const unsigned short v = __builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0);
-    return (float)__builtin_bit_cast(_Float16, v);
+    return __builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0);
+}
+template <typename T> __device__ __forceinline__ float raw_to_f(unsigned v);
+template <> __device__ __forceinline__ float raw_to_f<float>(unsigned v) { return __builtin_bit_cast(float, v); }
+template <> __device__ __forceinline__ float raw_to_f<__hip_bfloat16>(unsigned v)
+{
+    return __builtin_bit_cast(float, v << 16);   // v arrives zero-extended
+}
+template <> __device__ __forceinline__ float raw_to_f<__half>(unsigned v)
+{
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)v);
 }
 template <typename TY>
 __device__ __forceinline__ void buf_store_elem(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v);
@@ -116,11 +134,11 @@ __device__ __forceinline__ void buf_store_elem<__half>(__amdgpu_buffer_rsrc_t r,
     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), r, voff, soff, 0);
 }
 
-template <int NK>
+template <typename T, int NK>
 struct TileOps {
-    float araw[NK][8];  // x_dbl row of MY position (lane & 31), ranks 16kk + 8hi .. +7
-    float bv, cv;       // B, C of MY position
-    float u[16];        // x of my 16 (position, channel) elements
+    float araw[NK][8];               // x_dbl row of MY position (lane & 31), ranks 16kk + 8hi .. +7
+    float bv, cv;                    // B, C of MY position
+    typename RawOf<T>::type u[16];   // x of my 16 (position, channel) elements, raw bits
 };
 
 // One wave's view of a (direction, 32-channel tile): loop-invariant operands + the per-tile steps shared by
@@ -140,12 +158,11 @@ template <typename T, int NK, bool SPLIT>
 struct ScanWave {
     frag8_t wh[NK], wl[NK];  // dt_w[k][channel][16kk + 8hi + j] * log2(e), bf16 hi (+ lo residual)
     float bias2, An, Dk;
-    unsigned roff[NK];       // byte offset of my 8-rank run inside an x_dbl group (clamped, see fetch)
+    unsigned roff[NK];       // byte offset of my 8-rank run inside an x_dbl group
     unsigned bcoff;          // byte offset of (B, C) inside the group
     unsigned cx;             // byte offset of my channel inside an x row
     unsigned xrow, prow;     // bytes per x row / per x_dbl row
     int hi, r32, R;
-    bool rvec;               // every 8-rank run is whole and 16-byte aligned
     float *st;               // this wave's LDS stage: [0] x-row byte offsets, [1] B*ln2, [2] C per position
 
     __device__ __forceinline__ void init(const float *dt_w, const float *dt_bias, const float *Aneg, const float *Ds,
@@ -155,7 +172,7 @@ struct ScanWave {
         hi = lane >> 5;
         R = R_;
         st = st_;
-        rvec = (R & 7) == 0;
+        const int R8 = xdbl_rank_pad(R);
         const float *wrow = dt_w + kd * R;
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
@@ -166,15 +183,14 @@ struct ScanWave {
                 t[j] = r < R ? wrow[r] * 1.44269504088896f : 0.f;
             }
             pack_frag<SPLIT>(t, wh[kk], wl[kk]);
-            // ranks >= R meet zero dt_w fragments, so those lanes may read any finite in-row floats:
-            // clamp the offset instead of predicating the load (RG >= R + 2 >= 10 when rvec)
+            // a run past the padded ranks meets all-zero dt_w fragments: read run 0 instead of predicating
             const int r0 = kk * 16 + hi * 8;
-            roff[kk] = (unsigned)((r0 < R ? r0 : RG - 8) * 4);
+            roff[kk] = (unsigned)((r0 < R8 ? r0 : 0) * 4);
         }
         bias2 = dt_bias[kd] * 1.44269504088896f;
         An = Aneg[kd];
         Dk = Ds[kd];
-        bcoff = (unsigned)(R * 4);
+        bcoff = (unsigned)(R8 * 4);
         cx = (unsigned)(cc_ * (int)sizeof(T));
         xrow = (unsigned)(D * (int)sizeof(T));
         prow = (unsigned)(PC * 4);
@@ -192,7 +208,7 @@ struct ScanWave {
 
     // issue every gather of one tile; idxv = pixel index of MY position in that tile (always a valid pixel)
     __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rp, int idxv,
-                                          TileOps<NK> &o) const
+                                          TileOps<T, NK> &o) const
     {
         if (hi == 0) st[r32] = __builtin_bit_cast(float, (unsigned)idxv * xrow);
         __builtin_amdgcn_wave_barrier();
@@ -202,38 +218,24 @@ struct ScanWave {
         const unsigned pr = (unsigned)idxv * prow;
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
-            if (rvec) {
-                // (bit_cast the WHOLE vector: hipcc miscompiles __builtin_bit_cast(float, vec[j]) to element 0)
-                const v4f v0 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rp, pr + roff[kk], 0, 0));
-                const v4f v1 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rp, pr + roff[kk] + 16, 0, 0));
+            // (bit_cast the WHOLE vector: hipcc miscompiles __builtin_bit_cast(float, vec[j]) to element 0)
+            const v4f v0 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rp, pr + roff[kk], 0, 0));
+            const v4f v1 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rp, pr + roff[kk] + 16, 0, 0));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o.araw[kk][j] = v0[j];
-                    o.araw[kk][4 + j] = v1[j];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int r = kk * 16 + hi * 8 + j;  // clamped: a rank >= R meets a zero weight
-                    o.araw[kk][j] = __builtin_bit_cast(
-                        float, __builtin_amdgcn_raw_buffer_load_b32(rp, pr + (unsigned)((r < R ? r : R - 1) * 4), 0, 0));
-                }
+            for (int j = 0; j < 4; ++j) {
+                o.araw[kk][j] = v0[j];
+                o.araw[kk][4 + j] = v1[j];
             }
         }
-        if (rvec) {
-            const v2f bc = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rp, pr + bcoff, 0, 0));
-            o.bv = bc.x;
-            o.cv = bc.y;
-        } else {
-            o.bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, pr + bcoff, 0, 0));
-            o.cv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, pr + bcoff + 4, 0, 0));
-        }
+        const v2f bc = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rp, pr + bcoff, 0, 0));
+        o.bv = bc.x;
+        o.cv = bc.y;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o.u[r] = buf_load_elem<T>(rx, __builtin_bit_cast(unsigned, xo[r]) + cx);
+        for (int r = 0; r < 16; ++r) o.u[r] = buf_load_raw<T>(rx, __builtin_bit_cast(unsigned, xo[r]) + cx);
     }
 
     // publish B*ln2 and C of the current tile's positions, read back my 16 of each
-    __device__ __forceinline__ void stage_bc(const TileOps<NK> &cur, float (&Bp)[16], float (&Cp)[16], bool want_c) const
+    __device__ __forceinline__ void stage_bc(const TileOps<T, NK> &cur, float (&Bp)[16], float (&Cp)[16], bool want_c) const
     {
         if (hi == 0) {
             st[kTP + r32] = cur.bv * 0.693147180559945f;
@@ -246,9 +248,11 @@ struct ScanWave {
 
     // dt_proj on the matrix core + per-element decay / input terms.  nvalid = positions of this tile
     // inside the sequence (>= 32: all of them)
-    __device__ __forceinline__ void terms(const TileOps<NK> &cur, const float (&Bp)[16], int nvalid, float (&a)[16],
-                                          float (&bb)[16]) const
+    __device__ __forceinline__ void terms(const TileOps<T, NK> &cur, const float (&Bp)[16], int nvalid, float (&a)[16],
+                                          float (&bb)[16], float (&uf)[16]) const
     {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) uf[r] = raw_to_f<T>(cur.u[r]);
         acc16_t acc;
         if (nvalid < kTP) {  // wave-uniform: only the last tile of a sequence / segment
 #pragma unroll
@@ -277,7 +281,7 @@ struct ScanWave {
             const v2f e = t * av;
             a[r] = __builtin_amdgcn_exp2f(e.x);
             a[r + 1] = __builtin_amdgcn_exp2f(e.y);
-            const v2f bu = v2f{Bp[r], Bp[r + 1]} * v2f{cur.u[r], cur.u[r + 1]};
+            const v2f bu = v2f{Bp[r], Bp[r + 1]} * v2f{uf[r], uf[r + 1]};
             const v2f bt = t * bu;
             bb[r] = bt.x;
             bb[r + 1] = bt.y;
@@ -321,7 +325,7 @@ struct ScanWave {
     // soffset.  MASKED (ragged tile / channel edge, wave-uniform choice): an element outside the tensor gets
     // the out-of-range VECTOR offset, which the range check drops whatever the scalar offset is.
     template <typename TY, bool MASKED>
-    __device__ __forceinline__ void replay(__amdgpu_buffer_rsrc_t ry, unsigned yv, unsigned yrow, const TileOps<NK> &cur,
+    __device__ __forceinline__ void replay(__amdgpu_buffer_rsrc_t ry, unsigned yv, unsigned yrow, const float (&uf)[16],
                                            const float (&a)[16], const float (&bb)[16], const float (&Cp)[16],
                                            const float (&preA)[4], const float (&preH)[4], float hin, bool cok,
                                            int nvalid) const
@@ -336,7 +340,7 @@ struct ScanWave {
                 const float h0 = fmaf(a[r], hh, bb[r]);
                 const float h1 = fmaf(a[r + 1], h0, bb[r + 1]);
                 hh = h1;
-                const v2f o = v2f{Cp[r], Cp[r + 1]} * v2f{h0, h1} + dv * v2f{cur.u[r], cur.u[r + 1]};
+                const v2f o = v2f{Cp[r], Cp[r + 1]} * v2f{h0, h1} + dv * v2f{uf[r], uf[r + 1]};
                 const int p0 = q + 8 * g + 4 * hi;  // position of element r inside the tile
                 const unsigned v0 = !MASKED || (cok && p0 < nvalid) ? yv : kOutOfRange;
                 const unsigned v1 = !MASKED || (cok && p0 + 1 < nvalid) ? yv : kOutOfRange;
@@ -392,28 +396,48 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     // hipcc wait vmcnt(0) every tile.  Loads past the end of the sequence are clamped, not skipped.
     constexpr int AHEAD = NK <= 2 ? 2 : 1;
     constexpr int NS = AHEAD + 1;
-    TileOps<NK> ops[NS];
+    TileOps<T, NK> ops[NS];
+    // The index vectors run TWO further tiles ahead in their own static ring (idxr[t % NS]): vmcnt retires in
+    // order, so an index loaded in the same step as the gathers it follows, and needed one step later, would
+    // drain those gathers every tile and void the prefetch.
+    // Prologue: every index load is issued BEFORE the first gathers, so the loop is entered with the same
+    // in-flight picture the back-edge has (a younger index load at entry would make hipcc drain there).
+    int idxr[NS], idx0[AHEAD];
 #pragma unroll
-    for (int t = 0; t < AHEAD; ++t) w.fetch(rx, rp, load_idx(t), ops[t]);
-    int idx_ahead = load_idx(AHEAD);   // index vector of tile s + AHEAD
+    for (int t = 0; t < AHEAD; ++t) idx0[t] = load_idx(t);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) idxr[(AHEAD + t) % NS] = max(load_idx(AHEAD + t), 0);   // tiles AHEAD .. AHEAD + NS - 1
+    // (the max() is a no-op on a valid table; it makes the ring values ARRIVED at loop entry, so hipcc merges the
+    //  entry and back-edge wait states without a drain)
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) w.fetch(rx, rp, idx0[t], ops[t]);
 
+    // The per-super-chunk fold below always walks kMaxW aggregate rows (a loop with a run-time trip count
+    // inside the tile loop makes hipcc drain the gather pipeline at the loop head): rows of absent waves
+    // hold the identity (decay 1, state 0).
+    for (int i = threadIdx.x; i < 2 * kMaxW * kTP; i += blockDim.x) {
+        const int bq = i / kTP;   // buf * kMaxW + q
+        if (bq % kMaxW >= W) {
+            agg[bq / kMaxW][bq % kMaxW][0][i % kTP] = 1.f;
+            agg[bq / kMaxW][bq % kMaxW][1][i % kTP] = 0.f;
+        }
+    }
+    __syncthreads();
     const bool cfull = blockIdx.x * kTP + kTP <= D;  // block-uniform: no channel masking needed
     float carry = 0.f;
-    for (int s0 = 0; s0 < nsuper; s0 += NS) {
-#pragma unroll
-      for (int sti = 0; sti < NS; ++sti) {
-        const int s = s0 + sti;
-        if (s >= nsuper) break;  // block-uniform
-        TileOps<NK> &cur = ops[sti];
+    // one super-chunk; STI = ring slot of tile s (compile-time: the ring must be indexed statically)
+    auto step = [&](auto sti_c, int s) {
+        constexpr int sti = decltype(sti_c)::value;
+        TileOps<T, NK> &cur = ops[sti];
         const int l0 = s * span + wv * kTP;
         float Bp[16], Cp[16];
         w.stage_bc(cur, Bp, Cp, true);
         // tile s + AHEAD goes into the stage tile s - 1 just vacated
-        w.fetch(rx, rp, idx_ahead, ops[(sti + AHEAD) % NS]);
-        idx_ahead = load_idx(s + AHEAD + 1);
+        w.fetch(rx, rp, idxr[(sti + AHEAD) % NS], ops[(sti + AHEAD) % NS]);
+        idxr[(sti + AHEAD) % NS] = load_idx(s + AHEAD + NS);   // consumed NS steps from now
 
-        float a[16], bb[16], preA[4], preH[4], runA, runH;
-        w.terms(cur, Bp, L - l0, a, bb);
+        float a[16], bb[16], uf[16], preA[4], preH[4], runA, runH;
+        w.terms(cur, Bp, L - l0, a, bb, uf);
         w.prefix(a, bb, preA, preH, runA, runH);
 
         // ---- one barrier per super-chunk: fold the preceding waves' (decay, state) pairs
@@ -424,19 +448,31 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         }
         __syncthreads();
         float h = carry, hin = carry;
-        for (int q = 0; q < W; ++q) {
+#pragma unroll
+        for (int q = 0; q < kMaxW; ++q) {   // fixed trip count: rows q >= W hold the identity (see above)
             if (q == wv) hin = h;
             h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
         }
         carry = h;
         const unsigned yv = (unsigned)((l0 + 4 * hi) * D + cc_) * (unsigned)sizeof(TY);
         if (cfull && l0 + kTP <= L) {  // wave-uniform: ragged only at the sequence / channel edge
-            w.template replay<TY, false>(ry, yv, yrow, cur, a, bb, Cp, preA, preH, hin, true, kTP);
+            w.template replay<TY, false>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, true, kTP);
         } else {
-            w.template replay<TY, true>(ry, yv, yrow, cur, a, bb, Cp, preA, preH, hin, cok, L - l0);
+            w.template replay<TY, true>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, cok, L - l0);
         }
         __builtin_amdgcn_wave_barrier();
-      }
+    };
+    // Whole ring trips in the loop, the 0..NS-1 remaining super-chunks after it: an exit from the MIDDLE of the
+    // unrolled body (a `break`) makes hipcc drain every outstanding gather at the loop head.
+    int s0 = 0;
+    for (; s0 + NS <= nsuper; s0 += NS) {
+        step(std::integral_constant<int, 0>{}, s0);
+        step(std::integral_constant<int, 1>{}, s0 + 1);
+        if constexpr (NS > 2) step(std::integral_constant<int, 2>{}, s0 + 2);
+    }
+    if (s0 < nsuper) step(std::integral_constant<int, 0>{}, s0);
+    if constexpr (NS > 2) {
+        if (s0 + 1 < nsuper) step(std::integral_constant<int, 1>{}, s0 + 1);
     }
 }
 
@@ -531,10 +567,14 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
     };
     constexpr int AHEAD = NK <= 2 ? 2 : 1;
     constexpr int NS = AHEAD + 1;
-    TileOps<NK> ops[NS];
+    TileOps<T, NK> ops[NS];
+    int idxr[NS], idx0[AHEAD];   // index vectors, NS tiles ahead of their gathers (see ss2d_scan_cl_kernel)
 #pragma unroll
-    for (int t = 0; t < AHEAD; ++t) w.fetch(rx, rp, load_idx(t0 + t), ops[t]);
-    int idx_ahead = load_idx(t0 + AHEAD);
+    for (int t = 0; t < AHEAD; ++t) idx0[t] = load_idx(t0 + t);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) idxr[(AHEAD + t) % NS] = max(load_idx(t0 + AHEAD + t), 0);
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) w.fetch(rx, rp, idx0[t], ops[t]);
 
     float runA = 1.f, runH = 0.f;  // PASS 0: aggregate of the segment so far
     float hin = 0.f;               // PASS 1: state entering the current tile
@@ -546,15 +586,15 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
 #pragma unroll
       for (int sti = 0; sti < NS; ++sti) {
         const int t = t0 + i0 + sti;
-        TileOps<NK> &cur = ops[sti];
+        TileOps<T, NK> &cur = ops[sti];
         const int l0 = t * kTP;
         float Bp[16], Cp[16];
         w.stage_bc(cur, Bp, Cp, PASS == 1);
-        w.fetch(rx, rp, idx_ahead, ops[(sti + AHEAD) % NS]);
-        idx_ahead = load_idx(t + AHEAD + 1);
+        w.fetch(rx, rp, idxr[(sti + AHEAD) % NS], ops[(sti + AHEAD) % NS]);
+        idxr[(sti + AHEAD) % NS] = load_idx(t + AHEAD + NS);
 
-        float a[16], bb[16], preA[4], preH[4], tA, tH;
-        w.terms(cur, Bp, lend - l0, a, bb);   // positions at or past the segment end are the identity
+        float a[16], bb[16], uf[16], preA[4], preH[4], tA, tH;
+        w.terms(cur, Bp, lend - l0, a, bb, uf);   // positions at or past the segment end are the identity
         w.prefix(a, bb, preA, preH, tA, tH);
         if (PASS == 0) {
             runH = fmaf(tA, runH, tH);
@@ -562,9 +602,9 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
         } else {
             const unsigned yv = (unsigned)((l0 + 4 * hi) * D + cc_) * (unsigned)sizeof(TY);
             if (cfull && l0 + kTP <= lend) {  // wave-uniform
-                w.template replay<TY, false>(ry, yv, yrow, cur, a, bb, Cp, preA, preH, hin, true, kTP);
+                w.template replay<TY, false>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, true, kTP);
             } else {
-                w.template replay<TY, true>(ry, yv, yrow, cur, a, bb, Cp, preA, preH, hin, cok, lend - l0);
+                w.template replay<TY, true>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, cok, lend - l0);
             }
             hin = fmaf(tA, hin, tH);
         }
@@ -734,8 +774,14 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
         return TRAMBA_OK;
     }
     // ---- chained form (no workspace): one workgroup of W waves per sequence
-    int W = (l + kTP - 1) / kTP;
-    if (W > kMaxW) W = kMaxW;
+    // W waves per sequence: as many as keep the whole launch resident at once (2 waves per SIMD at this
+    // register budget = 2048 wave slots) -- beyond that, extra waves only add barrier partners and idle tile
+    // slots in the last super-chunk (measured, scripts/probe_scan_latency.py: 24x24 K=8 is 1.8x faster at W=2).
+    int W = kMaxW;
+    while (W > 1 && (long)batch * k * ct * W > 2048) W >>= 1;
+    if (W > (l + kTP - 1) / kTP) W = (l + kTP - 1) / kTP;
+    static const int forced_w = [] { const char *e = getenv("TRAMBA_SCAN_W"); return e ? atoi(e) : 0; }();
+    if (forced_w > 0 && forced_w < W) W = forced_w;
     dim3 grid(ct, k, batch), block(W * kWave);
 #define GO_(T, TY, NK_, SP_)                                                                               \
     hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK_, SP_>), grid, block, 0, s, (const T *)x, xdbl, table, \

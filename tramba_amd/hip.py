@@ -247,7 +247,7 @@ def cross_merge(ys, order: ScanOrder):
 
 # ----------------------------------------------------------------------------- channels-last kernels
 def ss2d_group_stride(r: int) -> int:
-    """Floats per direction group of the x_proj output: [dt_0..dt_{R-1}, B, C] padded to 4."""
+    """Floats per direction group of the x_proj output: [dt_0..dt_{R-1}, 0-pad to R8 = 8*ceil(R/8), B, C, 0, 0]."""
     return lib().tramba_ss2d_group_stride(r)
 
 
@@ -256,7 +256,8 @@ def pad_x_proj_weight(x_proj_weight: torch.Tensor) -> torch.Tensor:
     k, r2, d = x_proj_weight.shape
     rg = ss2d_group_stride(r2 - 2)
     w = x_proj_weight.new_zeros((k, rg, d))
-    w[:, :r2] = x_proj_weight
+    w[:, :r2 - 2] = x_proj_weight[:, :r2 - 2]
+    w[:, rg - 4:rg - 2] = x_proj_weight[:, r2 - 2:]      # B, C after the 8-padded ranks
     return w.reshape(k * rg, d)
 
 
