@@ -79,6 +79,15 @@ __device__ __forceinline__ void store_pack(T *p, const float (&in)[V])
     *reinterpret_cast<Pack<T, V> *>(p) = pk;
 }
 
+// ---- buffer (SRD) addressing: wave-uniform descriptor + 32-bit per-lane byte offset.  Accesses at or beyond
+// `bytes` are dropped (loads return 0) by the hardware range check.  Build descriptors from wave-uniform
+// values only (kernel arguments, blockIdx, readfirstlane results).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+constexpr unsigned kOutOfRange = 0x80000000u;  // a vector offset >= any num_records the host admits
+
 // ---- math ----
 // softplus with the reference's threshold (x > 20 -> x).  log1p via the w = 1+z trick keeps
 // full relative precision for small exp(x) while using the hardware exp/log.

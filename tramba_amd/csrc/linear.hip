@@ -139,6 +139,76 @@ struct ConvGeom {
     int hin, win, cin, hout, wout;
 };
 
+// Epilogue through LDS, block-wide (shared by the tile kernels): see the comment inside.
+template <typename T, typename TO, int BM, int BN>
+__device__ __forceinline__ void tile_epilogue(acc16_t (&acc)[BM / 64][BN / 64], unsigned char *lds,
+                                              const float *__restrict__ bias, const T *__restrict__ res,
+                                              TO *__restrict__ y, long M, int N, int act, long m0, int n0)
+{
+    constexpr int TM = BM / 64, TN = BN / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hi = lane >> 5;
+    // ---- epilogue through LDS, block-wide: the four waves drop their accumulators into one BM x BN fp32
+    // tile, then all 256 threads stream it out as 16-byte stores covering whole rows (a wave-private
+    // 32-column epilogue wrote 64-byte half lines with 8-byte stores: ~1 TB/s on the output-bound layers)
+    constexpr int WM = BM / 2, WN = BN / 2;
+    float *ep = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                ep[row * BN + wn * WN + j * 32 + r32] = acc[i][j][r];
+            }
+    __syncthreads();
+    constexpr int CPL = 8;                 // columns per lane: 16 bytes of a 16-bit output row
+    constexpr int LPRW = BN / CPL;         // lanes per row
+    constexpr int RPI = 256 / LPRW;        // rows per pass of the block
+    const int cl = (tid % LPRW) * CPL, rl = tid / LPRW;
+    const int gcol = n0 + cl;
+#pragma unroll
+    for (int it = 0; it < BM / RPI; ++it) {
+        const int row = it * RPI + rl;
+        const long grow = m0 + row;
+        if (grow >= M || gcol >= N) continue;
+        float o[CPL];
+        {
+            const float4 v0 = *reinterpret_cast<const float4 *>(ep + row * BN + cl);
+            const float4 v1 = *reinterpret_cast<const float4 *>(ep + row * BN + cl + 4);
+            o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+        }
+        if (gcol + CPL <= N && (N & 7) == 0) {
+            if (bias) {
+                float bv[CPL];
+                load_pack<float, CPL>(bias + gcol, bv);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) o[q] += bv[q];
+            }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) o[q] = apply_act(o[q], act);
+            if (res) {
+                float rv[CPL];
+                load_pack<T, CPL>(res + grow * N + gcol, rv);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) o[q] += rv[q];
+            }
+            store_pack<TO, CPL>(y + grow * N + gcol, o);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                if (gcol + q < N) {
+                    float t = apply_act(o[q] + (bias ? bias[gcol + q] : 0.f), act);
+                    if (res) t += Cvt<T>::to_f(res[grow * N + gcol + q]);
+                    y[grow * N + gcol + q] = Cvt<TO>::from_f(t);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, typename TO, int BM, int BN, int PF, bool CONV>
 __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__ x, const T *__restrict__ w,
                                                           const float *__restrict__ bias,
@@ -155,8 +225,19 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long m0 = (long)blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so with
+    // the plain (x = n-tile, y = m-tile) order the blocks sharing an A panel sit on 8 different XCDs and every
+    // L2 streams the whole of A.  Give XCD j a CONTIGUOUS run of tiles (n fastest) instead: an A panel is
+    // fetched by one L2, only the (small) weight matrix is replicated.
+    long m0;
+    int n0;
+    {
+        const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned q = nblk >> 3, r = nblk & 7, xcd = lin & 7, slot = lin >> 3;
+        const unsigned t = xcd * q + (xcd < r ? xcd : r) + slot;
+        m0 = (long)(t / gridDim.x) * BM;
+        n0 = (int)(t % gridDim.x) * BN;
+    }
     const int nk = (K + kBK - 1) / kBK;
 
     acc16_t acc[TM][TN];
@@ -296,64 +377,146 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
         for (int ui = 0; ui < NS; ++ui) kstep(kt0 + ui, pipe[ui % NS], pipe[(ui + 1) % NS]);
     }
 
-    // ---- epilogue through LDS, block-wide: the four waves drop their accumulators into one BM x BN fp32
-    // tile, then all 256 threads stream it out as 16-byte stores covering whole rows (a wave-private
-    // 32-column epilogue wrote 64-byte half lines with 8-byte stores: ~1 TB/s on the output-bound layers)
-    constexpr int WM = BM / 2, WN = BN / 2;
-    float *ep = reinterpret_cast<float *>(lds);
+    tile_epilogue<T, TO, BM, BN>(acc, lds, bias, res, y, M, N, act, m0, n0);
+}
+
+// Lean form of the tile kernel for the plain GEMM with K % 64 == 0 (every 1x1 convolution of the model).
+// The generic kernel spends ~37 VALU instructions per K step on addresses, clamps and masks -- more issue
+// time than its 4 MFMAs -- and these GEMMs run ~1 wave per SIMD, so that time is exposed.  Here:
+//   * operands come through buffer descriptors based at the block's first row: the per-thread byte offset
+//     is loop-invariant, the K step rides in the scalar offset, rows past M / N read as zero through the
+//     hardware range check -> no clamps, no masks, no 64-bit address arithmetic in the loop;
+//   * LDS write addresses are loop-invariant; fragment read addresses differ per 16-deep slice only by an
+//     XOR of bits 5-6 (chunk swizzle), and the buffer half is a compile-time immediate;
+//   * exactly nk steps run (ring trips + a statically indexed tail), so no zero-padded dummy steps.
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+
+template <typename T, typename TO, int BM, int BN, int PF>
+__global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ x, const T *__restrict__ w,
+                                                         const float *__restrict__ bias,
+                                                         const T *__restrict__ res, TO *__restrict__ y, long M,
+                                                         int N, int K, int act)
+{
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_PER_T = BM * (kBK / 8) / 256, B_PER_T = BN * (kBK / 8) / 256;
+    constexpr int TILE_BYTES = (BM + BN) * kBK * 2;
+    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int LDS_BYTES = 2 * TILE_BYTES > EPI_BYTES ? 2 * TILE_BYTES : EPI_BYTES;
+    constexpr int NS = PF + 1;
+    static_assert(NS % 2 == 0, "the LDS buffer parity must be a compile-time constant");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hi = lane >> 5;
+    long m0;
+    int n0;
+    {   // XCD-aware tile order (see linear_tiled_kernel)
+        const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned q = nblk >> 3, r = nblk & 7, xcd = lin & 7, slot = lin >> 3;
+        const unsigned t = xcd * q + (xcd < r ? xcd : r) + slot;
+        m0 = (long)(t / gridDim.x) * BM;
+        n0 = (int)(t % gridDim.x) * BN;
+    }
+    const int nk = K / kBK;
+    const unsigned rowb = (unsigned)K * 2u;   // bytes per operand row
+    const long mrows = M - m0 < BM ? M - m0 : BM;
+    const int nrows = N - n0 < BN ? N - n0 : BN;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(x + m0 * K, (unsigned)mrows * rowb);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(w + (long)n0 * K, (unsigned)nrows * rowb);
+
+    // loop-invariant per-thread offsets: global (row*K + 8c elements) and LDS (swizzled chunk)
+    unsigned ag[A_PER_T], bg[B_PER_T], al[A_PER_T], bl[B_PER_T];
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+        const int q = tid + i * 256, row = q >> 3, c = q & 7;
+        ag[i] = (unsigned)row * rowb + (unsigned)c * 16u;
+        al[i] = (unsigned)(row * 128 + swz_chunk(row, c) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+        const int q = tid + i * 256, row = q >> 3, c = q & 7;
+        bg[i] = (unsigned)row * rowb + (unsigned)c * 16u;
+        bl[i] = (unsigned)(BM * kBK * 2 + row * 128 + swz_chunk(row, c) * 16);
+    }
+    // fragment read offsets of the 16-deep slice kk = 0; slice kk is the same offset ^ (kk * 32)
+    unsigned ard[TM], brd[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / 2) + i * 32 + r32;
+        ard[i] = (unsigned)(row * 128 + swz_chunk(row, hi) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * (BN / 2) + j * 32 + r32;
+        brd[j] = (unsigned)(BM * kBK * 2 + row * 128 + swz_chunk(row, hi) * 16);
+    }
+
+    acc16_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                ep[row * BN + wn * WN + j * 32 + r32] = acc[i][j][r];
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    struct Stage { v4u_t a[A_PER_T], b[B_PER_T]; };
+    auto gload = [&](int kt, Stage &st) {   // a K step past the end reads the following rows / zeros: never used
+        const unsigned so = (unsigned)kt * (kBK * 2);
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) st.a[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, ag[i], so, 0);
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) st.b[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, bg[i], so, 0);
+    };
+    auto lstore = [&](int par, const Stage &st) {
+        unsigned char *base = lds + par * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) *reinterpret_cast<v4u_t *>(base + al[i]) = st.a[i];
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) *reinterpret_cast<v4u_t *>(base + bl[i]) = st.b[i];
+    };
+
+    Stage pipe[NS];
+    gload(0, pipe[0]);
+    lstore(0, pipe[0]);
+#pragma unroll
+    for (int i = 1; i < NS; ++i) gload(i, pipe[i]);
     __syncthreads();
-    constexpr int CPL = 8;                 // columns per lane: 16 bytes of a 16-bit output row
-    constexpr int LPRW = BN / CPL;         // lanes per row
-    constexpr int RPI = 256 / LPRW;        // rows per pass of the block
-    const int cl = (tid % LPRW) * CPL, rl = tid / LPRW;
-    const int gcol = n0 + cl;
+    // one K step; `par` (LDS half holding tile kt) is a literal at every call site
+    auto kstep = [&](int kt, int par, Stage &load_into, const Stage &store_from) {
+        gload(kt + NS, load_into);  // this stage held tile kt, already in LDS
+        const unsigned char *base = lds + par * TILE_BYTES;
 #pragma unroll
-    for (int it = 0; it < BM / RPI; ++it) {
-        const int row = it * RPI + rl;
-        const long grow = m0 + row;
-        if (grow >= M || gcol >= N) continue;
-        float o[CPL];
-        {
-            const float4 v0 = *reinterpret_cast<const float4 *>(ep + row * BN + cl);
-            const float4 v1 = *reinterpret_cast<const float4 *>(ep + row * BN + cl + 4);
-            o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+        for (int kk = 0; kk < kBK / 16; ++kk) {
+            frag8_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const frag8_t *>(base + (ard[i] ^ (unsigned)(kk * 32)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const frag8_t *>(base + (brd[j] ^ (unsigned)(kk * 32)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
         }
-        if (gcol + CPL <= N && (N & 7) == 0) {
-            if (bias) {
-                float bv[CPL];
-                load_pack<float, CPL>(bias + gcol, bv);
+        lstore(par ^ 1, store_from);
+        __syncthreads();
+    };
+    constexpr int UNR = 4 * NS;   // hipcc drains vmcnt at the top of every loop trip: long trips
+    int kt0 = 0;
+    for (; kt0 + UNR <= nk; kt0 += UNR) {
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) o[q] += bv[q];
-            }
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) o[q] = apply_act(o[q], act);
-            if (res) {
-                float rv[CPL];
-                load_pack<T, CPL>(res + grow * N + gcol, rv);
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) o[q] += rv[q];
-            }
-            store_pack<TO, CPL>(y + grow * N + gcol, o);
-        } else {
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                if (gcol + q < N) {
-                    float t = apply_act(o[q] + (bias ? bias[gcol + q] : 0.f), act);
-                    if (res) t += Cvt<T>::to_f(res[grow * N + gcol + q]);
-                    y[grow * N + gcol + q] = Cvt<TO>::from_f(t);
-                }
-            }
-        }
+        for (int ui = 0; ui < UNR; ++ui) kstep(kt0 + ui, ui & 1, pipe[ui % NS], pipe[(ui + 1) % NS]);
     }
+    for (; kt0 + NS <= nk; kt0 += NS) {
+#pragma unroll
+        for (int ui = 0; ui < NS; ++ui) kstep(kt0 + ui, ui & 1, pipe[ui % NS], pipe[(ui + 1) % NS]);
+    }
+    // the 0 .. NS-1 remaining steps, ring indices still static (kt0 is a multiple of NS)
+#pragma unroll
+    for (int ui = 0; ui < NS - 1; ++ui)
+        if (kt0 + ui < nk) kstep(kt0 + ui, ui & 1, pipe[ui % NS], pipe[(ui + 1) % NS]);
+
+    tile_epilogue<T, TO, BM, BN>(acc, lds, bias, res, y, M, N, act, m0, n0);
 }
 
 // Tile choice: 64x64 (3 K-tiles in flight) wins on every GEMM of this model (M = 576..36864, N <= 4096,
@@ -368,10 +531,23 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
         return e && strcmp(e, "128x128") == 0;
     }();
     const long big = ((m + 127) / 128) * ((n + 127) / 128);
+    // lean kernel: whole 64-deep K steps, and a 64-row operand panel within 32-bit byte offsets
+    static const bool no_lean = getenv("TRAMBA_GEMM_LEAN") && strcmp(getenv("TRAMBA_GEMM_LEAN"), "0") == 0;
+    const bool lean_ok = !no_lean && k % 64 == 0 && (double)k * 2.0 * 128.0 < 2147483648.0;
     if (force_big || (big >= 2048 && k >= 1024)) {
         dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
         hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2, CONV>), grid, block, 0, s, (const T *)x,
                            (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);
+    } else if (!CONV && lean_ok && k <= 128) {
+        dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
+        hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 1>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                           (const T *)res, (TO *)y, m, n, k, act);
+    } else if (!CONV && lean_ok && k >= 1024) {
+        // (the 4-stage lean kernel holds 168 VGPRs against the generic kernel's 140: it wins where the K loop is
+        //  long and blocks are few, and loses a resident block per CU on the short-K, many-block layers)
+        dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
+        hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 3>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                           (const T *)res, (TO *)y, m, n, k, act);
     } else if (k <= 128) {  // 1-2 K steps: a 2-stage ring, no padded dummy steps
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
         hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 64, 64, 1, CONV>), grid, block, 0, s, (const T *)x,

@@ -81,12 +81,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // descriptor + a 32-bit per-lane BYTE offset: no 64-bit address arithmetic in the VALU (the kernels are
 // VALU-bound), row strides ride in the scalar `soffset`, and an element outside the tensor is given an
 // out-of-range vector offset which the hardware range check drops: no branches around the stores.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
-}
-constexpr unsigned kOutOfRange = 0x80000000u;  // >= any num_records the host admits: access dropped
-
 template <typename T> struct RawOf { typedef unsigned short type; };
 template <> struct RawOf<float> { typedef unsigned type; };
 
