@@ -609,6 +609,175 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// ss2d_merge_norm_cl, streaming form (bijective orders on large maps):
+// y[b, p, :] = act(LayerNorm(sum over the CSR entries e of pixel p of ys[b, entry e, :])).
+// One wave owns P consecutive pixels of one image.  Their CSR window (P+1 pointers, then up to 64 entries)
+// is fetched ONCE, so a pixel costs one memory latency -- the row gathers -- instead of three dependent
+// ones (pointer -> entry -> rows); the rows of the next batch are requested before the current batch is
+// reduced (2 static register slots, loop unrolled by two, exit test at the bottom only).  The loop body is
+// branch-free: rows past a batch's count are clamped re-reads weighted 0, LayerNorm runs for every batch
+// and only a pixel's last batch stores (the others get the out-of-range vector offset).
+// NIT = wave iterations per row (D <= 64*V*NIT); BATCH = rows requested per step.
+template <typename TY> struct YsRaw;
+template <> struct YsRaw<float> { static constexpr int kBytes = 4; };
+template <> struct YsRaw<__half> { static constexpr int kBytes = 2; };
+template <> struct YsRaw<__hip_bfloat16> { static constexpr int kBytes = 2; };
+
+template <typename TY, int V>
+__device__ __forceinline__ void buf_load_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float (&out)[V])
+{
+    if constexpr (sizeof(TY) == 4) {
+        static_assert(V == 4 || V == 2 || V == 1, "vector width");
+        if constexpr (V == 4) {
+            const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        } else if constexpr (V == 2) {
+            const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+            out[0] = v.x; out[1] = v.y;
+        } else {
+            out[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+        }
+    } else {
+        Pack<TY, V> pk;
+        if constexpr (V == 4) {
+            pk = __builtin_bit_cast(Pack<TY, V>, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+        } else if constexpr (V == 2) {
+            pk = __builtin_bit_cast(Pack<TY, V>, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+        } else {
+            pk = __builtin_bit_cast(Pack<TY, V>, __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0));
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) out[v] = Cvt<TY>::to_f(pk.v[v]);
+    }
+}
+
+template <typename TY, typename T, int V, int NIT, int BATCH>
+__global__ __launch_bounds__(256) void ss2d_merge_norm_stream_kernel(
+    const TY *__restrict__ ys, const int32_t *__restrict__ inv_ptr, const int32_t *__restrict__ inv_idx,
+    const float *__restrict__ ln_w, const float *__restrict__ ln_b, T *__restrict__ y, long nwaves, int nchunk,
+    int P, int L, int D, int K, float eps, int act)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const long wid = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wid >= nwaves) return;   // wave-uniform, no barriers below
+    const int b = (int)(wid / nchunk);
+    const int pl0 = (int)(wid % nchunk) * P;
+    const int np = L - pl0 < P ? L - pl0 : P;   // pixels of this wave
+
+    // CSR window: pointers of pixels pl0 .. pl0+np in lanes 0..np, then 64 entries from the first one
+    const int ptr = inv_ptr[pl0 + (lane < np ? lane : np)];
+    const int e_lo = __builtin_amdgcn_readlane(ptr, 0), e_hi = __builtin_amdgcn_readlane(ptr, np);
+    int ebase = e_lo;
+    int ent = inv_idx[ebase + lane < e_hi ? ebase + lane : e_hi - 1];
+
+    const unsigned yrow = (unsigned)D * (unsigned)sizeof(T), srow = (unsigned)D * (unsigned)sizeof(TY);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(ys + (long)b * K * L * D, (unsigned)K * L * srow);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(y + ((long)b * L + pl0) * D, (unsigned)np * yrow);
+
+    // loop-invariant per-lane operands
+    float gw[NIT][V], gb[NIT][V];
+    unsigned coff[NIT];       // byte offset of my channels in a ys row, out of range past D
+    unsigned ooff[NIT];       // same in an output row
+    bool cin[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c0 = (it * kWave + lane) * V;
+        cin[it] = c0 + V <= D;
+        coff[it] = cin[it] ? (unsigned)c0 * (unsigned)sizeof(TY) : kOutOfRange;
+        ooff[it] = cin[it] ? (unsigned)c0 * (unsigned)sizeof(T) : kOutOfRange;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            gw[it][v] = cin[it] ? ln_w[c0 + v] : 0.f;
+            gb[it][v] = cin[it] ? ln_b[c0 + v] : 0.f;
+        }
+    }
+
+    struct Batch { int j, e0, cnt; bool last, valid; };
+    int sj = 0, se = e_lo;   // stream state: current pixel, next entry
+    auto next_batch = [&]() -> Batch {
+        Batch q;
+        q.valid = sj < np;
+        const int jj = q.valid ? sj : np - 1;
+        const int eend = __builtin_amdgcn_readlane(ptr, jj + 1);
+        q.j = jj;
+        q.e0 = q.valid ? se : e_hi - 1;
+        const int left = q.valid ? eend - se : 1;
+        q.cnt = left < BATCH ? left : BATCH;
+        q.last = q.valid && q.cnt == left;
+        if (q.valid) {
+            se += q.cnt;
+            if (q.last) ++sj;
+        }
+        return q;
+    };
+    auto issue = [&](const Batch &q, float (&t)[BATCH][NIT][V]) {
+        if (q.e0 + q.cnt > ebase + kWave) {   // wave-uniform, rare: slide the entry window
+            ebase = q.e0;
+            ent = inv_idx[ebase + lane < e_hi ? ebase + lane : e_hi - 1];
+        }
+#pragma unroll
+        for (int r = 0; r < BATCH; ++r) {
+            const int ei = q.e0 - ebase + (r < q.cnt ? r : q.cnt - 1);   // clamped: weighted 0 below
+            const unsigned so = (unsigned)__builtin_amdgcn_readlane(ent, ei) * srow;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) buf_load_row<TY, V>(rs, coff[it], so, t[r][it]);
+        }
+    };
+    float acc[kNormMaxIt][V];
+#pragma unroll
+    for (int it = 0; it < kNormMaxIt; ++it)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[it][v] = 0.f;
+    auto consume = [&](const Batch &q, const float (&t)[BATCH][NIT][V]) {
+#pragma unroll
+        for (int r = 0; r < BATCH; ++r) {
+            const float wr = (q.valid && r < q.cnt) ? 1.f : 0.f;   // scalar
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[it][v] = fmaf(t[r][it][v], wr, acc[it][v]);
+        }
+        float mean, rstd;
+        wave_layernorm<V>(acc, NIT, D, lane, eps, mean, rstd);
+        const unsigned so = (unsigned)q.j * yrow;
+        const float keep = q.last ? 0.f : 1.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            float o[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                o[v] = apply_act((acc[it][v] - mean) * rstd * gw[it][v] + gb[it][v], act);
+                acc[it][v] *= keep;
+            }
+            const unsigned vo = q.last ? ooff[it] : kOutOfRange;
+            const Pack<T, V> pk = [&] { Pack<T, V> z; for (int v = 0; v < V; ++v) z.v[v] = Cvt<T>::from_f(o[v]); return z; }();
+            if constexpr (sizeof(T) * V == 16) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pk), ro, vo, so, 0);
+            } else if constexpr (sizeof(T) * V == 8) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, pk), ro, vo, so, 0);
+            } else if constexpr (sizeof(T) * V == 4) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), ro, vo, so, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, pk), ro, vo, so, 0);
+            }
+        }
+    };
+
+    float t0[BATCH][NIT][V], t1[BATCH][NIT][V];
+    Batch c0 = next_batch();
+    issue(c0, t0);
+    while (true) {
+        const Batch c1 = next_batch();
+        issue(c1, t1);
+        consume(c0, t0);
+        c0 = next_batch();
+        issue(c0, t0);
+        consume(c1, t1);
+        if (!c0.valid) break;
+    }
+}
+
+// ss2d_merge_norm_cl, one-wave-per-pixel form (small maps, wide rows, many-to-one Helix tables).
 // NIT = wave iterations per row (D <= 64*V*NIT); BATCH rows of ys are requested back to back
 // before any is consumed, so a pixel pays ~1 memory latency instead of one per direction.
 template <typename TY, typename T, int V, int NIT>
@@ -802,17 +971,29 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
     int v = (d % 4 == 0) ? 4 : ((d % 2 == 0) ? 2 : 1);
     TRAMBA_CHECK((d + kWave * v - 1) / (kWave * v) <= kNormMaxIt, "ss2d_merge_norm_cl: D=%d too large", d);
     TRAMBA_CHECK(aligned16(ys) && aligned16(y), "ss2d_merge_norm_cl: tensors must be 16-byte aligned");
-    dim3 grid((unsigned)((npix + 3) / 4)), block(256);
     const int nit_need = (d + kWave * v - 1) / (kWave * v);
     const int nit = nit_need <= 1 ? 1 : (nit_need <= 2 ? 2 : (nit_need <= 4 ? 4 : 8));
-#define GO_(TY, T, V_, N_)                                                                                  \
-    hipLaunchKernelGGL((ss2d_merge_norm_cl_kernel<TY, T, V_, N_>), grid, block, 0, s, (const TY *)ys, inv_ptr, \
-                       inv_idx, ln_w, ln_b, (T *)y, npix, l, d, k, eps, act)
+    // Streaming form (measured, scripts/bench_scan.py): wins where one batch covers a pixel (K <= 4), the row
+    // is at most two wave iterations and the map is large enough to fill the chip with 16-pixel waves
+    // (6 TB/s on 96x96 D=256); elsewhere one wave per pixel is faster.
+    const bool stream_form = k <= 4 && nit <= 2 && npix >= 8192 && (double)k * l * d * 4.0 < 4294967296.0;
+    const int pw = 16;
+    const int nchunk = (l + pw - 1) / pw;
+    const long nwaves = (long)batch * nchunk;
+    dim3 grid(stream_form ? (unsigned)((nwaves + 3) / 4) : (unsigned)((npix + 3) / 4)), block(256);
+#define GO_(TY, T, V_, N_)                                                                                    \
+    if (stream_form)                                                                                          \
+        hipLaunchKernelGGL((ss2d_merge_norm_stream_kernel<TY, T, V_, (N_ <= 2 ? N_ : 2), 4>), grid, block, 0, s, \
+                           (const TY *)ys, inv_ptr, inv_idx, ln_w, ln_b, (T *)y, nwaves, nchunk, pw, l, d, k, eps, \
+                           act);                                                                              \
+    else                                                                                                      \
+        hipLaunchKernelGGL((ss2d_merge_norm_cl_kernel<TY, T, V_, N_>), grid, block, 0, s, (const TY *)ys, inv_ptr, \
+                           inv_idx, ln_w, ln_b, (T *)y, npix, l, d, k, eps, act)
 #define BY_N_(TY, T, V_)               \
-    if (nit == 1) GO_(TY, T, V_, 1);   \
-    else if (nit == 2) GO_(TY, T, V_, 2); \
-    else if (nit == 4) GO_(TY, T, V_, 4); \
-    else GO_(TY, T, V_, 8);
+    if (nit == 1) { GO_(TY, T, V_, 1); }   \
+    else if (nit == 2) { GO_(TY, T, V_, 2); } \
+    else if (nit == 4) { GO_(TY, T, V_, 4); } \
+    else { GO_(TY, T, V_, 8); }
 #define BY_V_(TY, T)                   \
     if (v == 4) { BY_N_(TY, T, 4) }    \
     else if (v == 2) { BY_N_(TY, T, 2) } \
