@@ -179,7 +179,8 @@ def test_linear_cl(dtype, mnk):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("fam", ["raster", "helix", "window", "dilation"])
-@pytest.mark.parametrize("cfg", [(2, 12, 32, 2), (1, 24, 64, 4), (1, 16, 40, 3), (1, 48, 128, 8), (1, 12, 96, 40), (1, 24, 32, 64), (2, 96, 64, 8)])
+@pytest.mark.parametrize("cfg", [(2, 12, 32, 2), (1, 24, 64, 4), (1, 16, 40, 3), (1, 48, 128, 8), (1, 12, 96, 40), (1, 24, 32, 64), (2, 96, 64, 8),
+                                 (1, 12, 1024, 16), (1, 8, 2048, 8)])
 def test_ss2d_fused_core(dtype, fam, cfg):
     """fused channels-last scan + merge/LayerNorm/GELU against the oracle's NCHW composition."""
     b, h, d, r = cfg

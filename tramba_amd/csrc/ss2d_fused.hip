@@ -842,6 +842,107 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_cl_kernel(
     }
 }
 
+// ss2d_merge_norm_cl, split-row form (small maps with wide rows: 24x24 D=1024, 12x12 D=2048): the WPP waves of
+// a workgroup share ONE pixel, each owning every WPP-th 64*V-channel slice of the row, so a 2304-pixel map
+// puts 9216 waves in flight instead of 2304; the LayerNorm statistics cross the waves through LDS.
+template <typename TY, typename T, int V, int NIT, int WPP>
+__global__ __launch_bounds__(256) void ss2d_merge_norm_split_kernel(
+    const TY *__restrict__ ys, const int32_t *__restrict__ inv_ptr, const int32_t *__restrict__ inv_idx,
+    const float *__restrict__ ln_w, const float *__restrict__ ln_b, T *__restrict__ y, long npix, int L,
+    int D, int K, float eps, int act)
+{
+    static_assert(NIT % WPP == 0 && 4 % WPP == 0, "waves per pixel must divide the iterations and the block");
+    constexpr int NITW = NIT / WPP;            // slices per wave
+    constexpr int PPB = 4 / WPP;               // pixels per workgroup
+    constexpr int BATCH = NITW == 1 ? 4 : 2;
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = wv % WPP, pb = wv / WPP;
+    long pix = (long)blockIdx.x * PPB + pb;
+    const bool live = pix < npix;              // wave-uniform; dead waves still join the barriers
+    if (!live) pix = npix - 1;
+    const int b = (int)(pix / L), p = (int)(pix % L);
+    float acc[NITW][V];
+#pragma unroll
+    for (int it = 0; it < NITW; ++it)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[it][v] = 0.f;
+
+    const TY *yb = ys + (long)b * K * L * D;
+    const int e0 = inv_ptr[p], e1 = inv_ptr[p + 1];
+    for (int e = e0; e < e1; e += BATCH) {
+        const int mine = (lane < BATCH && e + lane < e1) ? inv_idx[e + lane] : 0;
+        float t[BATCH][NITW][V];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if (e + j < e1) {  // wave-uniform
+                const TY *row = yb + (long)__builtin_amdgcn_readlane(mine, j) * D;  // entry = k*L + l
+#pragma unroll
+                for (int it = 0; it < NITW; ++it) {
+                    const int c0 = ((it * WPP + sub) * kWave + lane) * V;
+                    if (c0 + V <= D) {
+                        load_pack<TY, V>(row + c0, t[j][it]);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) t[j][it][v] = 0.f;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+            if (e + j < e1)
+#pragma unroll
+                for (int it = 0; it < NITW; ++it)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[it][v] += t[j][it][v];
+    }
+    // two-pass statistics over the WPP slices of the row (channels past D hold 0 and are masked out)
+    float sl = 0.f;
+#pragma unroll
+    for (int it = 0; it < NITW; ++it)
+#pragma unroll
+        for (int v = 0; v < V; ++v) sl += acc[it][v];
+    sl = wave_sum(sl);
+    if (lane == 0) red[0][wv] = sl;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < WPP; ++q) tot += red[0][pb * WPP + q];
+    const float mean = tot / (float)D;
+    float ql = 0.f;
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+        const int c0 = ((it * WPP + sub) * kWave + lane) * V;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float dlt = acc[it][v] - mean;
+            if (c0 + v < D) ql = fmaf(dlt, dlt, ql);
+        }
+    }
+    ql = wave_sum(ql);
+    if (lane == 0) red[1][wv] = ql;
+    __syncthreads();
+    float qt = 0.f;
+#pragma unroll
+    for (int q = 0; q < WPP; ++q) qt += red[1][pb * WPP + q];
+    const float rstd = rsqrtf(qt / (float)D + eps);
+    if (!live) return;
+    T *orow = y + pix * D;
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+        const int c0 = ((it * WPP + sub) * kWave + lane) * V;
+        if (c0 + V <= D) {
+            float o[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                o[v] = apply_act((acc[it][v] - mean) * rstd * ln_w[c0 + v] + ln_b[c0 + v], act);
+            store_pack<T, V>(orow + c0, o);
+        }
+    }
+}
+
 }  // namespace tramba
 
 using namespace tramba;
@@ -980,9 +1081,15 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
     const int pw = 16;
     const int nchunk = (l + pw - 1) / pw;
     const long nwaves = (long)batch * nchunk;
-    dim3 grid(stream_form ? (unsigned)((nwaves + 3) / 4) : (unsigned)((npix + 3) / 4)), block(256);
+    // split-row form: a wide row (>= 4 wave iterations) on a map too small to fill the chip one wave per pixel
+    const bool split_form = !stream_form && nit >= 4 && npix <= 16384;
+    dim3 grid(stream_form ? (unsigned)((nwaves + 3) / 4) : (split_form ? (unsigned)npix : (unsigned)((npix + 3) / 4))),
+        block(256);
 #define GO_(TY, T, V_, N_)                                                                                    \
-    if (stream_form)                                                                                          \
+    if (split_form)                                                                                           \
+        hipLaunchKernelGGL((ss2d_merge_norm_split_kernel<TY, T, V_, (N_ >= 4 ? N_ : 4), 4>), grid, block, 0, s, \
+                           (const TY *)ys, inv_ptr, inv_idx, ln_w, ln_b, (T *)y, npix, l, d, k, eps, act);    \
+    else if (stream_form)                                                                                          \
         hipLaunchKernelGGL((ss2d_merge_norm_stream_kernel<TY, T, V_, (N_ <= 2 ? N_ : 2), 4>), grid, block, 0, s, \
                            (const TY *)ys, inv_ptr, inv_idx, ln_w, ln_b, (T *)y, nwaves, nchunk, pw, l, d, k, eps, \
                            act);                                                                              \
