@@ -240,3 +240,44 @@ def test_stem_conv_ln_gelu(dtype, cfg):
     got = hip().stem_conv_ln_gelu(img.to(DEV), w.to(DEV), bias.to(DEV), lw.to(DEV), lb.to(DEV), 1e-5, dtype)
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol)
+
+
+def test_two_stream_concurrency_is_bitwise_stable():
+    """Kernels of two HIP streams running concurrently must not change each other's results (the decoder's guide
+    branch runs beside the encoder, tramba_amd/models.py).  Regression: a 16-byte buffer store with an SGPR
+    offset lost its data to the next VALU write when the memory system was busy (fp32 streaming merge)."""
+    H = hip()
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(5)
+
+    def scan_ops(d, r, fam, dtype):
+        order = H.scan_order(fam, 96, 96, dev)
+        k, l = order.k, 96 * 96
+        x = torch.randn(1, l, d, generator=g).to(dev, dtype)
+        wx = (torch.randn(k, r + 2, d, generator=g) * d ** -0.5).to(dev, dtype)
+        xdbl = H.linear_cl(x, H.pad_x_proj_weight(wx), out_dtype=torch.float32)
+        dt_w = (torch.randn(k, d, r, generator=g) * r ** -0.5).to(dev)
+        dt_b = (torch.randn(k * d, generator=g) * 0.5 - 3).to(dev)
+        a = -torch.rand(k * d, generator=g).to(dev) - 0.5
+        ds = torch.ones(k * d, device=dev)
+        lw, lb = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+        ys0 = H.ss2d_scan_cl(x, xdbl, order, dt_w, dt_b, a, ds, torch.float32)
+        return {"scan": lambda: H.ss2d_scan_cl(x, xdbl, order, dt_w, dt_b, a, ds, torch.float32),
+                "merge": lambda: H.ss2d_merge_norm_cl(ys0, order, lw, lb, 1e-5, 2, dtype)}
+
+    xs = torch.randn(1, 192, 192, 128, generator=g).to(dev)
+    ws = (torch.randn(256, 128, generator=g) * 0.1).to(dev)
+    side_ops = [lambda: H.linear_cl(xs, ws, None, None, 2), scan_ops(256, 8, "window", torch.float32)["merge"]]
+    side = torch.cuda.Stream()
+    for dtype in (torch.float32, torch.bfloat16):
+        for name, op in scan_ops(512, 16, "raster", dtype).items():
+            ref = op().clone()
+            torch.cuda.synchronize()
+            for sop in side_ops:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    keep = [sop() for _ in range(30)]
+                outs = [op() for _ in range(10)]
+                torch.cuda.synchronize()
+                assert all(torch.equal(o, ref) for o in outs), (name, dtype)
+                del keep

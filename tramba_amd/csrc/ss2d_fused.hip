@@ -749,16 +749,20 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_stream_kernel(
                 o[v] = apply_act((acc[it][v] - mean) * rstd * gw[it][v] + gb[it][v], act);
                 acc[it][v] *= keep;
             }
-            const unsigned vo = q.last ? ooff[it] : kOutOfRange;
+            // The row offset goes into the VECTOR offset, the scalar offset stays 0: a 16-byte buffer store with
+            // an SGPR soffset is exempt from hipcc's "VALU overwrites the data of a >64-bit store" wait state,
+            // yet on gfx950 under memory back-pressure the store then picked up the overwritten registers
+            // (seen as corrupted dword 0 of lanes 12-15 per 16 when two streams ran; scripts/debug_concurrent.py).
+            const unsigned vo = (q.last ? ooff[it] : kOutOfRange) + so;
             const Pack<T, V> pk = [&] { Pack<T, V> z; for (int v = 0; v < V; ++v) z.v[v] = Cvt<T>::from_f(o[v]); return z; }();
             if constexpr (sizeof(T) * V == 16) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pk), ro, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pk), ro, vo, 0, 0);
             } else if constexpr (sizeof(T) * V == 8) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, pk), ro, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, pk), ro, vo, 0, 0);
             } else if constexpr (sizeof(T) * V == 4) {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), ro, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), ro, vo, 0, 0);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, pk), ro, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, pk), ro, vo, 0, 0);
             }
         }
     };

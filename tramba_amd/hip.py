@@ -156,6 +156,8 @@ class ScanOrder:
         self.table = torch.from_numpy(host).to(device)
         self.inv_ptr = torch.from_numpy(ptr).to(device)
         self.inv_idx = torch.from_numpy(idx).to(device)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(device).synchronize()   # tables are shared by every stream from here on
 
 
 def scan_order(family: str, h: int, w: int, device, param: int = 0) -> ScanOrder:
@@ -265,11 +267,12 @@ _scan_ws = {}
 
 
 def _scan_workspace(device, nbytes):
-    """Per-device scratch for the wave-segment scan (grown on demand, reused by every launch: launches
-    on one stream are ordered, and graph capture sees a stable address)."""
-    ws = _scan_ws.get(str(device))
+    """Per-(device, stream) scratch for the wave-segment scan (grown on demand, reused by every launch: launches
+    on one stream are ordered, and graph capture sees a stable address; concurrent streams get their own)."""
+    key = (str(device), _stream())
+    ws = _scan_ws.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _scan_ws[str(device)] = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
+        ws = _scan_ws[key] = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
     return ws
 
 

@@ -5,6 +5,7 @@
 "encoder"), 679 state_dict entries for Tramba-V so ``load_state_dict(strict=True)`` of a reference
 checkpoint works (test_TSOD.py:36-38).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -15,6 +16,19 @@ from . import hip
 from .modules import (FinalPatchExpand_X4, FreqBlockv6, LayerNorm2d, Linear2d, MultiScaleDecoderBlock, PatchExpand,
                       VSSMEncoder, _init_weights, _need_device, from_cl, load_pretrained_Base, to_cl)
 from .ops import CrossMerge_Line, CrossScan_Line
+
+
+# Independent branches of the inference graph on separate HIP streams (TRAMBA_OVERLAP=0 disables).
+OVERLAP_BRANCHES = os.environ.get("TRAMBA_OVERLAP", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 class VSSMDecoder(nn.Module):
@@ -63,15 +77,22 @@ class VSSMDecoder(nn.Module):
         y = F.linear(x, w, conv.bias.to(x.dtype))
         return y.permute(0, 3, 1, 2)
 
-    def _forward_cl(self, skips_cl):
-        """skips_cl: [image, s1..sn] with s* channels-last.  Trambav6.py:114-139."""
+    def _forward_cl(self, skips_cl, guides=None):
+        """skips_cl: [image, s1..sn] with s* channels-last.  Trambav6.py:114-139.
+        guides: optional {decoder stage: (tensor, event)} of guide-branch outputs already computed on a side
+        stream (BaseUMamba._forward_overlapped); the event is waited for right before the first use."""
         x_low = skips_cl[-1]
         outs = []
         n = len(self.stage_layers)
         for s in range(n):
             x = self.expand_layers[s]._forward_cl(x_low)
             if s < n - 1:
-                mid = self.guide_layers[s]._forward_cl(skips_cl[-(s + 2)])
+                if guides is not None and s in guides:
+                    mid, ready = guides[s]
+                    torch.cuda.current_stream().wait_event(ready)
+                    mid.record_stream(torch.cuda.current_stream())
+                else:
+                    mid = self.guide_layers[s]._forward_cl(skips_cl[-(s + 2)])
                 x = self.concat_back_dim[s]._forward_cl(torch.cat((x, mid), dim=-1))
                 for blk in self.stage_layers[s].blocks:
                     x = blk._forward_cl(x)
@@ -95,12 +116,43 @@ class BaseUMamba(nn.Module):
         if use_pretrain:
             load_pretrained_Base(self.vssm_encoder, ckpt_path=pretrained_path)
 
+    def _forward_overlapped(self, x):
+        """Inference only.  The decoder's guide branch (FreqBlockv6 on an encoder skip) depends on nothing but
+        that skip: it is issued on a side stream the moment the encoder stage finishes, so its large 96x96 /
+        48x48 kernels fill the CUs that the encoder's small 24x24 / 12x12 launches leave idle.  Captured into a
+        hipGraph the fork/join become graph edges."""
+        main = torch.cuda.current_stream()
+        side = _side_stream(x.device)
+        dec = self.decoder
+        n = len(dec.stage_layers)
+        guides = {}
+
+        def on_stage(i, feat):          # encoder stage i -> skips[i + 1] -> decoder stage n - 2 - i
+            s = n - 2 - i
+            if s < 0 or s >= len(dec.guide_layers):
+                return
+            side.wait_stream(main)
+            feat.record_stream(side)
+            with torch.cuda.stream(side):
+                mid = dec.guide_layers[s]._forward_cl(feat)
+                ready = torch.cuda.Event()
+                ready.record(side)
+            guides[s] = (mid, ready)
+
+        skips = self.vssm_encoder._forward_cl(x, on_stage=on_stage)
+        out = dec._forward_cl(skips, guides=guides)
+        main.wait_stream(side)          # join (a no-op in time: every guide was already waited for)
+        return out
+
     def forward(self, x):
         _need_device(x)
         if self.compute_dtype is not None:
             x = x.to(self.compute_dtype)
-        skips = self.vssm_encoder._forward_cl(x)
-        out = self.decoder._forward_cl(skips)
+        if OVERLAP_BRANCHES and not torch.is_grad_enabled() and type(self.decoder) is VSSMDecoder:
+            out = self._forward_overlapped(x)
+        else:
+            skips = self.vssm_encoder._forward_cl(x)
+            out = self.decoder._forward_cl(skips)
         if self.compute_dtype is not None:
             out = [o.float() for o in out] if isinstance(out, list) else out.float()
         return out

@@ -745,8 +745,10 @@ class VSSMEncoder(nn.Module):
             self.layers.append(nn.Sequential(OrderedDict(blocks=nn.Sequential(*blocks))))
         self.apply(_init_weights)
 
-    def _forward_cl(self, x_img):
-        """x_img: NCHW image batch.  Returns [image, s1, s2, s3, s4] with s* channels-last (B,H,W,C)."""
+    def _forward_cl(self, x_img, on_stage=None):
+        """x_img: NCHW image batch.  Returns [image, s1, s2, s3, s4] with s* channels-last (B,H,W,C).
+        on_stage(i, feature) is called as soon as stage i's output exists (the decoder's guide branch of that
+        resolution starts there, on its own stream)."""
         feats = [x_img]
         pe = self.patch_embed
         if (_infer(x_img, pe[0].weight) and pe[0].in_channels == 3 and pe[0].out_channels == 64
@@ -763,6 +765,8 @@ class VSSMEncoder(nn.Module):
             for blk in layer.blocks:
                 x = blk._forward_cl(x)
             feats.append(x)
+            if on_stage is not None:
+                on_stage(s, x)
             if s < self.num_layers - 1:
                 ds = self.downsample[s]
                 x = ds[3]._forward_cl(_conv_cl(ds[1], x))
