@@ -143,6 +143,16 @@ int tramba_layernorm_cl(const void *x, const float *w, const float *b, void *y, 
 /* x: (B, H, W, P*P*C) -> y: (B, H*P, W*P, C) with y[b,hP+p1,wP+p2,:] = LN(x[b,h,w,(p1*P+p2)*C : +C]). */
 int tramba_shuffle_norm_cl(const void *x, const float *w, const float *b, void *y, int batch, int h,
                            int wd, int c, int p, float eps, int dtype, void *stream);
+/* shuffle_norm followed by a 1x1 convolution to ONE channel (FinalPatchExpand_X4 + the full-resolution
+ * seg_layers head, Trambav6.py:132-137): y (B, H*P, W*P) f32 = <LayerNorm(shuffled row) rounded to dtype, head_w>
+ * + head_b.  The normalised (B, H*P, W*P, C) map is never written. */
+int tramba_shuffle_norm_head_cl(const void *x, const float *w, const float *b, const float *head_w, float head_b,
+                                float *y, int batch, int h, int wd, int c, int p, float eps, int dtype,
+                                void *stream);
+/* y[row] = <x[row, :], w> + bias: nn.Conv2d(C, 1, 1) on a channels-last map (decoder seg_layers,
+ * Trambav6.py:62,67).  x (rows, C) dtype, w (C) f32, y (rows) f32. */
+int tramba_rowdot_cl(const void *x, const float *w, float bias, float *y, int64_t rows, int c, int dtype,
+                     void *stream);
 /* Depth-wise stencils take TAP-MAJOR weights wt (ks*ks, C) f32 + bias bt (C) f32 produced by
  * tramba_dw_pack from the reference layout w (C, ks, ks), bias (C) or NULL.  With w3/b3/w5/b5
  * non-NULL (ks = 7) it packs the multi-scale stencil of DWMSMlp: identity + 3x3 + 5x5 + 7x7 folded

@@ -281,3 +281,39 @@ def test_two_stream_concurrency_is_bitwise_stable():
                 torch.cuda.synchronize()
                 assert all(torch.equal(o, ref) for o in outs), (name, dtype)
                 del keep
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rc", [(1000, 128), (77, 512), (4096, 256), (13, 1024), (300, 40)])
+def test_rowdot_cl(dtype, rc):
+    """nn.Conv2d(C, 1, 1) on channels-last rows (decoder seg heads, Trambav6.py:62,67)."""
+    rows, c = rc
+    g = torch.Generator().manual_seed(rows + c)
+    x = torch.randn(rows, c, generator=g).to(dtype)
+    w = torch.randn(c, generator=g) * c ** -0.5
+    got = hip().rowdot_cl(x.to(DEV), w.to(DEV), 0.37)
+    want = x.double() @ w.double() + 0.37
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=1e-5, atol=1e-5 if dtype == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 6, 128, 4), (1, 5, 64, 2), (1, 12, 128, 4)])
+def test_shuffle_norm_head_cl(dtype, cfg):
+    """FinalPatchExpand_X4's shuffle + LayerNorm fused with the 1x1 head == shuffle_norm_cl followed by rowdot."""
+    b, h, c, p = cfg
+    H = hip()
+    g = torch.Generator().manual_seed(h * c + p)
+    x = torch.randn(b, h, h, p * p * c, generator=g).to(dtype).to(DEV)
+    lw, lb = (1 + 0.1 * torch.randn(c, generator=g)).to(DEV), (0.1 * torch.randn(c, generator=g)).to(DEV)
+    hw = (torch.randn(c, generator=g) * c ** -0.5).to(DEV)
+    got = H.shuffle_norm_head_cl(x, lw, lb, hw, -0.21, p)
+    mid = H.shuffle_norm_cl(x, lw, lb, p)                      # (B, H*P, W*P, C), rounded to dtype like the fused path
+    want = H.rowdot_cl(mid, hw, -0.21)
+    assert got.shape == (b, h * p, h * p)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # and against the oracle's composition in fp64
+    y = x.double().cpu().view(b, h, h, p, p, c).permute(0, 1, 3, 2, 4, 5).reshape(b, h * p, h * p, c)
+    y = F.layer_norm(y, (c,), lw.double().cpu(), lb.double().cpu(), 1e-5)
+    ref = y @ hw.double().cpu() - 0.21
+    np.testing.assert_allclose(got.cpu().double().numpy(), ref.numpy(), rtol=2e-2 if dtype != torch.float32 else 1e-4,
+                               atol=2e-2 if dtype != torch.float32 else 1e-4)

@@ -74,7 +74,8 @@ template <typename T, int V, int LPR>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const T *__restrict__ x, const float *__restrict__ w,
                                                             const float *__restrict__ bvec, T *__restrict__ y,
                                                             long rows, int C, float eps, int act, int P, int H,
-                                                            int W)
+                                                            int W, const float *__restrict__ head_w, float head_b,
+                                                            float *__restrict__ head_out)
 {
     constexpr int RPW = kWave / LPR;
     const int lane = threadIdx.x & (kWave - 1);
@@ -119,12 +120,49 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const T *__restrict
     load_pack<float, V>(bvec + c0, bv);
 #pragma unroll
     for (int i = 0; i < V; ++i) o[i] = apply_act((v[i] - mean) * rstd * wv[i] + bv[i], act);
+    if (head_w) {   // fused 1x1 "segmentation" head (C -> 1): the normalised row never reaches memory
+        float hv[V], d = 0.f;
+        load_pack<float, V>(head_w + c0, hv);
+#pragma unroll
+        for (int i = 0; i < V; ++i) d = fmaf(Cvt<T>::to_f(Cvt<T>::from_f(o[i])), hv[i], d);   // as if stored in T
+#pragma unroll
+        for (int of = LPR / 2; of > 0; of >>= 1) d += __shfl_xor(d, of, LPR);
+        if (sub == 0) head_out[orow] = d + head_b;
+        return;
+    }
     store_pack<T, V>(y + orow * C + c0, o);
+}
+
+// y[row] = <x[row, :], w> + b   (a 1x1 convolution to ONE channel: the decoder's deep-supervision heads)
+template <typename T, int V, int LPR>
+__global__ __launch_bounds__(256) void rowdot_rows_kernel(const T *__restrict__ x, const float *__restrict__ w, float b,
+                                                         float *__restrict__ y, long rows, int C)
+{
+    constexpr int RPW = kWave / LPR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int sub = lane % LPR;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long row = wave * RPW + lane / LPR;
+    const bool rok = row < rows;
+    float d = 0.f;
+    for (int c0 = sub * V; c0 < C; c0 += LPR * V) {   // LPR * V divides C (host-checked)
+        float v[V], wv[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = 0.f;
+        if (rok) load_pack<T, V>(x + row * C + c0, v);
+        load_pack<float, V>(w + c0, wv);
+#pragma unroll
+        for (int i = 0; i < V; ++i) d = fmaf(v[i], wv[i], d);
+    }
+#pragma unroll
+    for (int of = LPR / 2; of > 0; of >>= 1) d += __shfl_xor(d, of, LPR);
+    if (rok && sub == 0) y[row] = d + b;
 }
 
 template <typename T>
 static int launch_layernorm(const void *x, const float *w, const float *b, void *y, long rows, int c,
-                            float eps, int act, int P, int H, int W, hipStream_t s)
+                            float eps, int act, int P, int H, int W, hipStream_t s,
+                            const float *head_w = nullptr, float head_b = 0.f, float *head_out = nullptr)
 {
     constexpr int VM = sizeof(T) == 2 ? 8 : 4;
     if (c % VM == 0 && c / VM <= kWave && aligned16(w) && aligned16(b)) {
@@ -135,7 +173,7 @@ static int launch_layernorm(const void *x, const float *w, const float *b, void 
         dim3 grid((unsigned)((waves + 3) / 4)), block(256);
 #define GOR_(L_)                                                                                            \
     hipLaunchKernelGGL((layernorm_rows_kernel<T, VM, L_>), grid, block, 0, s, (const T *)x, w, b, (T *)y, rows, c, \
-                       eps, act, P, H, W)
+                       eps, act, P, H, W, head_w, head_b, head_out)
         switch (lpr) {
         case 1: GOR_(1); break;
         case 2: GOR_(2); break;
@@ -148,6 +186,10 @@ static int launch_layernorm(const void *x, const float *w, const float *b, void 
 #undef GOR_
         TRAMBA_LAUNCH_CHECK();
         return TRAMBA_OK;
+    }
+    if (head_w) {
+        set_error("shuffle_norm_head: C=%d needs C %% %d == 0 and C <= %d", c, VM, kWave * VM);
+        return TRAMBA_ERR_UNSUPPORTED;
     }
     const int maxv = sizeof(T) == 2 ? 8 : 4;
     const int v = norm_vec(c, maxv);
@@ -166,6 +208,30 @@ static int launch_layernorm(const void *x, const float *w, const float *b, void 
     default: GO_(1); break;
     }
 #undef GO_
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+template <typename T>
+static int launch_rowdot(const void *x, const float *w, float bias, float *y, long rows, int c, hipStream_t s)
+{
+    constexpr int VM = sizeof(T) == 2 ? 8 : 4;
+    TRAMBA_CHECK(c % VM == 0, "rowdot_cl: C=%d must be a multiple of %d", c, VM);
+    int lpr = 1;   // lanes per row: the largest power of two <= 64 with lpr * VM dividing C
+    while (lpr < kWave && c % (2 * lpr * VM) == 0) lpr <<= 1;
+    const long waves = (rows + (kWave / lpr) - 1) / (kWave / lpr);
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define GOD_(L_) hipLaunchKernelGGL((rowdot_rows_kernel<T, VM, L_>), grid, block, 0, s, (const T *)x, w, bias, y, rows, c)
+    switch (lpr) {
+    case 1: GOD_(1); break;
+    case 2: GOD_(2); break;
+    case 4: GOD_(4); break;
+    case 8: GOD_(8); break;
+    case 16: GOD_(16); break;
+    case 32: GOD_(32); break;
+    default: GOD_(64); break;
+    }
+#undef GOD_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
@@ -308,6 +374,30 @@ extern "C" int tramba_shuffle_norm_cl(const void *x, const float *w, const float
     const long rows = (long)batch * h * wd * p * p;
     TRAMBA_DISPATCH_DTYPE(dtype, T,
         return launch_layernorm<T>(x, w, b, y, rows, c, eps, TRAMBA_ACT_NONE, p, h, wd, (hipStream_t)stream));
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_shuffle_norm_head_cl(const void *x, const float *w, const float *b, const float *head_w,
+                                           float head_b, float *y, int batch, int h, int wd, int c, int p, float eps,
+                                           int dtype, void *stream)
+{
+    TRAMBA_CHECK(x && w && b && head_w && y, "shuffle_norm_head_cl: null tensor");
+    TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0 && p >= 1, "shuffle_norm_head_cl: empty shape");
+    TRAMBA_CHECK(aligned16(x) && aligned16(head_w), "shuffle_norm_head_cl: tensors must be 16-byte aligned");
+    const long rows = (long)batch * h * wd * p * p;
+    TRAMBA_DISPATCH_DTYPE(dtype, T,
+        return launch_layernorm<T>(x, w, b, nullptr, rows, c, eps, TRAMBA_ACT_NONE, p, h, wd, (hipStream_t)stream,
+                                   head_w, head_b, y));
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_rowdot_cl(const void *x, const float *w, float bias, float *y, int64_t rows, int c, int dtype,
+                                void *stream)
+{
+    TRAMBA_CHECK(x && w && y, "rowdot_cl: null tensor");
+    TRAMBA_CHECK(rows > 0 && c > 0, "rowdot_cl: empty shape");
+    TRAMBA_CHECK(aligned16(x) && aligned16(w), "rowdot_cl: tensors must be 16-byte aligned");
+    TRAMBA_DISPATCH_DTYPE(dtype, T, return launch_rowdot<T>(x, w, bias, y, (long)rows, c, (hipStream_t)stream));
     return TRAMBA_OK;
 }
 

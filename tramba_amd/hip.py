@@ -7,6 +7,7 @@ the library is missing or the tensors are not on a HIP device the call raises.
 import ctypes
 import os
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -46,6 +47,8 @@ SIGNATURES = {
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_shuffle_norm_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_f, c_int, c_vp]),
+    "tramba_shuffle_norm_head_cl": (c_int, [c_vp] * 4 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
+    "tramba_rowdot_cl": (c_int, [c_vp, c_vp, c_f, c_vp, c_i64, c_int, c_int, c_vp]),
     "tramba_dw_pack": (c_int, [c_vp] * 8 + [c_int] * 2 + [c_vp]),
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
@@ -111,11 +114,28 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_f32_cache = {}
+
+
 def _f32(t):
+    """fp32 contiguous view of a parameter / buffer.  16-bit parameters (prepare_inference) are converted ONCE per
+    (object, version, storage): a cast kernel per bias per call was ~10 launches of every forward."""
     if t is None:
         return None
-    t = t.detach()
-    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t.detach()
+    key = id(t)
+    ver = (t._version, t.data_ptr(), t.dtype)
+    hit = _f32_cache.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is t:
+        return hit[1]
+    conv = t.detach().float().contiguous()
+    try:
+        ref = weakref.ref(t, lambda _r, k=key: _f32_cache.pop(k, None))
+    except TypeError:
+        return conv
+    _f32_cache[key] = (ver, conv, ref)
+    return conv
 
 
 # ----------------------------------------------------------------------------- tables
@@ -325,6 +345,26 @@ def shuffle_norm_cl(x, w, b, p, eps=1e-5):
     y = torch.empty((bb, h * p, wd * p, c), dtype=x.dtype, device=x.device)
     _check(lib().tramba_shuffle_norm_cl(_ptr(x), _ptr(w), _ptr(b), _ptr(y), bb, h, wd, c, p, eps, dt(x), _stream()),
            "shuffle_norm_cl")
+    return y
+
+
+def shuffle_norm_head_cl(x, w, b, head_w, head_b: float, p, eps=1e-5):
+    """x: (B, H, W, P*P*C) -> (B, H*P, W*P) f32: pixel-shuffle + LayerNorm over C + dot with head_w (C) + head_b."""
+    _dev(x, w, b, head_w)
+    bb, h, wd, cc = x.shape
+    c = cc // (p * p)
+    y = torch.empty((bb, h * p, wd * p), dtype=torch.float32, device=x.device)
+    _check(lib().tramba_shuffle_norm_head_cl(_ptr(x), _ptr(w), _ptr(b), _ptr(head_w), float(head_b), _ptr(y), bb, h, wd,
+                                             c, p, eps, dt(x), _stream()), "shuffle_norm_head_cl")
+    return y
+
+
+def rowdot_cl(x, w, bias: float):
+    """x: (..., C); w: (C) f32 -> (...) f32 = <x, w> + bias."""
+    _dev(x, w)
+    c = x.shape[-1]
+    y = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    _check(lib().tramba_rowdot_cl(_ptr(x), _ptr(w), float(bias), _ptr(y), x.numel() // c, c, dt(x), _stream()), "rowdot_cl")
     return y
 
 

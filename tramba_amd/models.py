@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import hip
 from .modules import (FinalPatchExpand_X4, FreqBlockv6, LayerNorm2d, Linear2d, MultiScaleDecoderBlock, PatchExpand,
-                      VSSMEncoder, _init_weights, _need_device, from_cl, load_pretrained_Base, to_cl)
+                      VSSMEncoder, _infer, _init_weights, _need_device, from_cl, load_pretrained_Base, to_cl)
 from .ops import CrossMerge_Line, CrossScan_Line
 
 
@@ -29,6 +29,19 @@ def _side_stream(device):
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=device)
     return st
+
+
+def _bias_scalar(conv: nn.Conv2d) -> float:
+    """The single bias of a C -> 1 head as a Python float, cached per parameter version (a .item() per forward
+    would synchronise the stream and cannot be captured into a graph)."""
+    b = conv.bias
+    if b is None:
+        return 0.0
+    key = (b._version, b.data_ptr())
+    hit = conv.__dict__.get("_tramba_bias_scalar")
+    if hit is None or hit[0] != key:
+        hit = conv.__dict__["_tramba_bias_scalar"] = (key, float(b.detach().float().item()))
+    return hit[1]
 
 
 class VSSMDecoder(nn.Module):
@@ -72,10 +85,24 @@ class VSSMDecoder(nn.Module):
 
     @staticmethod
     def _seg_cl(conv: nn.Conv2d, x):
-        """1x1 conv C -> 1 on a channels-last map; returns NCHW logits (B,1,H,W)."""
+        """1x1 conv C -> 1 on a channels-last map; returns NCHW logits (B,1,H,W) (fp32 from the HIP kernel)."""
+        if _infer(x, conv.weight) and x.shape[-1] % 8 == 0:
+            y = hip.rowdot_cl(x, hip._f32(conv.weight).view(-1), _bias_scalar(conv))
+            return y.unsqueeze(1)
         w = conv.weight.view(1, -1).to(x.dtype)
         y = F.linear(x, w, conv.bias.to(x.dtype))
         return y.permute(0, 3, 1, 2)
+
+    def _final_cl(self, x_low):
+        """Last decoder stage: FinalPatchExpand_X4 -> (Identity) -> seg head.  Inference fuses pixel-shuffle +
+        LayerNorm + the 1x1 head, so the (B, 4H, 4W, C) map is never materialised (Trambav6.py:132-137)."""
+        fin, conv = self.expand_layers[-1], self.seg_layers[-1]
+        if _infer(x_low, conv.weight) and isinstance(self.stage_layers[-1], nn.Identity) and fin.output_dim % 8 == 0:
+            xe = fin.expand._forward_cl(x_low)
+            y = hip.shuffle_norm_head_cl(xe, hip._f32(fin.norm.weight), hip._f32(fin.norm.bias),
+                                         hip._f32(conv.weight).view(-1), _bias_scalar(conv), fin.scale, fin.norm.eps)
+            return y.unsqueeze(1)
+        return self._seg_cl(conv, fin._forward_cl(x_low))
 
     def _forward_cl(self, skips_cl, guides=None):
         """skips_cl: [image, s1..sn] with s* channels-last.  Trambav6.py:114-139.
@@ -85,6 +112,9 @@ class VSSMDecoder(nn.Module):
         outs = []
         n = len(self.stage_layers)
         for s in range(n):
+            if s == n - 1:
+                outs.append(self._final_cl(x_low))
+                break
             x = self.expand_layers[s]._forward_cl(x_low)
             if s < n - 1:
                 if guides is not None and s in guides:
