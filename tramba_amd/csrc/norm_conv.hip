@@ -11,6 +11,9 @@
 //                     the four linear terms are ONE 7x7 depth-wise stencil (identity + 3x3 + 5x5 +
 //                     7x7 summed at pack time), so h is read once.
 // Lanes map to channels with 4..16-byte accesses.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "norm.h"
 
@@ -330,11 +333,145 @@ __global__ __launch_bounds__(256) void dwconv_cl_kernel(const T *__restrict__ x,
     }
 }
 
+// thread = 4 channels x TW consecutive output columns of one row.
+// The stencil is issue-bound (784 FMAs per thread at 7x7), so nothing but the FMAs and the unavoidable 16-bit
+// -> fp32 conversions may cost VALU: every load goes through a buffer descriptor with ONE per-thread byte
+// offset per column computed up front (the out-of-range offset where the column falls outside the image);
+// the row (dy) and tap offsets ride in the scalar offset; rows outside the image swap in the out-of-range
+// offset with one v_cndmask per load.  No 64-bit address arithmetic, no branches around loads.
+typedef float dw_v2f __attribute__((ext_vector_type(2)));
+typedef float dw_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned dw_v2u __attribute__((ext_vector_type(2)));
+
+// 4 channels of one pixel as loaded (raw bits; converted where consumed, so a prefetched row does not make
+// hipcc wait for it at the load site)
+template <typename T> struct DwRaw { dw_v2u v; };
+template <> struct DwRaw<float> { dw_v4f v; };
+
+template <typename T>
+__device__ __forceinline__ DwRaw<T> dw_load4(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    DwRaw<T> o;
+    if constexpr (sizeof(T) == 4) {
+        o.v = __builtin_bit_cast(dw_v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    } else {
+        o.v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+    }
+    return o;
+}
+
+template <typename T>
+__device__ __forceinline__ void dw_cvt4(const DwRaw<T> &raw, float (&out)[4])
+{
+    if constexpr (sizeof(T) == 4) {
+        out[0] = raw.v.x; out[1] = raw.v.y; out[2] = raw.v.z; out[3] = raw.v.w;
+    } else {
+        const Pack<T, 4> pk = __builtin_bit_cast(Pack<T, 4>, raw.v);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) out[v] = Cvt<T>::to_f(pk.v[v]);
+    }
+}
+
+template <typename T, int KS, int TW>
+__global__ __launch_bounds__(256) void dwconv4_cl_kernel(const T *__restrict__ x, const float *__restrict__ wt,
+                                                        const float *__restrict__ bt, T *__restrict__ y, int B,
+                                                        int H, int W, int C, int act)
+{
+    constexpr int V = 4, R = KS / 2, NI = TW + KS - 1;
+    // grid (x: channel-group x column-tile items of one row, y: row, z: image): no 64-bit index arithmetic (the
+    // flat-index form spent ~3k cycles per wave in three emulated 64-bit divisions)
+    const int cg = C / V, wtiles = (W + TW - 1) / TW;
+    unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = item < (unsigned)(cg * wtiles);
+    if (!live) item = (unsigned)(cg * wtiles) - 1u;   // keep the wave whole: dead lanes recompute the last item, never store
+    const int c0 = (int)(item % (unsigned)cg) * V;
+    const int w0 = (int)(item / (unsigned)cg) * TW;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+
+    const unsigned rowb = (unsigned)W * (unsigned)C * (unsigned)sizeof(T);   // bytes per image row
+    const unsigned colb = (unsigned)C * (unsigned)sizeof(T);                // bytes per pixel
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * H * W * C, (unsigned)H * rowb);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(wt, (unsigned)(KS * KS) * (unsigned)C * 4u);
+
+    // byte offset of (row h - R, column w0 - R + i, channel c0); out of range where the column is outside
+    unsigned voff[NI];
+    const int base = ((h - R) * W + (w0 - R)) * C + c0;   // may be negative: only used where the column is valid
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int wx = w0 - R + i;
+        voff[i] = (wx >= 0 && wx < W) ? (unsigned)((base + i * C) * (int)sizeof(T)) : kOutOfRange;
+    }
+    const unsigned woff = (unsigned)c0 * 4u;
+
+    dw_v2f acc[TW][2];
+    {
+        float bs[V];
+        load_pack<float, V>(bt + c0, bs);
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            acc[t][0] = dw_v2f{bs[0], bs[1]};
+            acc[t][1] = dw_v2f{bs[2], bs[3]};
+        }
+    }
+    // One row of taps at a time, the NEXT row's pixels already in flight (2 static register slots, the dy loop
+    // runs in pairs and is NOT unrolled further: fully unrolled, hipcc hoists all KS*KS weight loads and
+    // KS*(TW+KS-1) row loads to the top -- 438 VGPRs at 7x7, spilling into AGPRs).
+    static_assert(KS % 2 == 1, "odd stencils");
+    DwRaw<T> raw[2][NI];
+    auto issue = [&](int dy, DwRaw<T> (&r)[NI]) {
+        const int hy = h + dy - R;
+        const bool rowok = hy >= 0 && hy < H;
+        // (h - R) * W may be negative, i.e. voff wrapped: adding dy * rowb brings a valid row back into range in
+        // 32-bit arithmetic, so the sum is formed in the VECTOR offset (range-checked), not in soffset
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            r[i] = dw_load4<T>(rx, (rowok && voff[i] != kOutOfRange) ? voff[i] + (unsigned)dy * rowb : kOutOfRange);
+    };
+    auto compute = [&](int dy, const DwRaw<T> (&r)[NI]) {
+        float xin[NI][V];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) dw_cvt4<T>(r[i], xin[i]);
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) {
+            const dw_v4f v = __builtin_bit_cast(
+                dw_v4f, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, (unsigned)(dy * KS + dx) * (unsigned)C * 4u, 0));
+            const dw_v2f w01 = {v.x, v.y}, w23 = {v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                acc[t][0] = dw_v2f{xin[t + dx][0], xin[t + dx][1]} * w01 + acc[t][0];
+                acc[t][1] = dw_v2f{xin[t + dx][2], xin[t + dx][3]} * w23 + acc[t][1];
+            }
+        }
+    };
+    issue(0, raw[0]);
+#pragma unroll 1
+    for (int dy = 0; dy + 1 < KS; dy += 2) {
+        issue(dy + 1, raw[1]);
+        compute(dy, raw[0]);
+        issue(dy + 2, raw[0]);   // dy + 2 <= KS - 1 for every trip (KS odd)
+        compute(dy + 1, raw[1]);
+    }
+    compute(KS - 1, raw[0]);
+    if (!live) return;
+    T *yb = y + (long)b * H * W * C + c0;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        if (w0 + t < W) {
+            float o[V] = {apply_act(acc[t][0].x, act), apply_act(acc[t][0].y, act), apply_act(acc[t][1].x, act),
+                          apply_act(acc[t][1].y, act)};
+            store_pack<T, V>(yb + ((long)h * W + w0 + t) * C, o);
+        }
+    }
+}
+
 template <typename T, int KS>
 static int launch_dw(const void *x, const float *wt, const float *bt, void *y, int B, int H, int W, int C, int act,
                      hipStream_t s)
 {
-    constexpr int TW = 4;
+    // columns per thread: the stencil is L1/TA-bandwidth bound (every thread re-reads the ks*ks taps and ks rows
+    // of TW + ks - 1 pixels), so the wide 7x7 amortises them over 8 outputs; 3x3 / 5x5 keep 4 (more threads)
+    constexpr int TW = KS >= 7 ? 8 : 4;
     const int wtiles = (W + TW - 1) / TW;
     const int v = (C % 4 == 0) ? 4 : ((C % 2 == 0) ? 2 : 1);
     const long nthreads = (long)(C / v) * wtiles * H * B;
@@ -342,6 +479,14 @@ static int launch_dw(const void *x, const float *wt, const float *bt, void *y, i
 #define GO_(V_)                                                                                            \
     hipLaunchKernelGGL((dwconv_cl_kernel<T, KS, V_, TW>), grid, block, 0, s, (const T *)x, wt, bt, (T *)y, B, H, W, \
                        C, act, nthreads)
+    // buffer-addressed kernel: 4 channels per lane, every wave inside one image, 32-bit byte offsets
+    static const bool legacy = getenv("TRAMBA_DWCONV") && strcmp(getenv("TRAMBA_DWCONV"), "legacy") == 0;
+    if (!legacy && v == 4 && H <= 65535 && B <= 65535 && (double)H * W * C * sizeof(T) < 2147483648.0) {
+        dim3 g3((unsigned)(((long)(C / 4) * wtiles + 255) / 256), (unsigned)H, (unsigned)B);
+        hipLaunchKernelGGL((dwconv4_cl_kernel<T, KS, TW>), g3, block, 0, s, (const T *)x, wt, bt, (T *)y, B, H, W, C, act);
+        TRAMBA_LAUNCH_CHECK();
+        return TRAMBA_OK;
+    }
     if (v == 4) GO_(4);
     else if (v == 2) GO_(2);
     else GO_(1);
