@@ -47,13 +47,13 @@ __global__ __launch_bounds__(256) void layernorm_cl_kernel(const T *__restrict__
     wave_layernorm<V>(acc, nit, C, lane, eps, mean, rstd);
     long orow = row;
     if (P > 1) {
-        const int pp = (int)(row % (P * P));
-        const long pix = row / (P * P);
-        const int wi = (int)(pix % W);
-        const long bh = pix / W;  // b*H + h
-        const int hi = (int)(bh % H);
-        const long b = bh / H;
-        orow = (b * (long)(H * P) + (long)hi * P + pp / P) * (long)(W * P) + (long)wi * P + pp % P;
+        // 32-bit index arithmetic (rows < 2^31, host-checked): six emulated 64-bit divisions per lane were most of
+        // this kernel's instructions
+        const unsigned r32u = (unsigned)row, pp2 = (unsigned)(P * P);
+        const unsigned pp = r32u % pp2, pix = r32u / pp2;
+        const unsigned wi = pix % (unsigned)W, bh = pix / (unsigned)W;
+        const unsigned hi = bh % (unsigned)H, b = bh / (unsigned)H;
+        orow = ((long)b * (H * P) + (long)(hi * P + pp / P)) * (long)(W * P) + (long)(wi * P + pp % P);
     }
     T *yr = y + orow * C;
 #pragma unroll
@@ -110,13 +110,13 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const T *__restrict
     if (!(rok && cok)) return;
     long orow = row;
     if (P > 1) {
-        const int pp = (int)(row % (P * P));
-        const long pix = row / (P * P);
-        const int wi = (int)(pix % W);
-        const long bh = pix / W;
-        const int hi = (int)(bh % H);
-        const long b = bh / H;
-        orow = (b * (long)(H * P) + (long)hi * P + pp / P) * (long)(W * P) + (long)wi * P + pp % P;
+        // 32-bit index arithmetic (rows < 2^31, host-checked): six emulated 64-bit divisions per lane were most of
+        // this kernel's instructions
+        const unsigned r32u = (unsigned)row, pp2 = (unsigned)(P * P);
+        const unsigned pp = r32u % pp2, pix = r32u / pp2;
+        const unsigned wi = pix % (unsigned)W, bh = pix / (unsigned)W;
+        const unsigned hi = bh % (unsigned)H, b = bh / (unsigned)H;
+        orow = ((long)b * (H * P) + (long)(hi * P + pp / P)) * (long)(W * P) + (long)(wi * P + pp % P);
     }
     float wv[V], bv[V], o[V];
     load_pack<float, V>(w + c0, wv);
@@ -168,6 +168,10 @@ static int launch_layernorm(const void *x, const float *w, const float *b, void 
                             const float *head_w = nullptr, float head_b = 0.f, float *head_out = nullptr)
 {
     constexpr int VM = sizeof(T) == 2 ? 8 : 4;
+    if (rows >= 2147483647L) {
+        set_error("layernorm: %ld rows exceed the 32-bit row index of this build", rows);
+        return TRAMBA_ERR_UNSUPPORTED;
+    }
     if (c % VM == 0 && c / VM <= kWave && aligned16(w) && aligned16(b)) {
         const int need = c / VM;
         int lpr = 1;

@@ -528,11 +528,13 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long gid = (long)blockIdx.x * 4 + wv;
     if (gid >= nwaves) return;  // wave-uniform, the kernel has no barriers
-    const int sgm = (int)(gid % NSEG);
-    long rt = gid / NSEG;
-    const int ctile = (int)(rt % CT);
-    rt /= CT;
-    const int k = (int)(rt % K), b = (int)(rt / K);
+    // (32-bit: nwaves < 2^31, host-checked -- emulated 64-bit divisions cost hundreds of instructions per wave)
+    const unsigned g32 = (unsigned)gid;
+    const int sgm = (int)(g32 % (unsigned)NSEG);
+    unsigned rt = g32 / (unsigned)NSEG;
+    const int ctile = (int)(rt % (unsigned)CT);
+    rt /= (unsigned)CT;
+    const int k = (int)(rt % (unsigned)K), b = (int)(rt / (unsigned)K);
 
     const int r32 = lane & 31, hi = lane >> 5;
     const int c = ctile * kTP + r32;
@@ -660,8 +662,8 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_stream_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const long wid = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wid >= nwaves) return;   // wave-uniform, no barriers below
-    const int b = (int)(wid / nchunk);
-    const int pl0 = (int)(wid % nchunk) * P;
+    const int b = (int)((unsigned)wid / (unsigned)nchunk);   // 32-bit: nwaves < 2^31 (host-checked)
+    const int pl0 = (int)((unsigned)wid % (unsigned)nchunk) * P;
     const int np = L - pl0 < P ? L - pl0 : P;   // pixels of this wave
 
     // CSR window: pointers of pixels pl0 .. pl0+np in lanes 0..np, then 64 entries from the first one
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_cl_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const long pix = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (pix >= npix) return;
-    const int b = (int)(pix / L), p = (int)(pix % L);
+    const int b = (int)((unsigned)pix / (unsigned)L), p = (int)((unsigned)pix % (unsigned)L);   // npix < 2^31
     float acc[kNormMaxIt][V];
 #pragma unroll
     for (int it = 0; it < kNormMaxIt; ++it)
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_split_kernel(
     long pix = (long)blockIdx.x * PPB + pb;
     const bool live = pix < npix;              // wave-uniform; dead waves still join the barriers
     if (!live) pix = npix - 1;
-    const int b = (int)(pix / L), p = (int)(pix % L);
+    const int b = (int)((unsigned)pix / (unsigned)L), p = (int)((unsigned)pix % (unsigned)L);   // npix < 2^31
     float acc[NITW][V];
 #pragma unroll
     for (int it = 0; it < NITW; ++it)
@@ -1072,6 +1074,7 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
     TRAMBA_CHECK(ys_dtype == TRAMBA_F32 || ys_dtype == dtype, "ss2d_merge_norm_cl: ys must be f32 or dtype");
     hipStream_t s = (hipStream_t)stream;
     const long npix = (long)batch * l;
+    TRAMBA_CHECK(npix < 2147483647L, "ss2d_merge_norm_cl: B*L exceeds the 32-bit pixel index of this build");
     // vector width: largest of 4/2/1 dividing D such that the row fits kNormMaxIt iterations
     int v = (d % 4 == 0) ? 4 : ((d % 2 == 0) ? 2 : 1);
     TRAMBA_CHECK((d + kWave * v - 1) / (kWave * v) <= kNormMaxIt, "ss2d_merge_norm_cl: D=%d too large", d);
