@@ -142,12 +142,22 @@ struct TileOps {
 // Arithmetic per element (the kernels are VALU-bound, so every instruction here was counted):
 //   x' = (dt_raw + bias) * log2(e)   straight out of the MFMA: log2(e) is folded into the dt_w fragments and
 //                                    the accumulator starts at bias * log2(e)
-//   t  = max(x', log2(1 + exp2(min(x', 86))))          = softplus(dt_raw + bias) * log2(e)
+//   t  = x' > 30 ? x' : log2(1 + exp2(x'))             = softplus(dt_raw + bias) * log2(e)
 //        (the reference's threshold form, x > 20 -> x, equals this to below fp32 resolution)
 //   a  = exp2(t * A)                                   = exp(dt * A)
 //   bb = t * (B*ln2 * u)                               = dt * B * u      (ln2 folded into the staged B)
 // i.e. 3 transcendentals + min, max and 4 packed-able mul/add per element.  Positions past the end of the
 // sequence start the accumulator at -1e30 instead: t = 0 exactly, hence a = 1, bb = 0 (the identity).
+// lower-half / upper-half broadcast of a wave-wide value (gfx950 v_permlane32_swap)
+__device__ __forceinline__ void half_swap(float x, float &lower, float &upper)
+{
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    const unsigned lo = r[0], up = r[1];
+    lower = __builtin_bit_cast(float, lo);
+    upper = __builtin_bit_cast(float, up);
+}
+
 template <typename T, int NK, bool SPLIT>
 struct ScanWave {
     frag8_t wh[NK], wl[NK];  // dt_w[k][channel][16kk + 8hi + j] * log2(e), bf16 hi (+ lo residual)
@@ -269,9 +279,11 @@ struct ScanWave {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const v2f xr = {acc[r], acc[r + 1]};
-            v2f z = {__builtin_amdgcn_exp2f(fminf(xr.x, 86.f)), __builtin_amdgcn_exp2f(fminf(xr.y, 86.f))};
+            // x' > 30: log2(1 + 2^x') == x' to below fp32 resolution (and 2^x' may overflow to +inf, whose log2 is
+            // discarded by the select) -- one compare + select instead of min, max and an IEEE canonicalize
+            v2f z = {__builtin_amdgcn_exp2f(xr.x), __builtin_amdgcn_exp2f(xr.y)};
             z = z + one;
-            const v2f t = {fmaxf(xr.x, __builtin_amdgcn_logf(z.x)), fmaxf(xr.y, __builtin_amdgcn_logf(z.y))};
+            const v2f t = {xr.x > 30.f ? xr.x : __builtin_amdgcn_logf(z.x), xr.y > 30.f ? xr.y : __builtin_amdgcn_logf(z.y)};
             const v2f e = t * av;
             a[r] = __builtin_amdgcn_exp2f(e.x);
             a[r + 1] = __builtin_amdgcn_exp2f(e.y);
@@ -303,9 +315,11 @@ struct ScanWave {
         tH = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float oa = __shfl_xor(sa[g], 32, 64), oh = __shfl_xor(sh[g], 32, 64);
-            const float ea = hi ? oa : sa[g], eh = hi ? oh : sh[g];   // run 2g   (lower half-wave)
-            const float fa = hi ? sa[g] : oa, fh = hi ? sh[g] : oh;   // run 2g+1 (upper half-wave)
+            // v_permlane32_swap(X, X): first result = X's lower half in both halves, second = its upper half --
+            // both half-waves' run aggregates in one instruction each, no LDS permute, no selects
+            float ea, eh, fa, fh;   // run 2g (lower half-wave) / run 2g+1 (upper half-wave)
+            half_swap(sa[g], ea, fa);
+            half_swap(sh[g], eh, fh);
             const float midH = fmaf(ea, tH, eh), midA = ea * tA;
             preA[g] = hi ? midA : tA;
             preH[g] = hi ? midH : tH;
