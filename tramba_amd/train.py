@@ -4,7 +4,10 @@ loss:       train.py:76-85 -- every output bilinearly resized to the label size,
             binary_cross_entropy_with_logits + iou_loss (utils/loss.py:6-11), weights 1.
 optimizer:  train.py:266-280 -- Adam, parameters whose name contains "encoder" at 0.1 x lr.
 lr decay:   utils/lr.py:1-17.
+epoch loop, resume / best-MAE checkpoint files: train.py:212-263.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -63,3 +66,69 @@ def train_step(model, opt, images, label, reducer=None):
         reducer.finish()
     opt.step()
     return loss.detach()
+
+
+# ----------------------------------------------------------------------------- checkpoints / epoch loop
+# File formats and names of the reference's `fit` (train.py:212-263), so checkpoints interoperate both ways:
+#   <save_model>/<method>/<method>_resume.pth           {"model": state_dict, "optimizer": state_dict, "epoch": e}
+#   <save_model>/<method>/<method>_MAE_<mae>_<e+1>.pth   bare state_dict of a best-MAE epoch
+def _ckpt_dir(save_model, method):
+    return os.path.join(save_model, method)
+
+
+def save_resume(save_model, method, model, opt, epoch):
+    """train.py:254-262 (written every 5th epoch there)."""
+    d = _ckpt_dir(save_model, method)
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, f"{method}_resume.pth")
+    torch.save({"model": model.state_dict(), "optimizer": opt.state_dict(), "epoch": epoch}, path)
+    return path
+
+
+def save_best(save_model, method, model, mae, epoch):
+    """train.py:250-253: `<method>_MAE_<mae>_<epoch+1>.pth` holds the bare state_dict."""
+    d = _ckpt_dir(save_model, method)
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, f"{method}_MAE_{mae}_{epoch + 1}.pth")
+    torch.save(model.state_dict(), path)
+    return path
+
+
+def load_resume(resume, save_model, method, model, opt, map_location=None):
+    """train.py:214-229.  resume=None -> 0; "last" -> the resume file (model + optimizer, continues at epoch+1);
+    anything else is a state_dict path whose file name ends in `_<epoch>.pth` (continues at that number)."""
+    if resume is None:
+        return 0
+    if resume == "last":
+        ck = torch.load(os.path.join(_ckpt_dir(save_model, method), f"{method}_resume.pth"), map_location=map_location)
+        model.load_state_dict(ck["model"], strict=True)
+        opt.load_state_dict(ck["optimizer"])
+        return ck["epoch"] + 1
+    model.load_state_dict(torch.load(resume, map_location=map_location), strict=True)
+    return int(os.path.basename(resume).split("_")[-1].split(".")[0])
+
+
+def fit(model, opt, batches, epochs, base_lr, decay_epochs, decay_factors, save_model, method, start_epoch=0,
+        evaluate=None, see=0, best_mae=None, reducer=None, is_main=True, log=None):
+    """Epoch loop of train.py:212-263 around `train_step`.  `batches(epoch)` yields (images, label) device tensors;
+    `evaluate(model, epoch) -> MAE` runs from epoch `see` on (train.py:237); rank 0 (`is_main`) writes the files."""
+    history = []
+    for epoch in range(start_epoch, epochs):
+        lr = adjust_learning_rate(opt, epoch, decay_epochs, base_lr, decay_factors)
+        total, n = None, 0
+        for images, label in batches(epoch):
+            loss = train_step(model, opt, images, label, reducer=reducer)
+            total = loss if total is None else total + loss
+            n += 1
+        mean_loss = float(total / max(n, 1)) if total is not None else float("nan")   # one host sync per epoch
+        mae = None
+        if evaluate is not None and epoch + 1 >= see:
+            mae = evaluate(model, epoch)
+            if is_main and (best_mae is None or mae < best_mae):
+                save_best(save_model, method, model, mae, epoch)
+        if is_main and (epoch + 1) % 5 == 0:
+            save_resume(save_model, method, model, opt, epoch)
+        history.append({"epoch": epoch, "lr": lr, "loss": mean_loss, "mae": mae})
+        if log is not None:
+            log(history[-1])
+    return history
