@@ -162,6 +162,11 @@ int tramba_dw_pack(const float *w, const float *bias, const float *w3, const flo
 /* depth-wise ks x ks, stride 1, "same" padding, y = act(conv(x) + bt). */
 int tramba_dwconv_cl(const void *x, const float *wt, const float *bt, void *y, int batch, int h,
                      int wd, int c, int ks, int act, int dtype, void *stream);
+/* Training: gradients of the same stencil w.r.t. its tap-major weights and bias (what autograd computes for
+ * nn.Conv2d(groups=C), vmamba.py:301, 595-603).  gw (ks*ks, C) f32 and gb (C) f32 are ACCUMULATED into (fp32
+ * atomics): zero them first.  The input gradient is tramba_dwconv_cl(gy, flipped taps, zero bias). */
+int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *gw, float *gb, int batch, int h, int wd,
+                           int c, int ks, int dtype, void *stream);
 /* x: (B, n, n, C).  Y = Wy X Wx^T per channel; low = Y[:n/2,:n/2], high = Y[n/2:,n/2:],
  * both (B, n/2, n/2, C).  wx, wy: (n, n) f32.  tmp: (B, n, n, C) f32 workspace. */
 int tramba_dct_split_cl(const void *x, const float *wx, const float *wy, float *tmp, void *high,

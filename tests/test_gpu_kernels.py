@@ -317,3 +317,60 @@ def test_shuffle_norm_head_cl(dtype, cfg):
     ref = y @ hw.double().cpu() - 0.21
     np.testing.assert_allclose(got.cpu().double().numpy(), ref.numpy(), rtol=2e-2 if dtype != torch.float32 else 1e-4,
                                atol=2e-2 if dtype != torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 12, 64, 3), (1, 24, 130, 7), (2, 9, 32, 5), (1, 48, 256, 7)])
+def test_dwconv_training_path_matches_autograd(dtype, cfg):
+    """_DwConvCL (HIP forward, flipped-tap input gradient, atomic weight gradient) against F.conv2d autograd in fp64."""
+    from tramba_amd import modules as M
+    b, h, c, ks = cfg
+    g = torch.Generator().manual_seed(h * c + ks)
+    conv = torch.nn.Conv2d(c, c, ks, padding=ks // 2, groups=c, bias=True)
+    x = torch.randn(b, h, h, c, generator=g).to(dtype)
+    gy = torch.randn(b, h, h, c, generator=g).to(dtype)
+    # reference in fp64 on the (rounded) inputs
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    cr = torch.nn.Conv2d(c, c, ks, padding=ks // 2, groups=c, bias=True).double()
+    cr.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    yr = cr(xr)
+    yr.backward(gy.double().permute(0, 3, 1, 2))
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = M._dwconv_train_cl(xg, conv)
+    y.backward(gy.to(DEV))
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    np.testing.assert_allclose(y.detach().cpu().double().numpy(), yr.detach().permute(0, 2, 3, 1).numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(xg.grad.cpu().double().numpy(), xr.grad.permute(0, 2, 3, 1).numpy(), rtol=tol, atol=tol)
+    wtol = 1e-4 if dtype == torch.float32 else 3e-2
+    scale = float(cr.weight.grad.abs().max())
+    np.testing.assert_allclose(conv.weight.grad.cpu().double().numpy(), cr.weight.grad.numpy(), rtol=wtol, atol=wtol * scale)
+    np.testing.assert_allclose(conv.bias.grad.cpu().double().numpy(), cr.bias.grad.numpy(), rtol=wtol,
+                               atol=wtol * float(cr.bias.grad.abs().max()))
+
+
+def test_dwms_training_fold_matches_reference_sum():
+    """h + dw3(h) + dw5(h) + dw7(h) as one folded stencil: outputs and all six parameter gradients."""
+    from tramba_amd import modules as M
+    c, h = 64, 12
+    g = torch.Generator().manual_seed(3)
+    convs = [torch.nn.Conv2d(c, c, k, padding=k // 2, groups=c, bias=True).double() for k in (3, 5, 7)]
+    x = torch.randn(2, h, h, c, generator=g)
+    gy = torch.randn(2, h, h, c, generator=g)
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = xr + convs[0](xr) + convs[1](xr) + convs[2](xr)
+    yr.backward(gy.double().permute(0, 3, 1, 2))
+    dev = [torch.nn.Conv2d(c, c, k, padding=k // 2, groups=c, bias=True) for k in (3, 5, 7)]
+    for d, r in zip(dev, convs):
+        d.load_state_dict({k: v.float() for k, v in r.state_dict().items()})
+        d.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = M._dwms_train_cl(xg, dev[0], dev[1], dev[2])
+    y.backward(gy.to(DEV))
+    np.testing.assert_allclose(y.detach().cpu().double().numpy(), yr.detach().permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(xg.grad.cpu().double().numpy(), xr.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
+    for d, r in zip(dev, convs):
+        np.testing.assert_allclose(d.weight.grad.cpu().double().numpy(), r.weight.grad.numpy(), rtol=1e-3,
+                                   atol=1e-3 * float(r.weight.grad.abs().max()))
+        np.testing.assert_allclose(d.bias.grad.cpu().double().numpy(), r.bias.grad.numpy(), rtol=1e-3,
+                                   atol=1e-3 * float(r.bias.grad.abs().max()))

@@ -469,6 +469,98 @@ __global__ __launch_bounds__(256) void dwconv4_cl_kernel(const T *__restrict__ x
     }
 }
 
+// Weight / bias gradient of the depth-wise stencil (training): gw[tap][c] += sum over pixels of
+// gy[b,h,w,c] * x[b,h+dy-R,w+dx-R,c], gb[c] += sum gy.  Lanes = channel pairs, a wave owns RPW image rows
+// of one 128-channel tile and walks them 4 columns at a time (the forward kernel's register reuse with the
+// roles swapped: the accumulators are indexed by tap), then adds its ks*ks partial sums to global memory
+// with fp32 atomics (gw / gb zero-filled by the caller).
+template <typename T>
+__device__ __forceinline__ dw_v2f dw_load2(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(dw_v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+    } else {
+        const unsigned raw = __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
+        const Pack<T, 2> pk = __builtin_bit_cast(Pack<T, 2>, raw);
+        return dw_v2f{Cvt<T>::to_f(pk.v[0]), Cvt<T>::to_f(pk.v[1])};
+    }
+}
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void dwconv_wgrad_cl_kernel(const T *__restrict__ x, const T *__restrict__ gy,
+                                                             float *__restrict__ gw, float *__restrict__ gb, int H,
+                                                             int W, int C, int RPW)
+{
+    constexpr int V = 2, R = KS / 2, TW = 4, NI = TW + KS - 1;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = (blockIdx.x * kWave + lane) * V;
+    const bool cok = c0 + V <= C;
+    const int row0 = (blockIdx.y * 4 + wv) * RPW;       // first image row of this wave
+    const int b = blockIdx.z;
+    if (row0 >= H) return;                               // wave-uniform; no barriers in this kernel
+    const unsigned colb = (unsigned)C * (unsigned)sizeof(T), rowb = (unsigned)W * colb;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * H * W * C, (unsigned)H * rowb);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(gy + (long)b * H * W * C, (unsigned)H * rowb);
+    const unsigned cb = cok ? (unsigned)c0 * (unsigned)sizeof(T) : kOutOfRange;
+
+    dw_v2f acc[KS][KS], accb = {0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) acc[dy][dx] = dw_v2f{0.f, 0.f};
+
+    const int rend = row0 + RPW < H ? row0 + RPW : H;
+    for (int h = row0; h < rend; ++h) {
+        for (int w0 = 0; w0 < W; w0 += TW) {
+            dw_v2f g[TW];
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const unsigned vo = (w0 + t < W && cok) ? (unsigned)((h * W + w0 + t) * C) * (unsigned)sizeof(T) + cb : kOutOfRange;
+                g[t] = dw_load2<T>(rg, vo);
+                accb = accb + g[t];
+            }
+#pragma unroll 1
+            for (int dy = 0; dy < KS; ++dy) {
+                const int hy = h + dy - R;
+                const bool rowok = hy >= 0 && hy < H;
+                dw_v2f xin[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int wx = w0 - R + i;
+                    const unsigned vo = (rowok && wx >= 0 && wx < W && cok)
+                                            ? (unsigned)((hy * W + wx) * C) * (unsigned)sizeof(T) + cb : kOutOfRange;
+                    xin[i] = dw_load2<T>(rx, vo);
+                }
+                // acc[dy][dx] is indexed with a run-time dy: keep the row in registers through a switch-free copy
+                dw_v2f part[KS];
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx) {
+                    part[dx] = dw_v2f{0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) part[dx] = g[t] * xin[t + dx] + part[dx];
+                }
+#pragma unroll
+                for (int d2 = 0; d2 < KS; ++d2)
+                    if (d2 == dy)
+#pragma unroll
+                        for (int dx = 0; dx < KS; ++dx) acc[d2][dx] = acc[d2][dx] + part[dx];
+            }
+        }
+    }
+    if (!cok) return;
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) {
+            float *p = gw + (long)(dy * KS + dx) * C + c0;
+            atomicAdd(p, acc[dy][dx].x);
+            atomicAdd(p + 1, acc[dy][dx].y);
+        }
+    atomicAdd(gb + c0, accb.x);
+    atomicAdd(gb + c0 + 1, accb.y);
+}
+
 template <typename T, int KS>
 static int launch_dw(const void *x, const float *wt, const float *bt, void *y, int B, int H, int W, int C, int act,
                      hipStream_t s)
@@ -560,6 +652,26 @@ extern "C" int tramba_dw_pack(const float *w, const float *bias, const float *w3
     TRAMBA_CHECK(!ms || (ks == 7 && w3 && b3 && w5 && b5 && bias), "dw_pack: multi-scale needs ks=7 and all six tensors");
     hipLaunchKernelGGL(dw_pack_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, bias, w3, b3, w5, b5,
                        wt, bt, c, ks, ms);
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *gw, float *gb, int batch, int h, int wd,
+                                      int c, int ks, int dtype, void *stream)
+{
+    TRAMBA_CHECK(x && gy && gw && gb, "dwconv_wgrad_cl: null tensor");
+    TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0, "dwconv_wgrad_cl: empty shape");
+    TRAMBA_CHECK(ks == 3 || ks == 5 || ks == 7, "dwconv_wgrad_cl: kernel size %d unsupported (3,5,7)", ks);
+    TRAMBA_CHECK(c % 2 == 0, "dwconv_wgrad_cl: C=%d must be even", c);
+    TRAMBA_CHECK(batch <= 65535 && (double)h * wd * c * 4.0 < 2147483648.0, "dwconv_wgrad_cl: shape exceeds this build's limits");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpw = h >= 48 ? 4 : 1;
+    dim3 grid((unsigned)((c / 2 + kWave - 1) / kWave), (unsigned)((h + 4 * rpw - 1) / (4 * rpw)), (unsigned)batch), block(256);
+    TRAMBA_DISPATCH_DTYPE(dtype, T, {
+        if (ks == 3) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 3>), grid, block, 0, s, (const T *)x, (const T *)gy, gw, gb, h, wd, c, rpw);
+        else if (ks == 5) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 5>), grid, block, 0, s, (const T *)x, (const T *)gy, gw, gb, h, wd, c, rpw);
+        else hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 7>), grid, block, 0, s, (const T *)x, (const T *)gy, gw, gb, h, wd, c, rpw);
+    });
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }

@@ -51,6 +51,7 @@ SIGNATURES = {
     "tramba_rowdot_cl": (c_int, [c_vp, c_vp, c_f, c_vp, c_i64, c_int, c_int, c_vp]),
     "tramba_dw_pack": (c_int, [c_vp] * 8 + [c_int] * 2 + [c_vp]),
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
+    "tramba_dwconv_wgrad_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_conv3x3s2_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
@@ -391,6 +392,19 @@ def dwconv_cl(x, wt, bt, act=ACT_NONE):
     _check(lib().tramba_dwconv_cl(_ptr(x), _ptr(wt), _ptr(bt), _ptr(y), bb, h, wd, c, ks, act, dt(x), _stream()),
            "dwconv_cl")
     return y
+
+
+def dwconv_wgrad_cl(x, gy, ks):
+    """x, gy: (B, H, W, C) -> (gw (ks*ks, C) f32 tap-major, gb (C) f32)."""
+    _dev(x, gy)
+    bb, h, wd, c = x.shape
+    if gy.shape != x.shape or gy.dtype != x.dtype:
+        raise TrambaHipError("dwconv_wgrad_cl: x / gy mismatch")
+    gw = torch.zeros((ks * ks, c), dtype=torch.float32, device=x.device)
+    gb = torch.zeros((c,), dtype=torch.float32, device=x.device)
+    _check(lib().tramba_dwconv_wgrad_cl(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), bb, h, wd, c, ks, dt(x), _stream()),
+           "dwconv_wgrad_cl")
+    return gw, gb
 
 
 def dct_split_cl(x, wx, wy):

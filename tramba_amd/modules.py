@@ -122,12 +122,56 @@ class _ConvNative(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+class _DwConvCL(torch.autograd.Function):
+    """Depth-wise stencil on a channels-last map with autograd, all HIP (training path): forward
+    tramba_dwconv_cl; input gradient = the same kernel with the taps flipped; weight / bias gradient
+    tramba_dwconv_wgrad_cl.  wt (ks*ks, C) f32 tap-major, bt (C) f32."""
+
+    @staticmethod
+    def forward(ctx, x, wt, bt):
+        wt = wt.contiguous()
+        ctx.save_for_backward(x, wt)
+        return hip.dwconv_cl(x, wt, bt.contiguous(), hip.ACT_NONE)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wt = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = hip.dwconv_cl(gy, wt.flip(0).contiguous(), torch.zeros_like(wt[0]), hip.ACT_NONE)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            ks = int(round(wt.shape[0] ** 0.5))
+            gw, gb = hip.dwconv_wgrad_cl(x, gy, ks)
+        return gx, gw, gb
+
+
+def _tap_major(conv: nn.Conv2d):
+    """(C,1,ks,ks) / (C) parameters -> tap-major (ks*ks, C) + bias (C), fp32, differentiable."""
+    w = conv.weight.float()
+    c = w.shape[0]
+    wt = w.reshape(c, -1).t()
+    bt = conv.bias.float() if conv.bias is not None else w.new_zeros(c)
+    return wt, bt
+
+
 def _dwconv_train_cl(x_cl, conv: nn.Conv2d):
-    """(B,H,W,C) -> (B,H,W,C) through the native NCHW depth-wise kernels."""
-    x = from_cl(x_cl).contiguous()
-    w = conv.weight.to(x.dtype)
-    b = None if conv.bias is None else conv.bias.to(x.dtype)
-    return to_cl(_ConvNative.apply(x, w, b, (1, 1), tuple(conv.padding), w.shape[0]))
+    """(B,H,W,C) -> (B,H,W,C), training path of a depth-wise conv."""
+    wt, bt = _tap_major(conv)
+    return _DwConvCL.apply(x_cl.contiguous(), wt, bt)
+
+
+def _dwms_train_cl(h, c3: nn.Conv2d, c5: nn.Conv2d, c7: nn.Conv2d):
+    """h + dw3(h) + dw5(h) + dw7(h) (vmamba.py:622) as ONE 7x7 stencil: the fold is written in differentiable
+    torch ops on the small weight tensors, so autograd hands each parameter its share of the stencil gradient."""
+    w7 = c7.weight.float()
+    c = w7.shape[0]
+    wf = w7 + F.pad(c5.weight.float(), (1, 1, 1, 1)) + F.pad(c3.weight.float(), (2, 2, 2, 2))
+    ident = torch.zeros(1, 1, 7, 7, dtype=wf.dtype, device=wf.device)
+    ident[0, 0, 3, 3] = 1.0
+    wf = wf + ident
+    bt = c7.bias.float() + c5.bias.float() + c3.bias.float()
+    return _DwConvCL.apply(h.contiguous(), wf.reshape(c, 49).t(), bt)
 
 
 class DropPath(nn.Module):
@@ -575,7 +619,7 @@ class DWMSMlp(nn.Module):
                 lambda: hip.dw_pack(c7.weight, c7.bias, c3.weight, c3.bias, c5.weight, c5.bias))
             g = hip.dwconv_cl(h, wt, bt, hip.ACT_GELU)
         else:
-            g = F.gelu(h + self.dwc3._forward_cl(h) + self.dwc5._forward_cl(h) + self.dwc7._forward_cl(h))
+            g = F.gelu(_dwms_train_cl(h, c3, c5, c7))
         g = self.drop(g)
         return self.drop(self.fc2._forward_cl(g, residual=residual))
 
