@@ -140,6 +140,12 @@ int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr, const int3
 /* y = act(LayerNorm_C(x));  x, y: (rows, C).  w, b f32. */
 int tramba_layernorm_cl(const void *x, const float *w, const float *b, void *y, int64_t rows, int c,
                         float eps, int act, int dtype, void *stream);
+/* Training: LayerNorm backward over the last dim of (rows, C): dx in dtype; part (P, 2, C) f32 receives one partial
+ * (dgamma, dbeta) row per wave, P = tramba_layernorm_bwd_parts(rows): the caller sums over P (fixed order ->
+ * reproducible).  mean / rstd are recomputed from x. */
+int64_t tramba_layernorm_bwd_parts(int64_t rows);
+int tramba_layernorm_bwd_cl(const void *x, const void *dy, const float *w, void *dx, float *part, int64_t rows,
+                            int c, float eps, int dtype, void *stream);
 /* x: (B, H, W, P*P*C) -> y: (B, H*P, W*P, C) with y[b,hP+p1,wP+p2,:] = LN(x[b,h,w,(p1*P+p2)*C : +C]). */
 int tramba_shuffle_norm_cl(const void *x, const float *w, const float *b, void *y, int batch, int h,
                            int wd, int c, int p, float eps, int dtype, void *stream);
@@ -163,10 +169,12 @@ int tramba_dw_pack(const float *w, const float *bias, const float *w3, const flo
 int tramba_dwconv_cl(const void *x, const float *wt, const float *bt, void *y, int batch, int h,
                      int wd, int c, int ks, int act, int dtype, void *stream);
 /* Training: gradients of the same stencil w.r.t. its tap-major weights and bias (what autograd computes for
- * nn.Conv2d(groups=C), vmamba.py:301, 595-603).  gw (ks*ks, C) f32 and gb (C) f32 are ACCUMULATED into (fp32
- * atomics): zero them first.  The input gradient is tramba_dwconv_cl(gy, flipped taps, zero bias). */
-int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *gw, float *gb, int batch, int h, int wd,
-                           int c, int ks, int dtype, void *stream);
+ * nn.Conv2d(groups=C), vmamba.py:301, 595-603).  part (P, ks*ks + 1, C) f32, P = tramba_dwconv_wgrad_parts(batch, h):
+ * one partial row per wave slot, planes 0..ks*ks-1 = taps, last plane = bias; the caller sums over P (fixed
+ * order).  The input gradient is tramba_dwconv_cl(gy, flipped taps, zero bias). */
+int64_t tramba_dwconv_wgrad_parts(int batch, int h);
+int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *part, int batch, int h, int wd, int c, int ks,
+                           int dtype, void *stream);
 /* x: (B, n, n, C).  Y = Wy X Wx^T per channel; low = Y[:n/2,:n/2], high = Y[n/2:,n/2:],
  * both (B, n/2, n/2, C).  wx, wy: (n, n) f32.  tmp: (B, n, n, C) f32 workspace. */
 int tramba_dct_split_cl(const void *x, const float *wx, const float *wy, float *tmp, void *high,

@@ -374,3 +374,30 @@ def test_dwms_training_fold_matches_reference_sum():
                                    atol=1e-3 * float(r.weight.grad.abs().max()))
         np.testing.assert_allclose(d.bias.grad.cpu().double().numpy(), r.bias.grad.numpy(), rtol=1e-3,
                                    atol=1e-3 * float(r.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rc", [(500, 128), (77, 512), (4100, 256), (33, 1024), (64, 2048), (50, 40)])
+def test_layernorm_training_path_matches_autograd(dtype, rc):
+    """_LayerNormCL (HIP forward + HIP backward with atomic dgamma/dbeta) against F.layer_norm autograd in fp64."""
+    from tramba_amd import modules as M
+    rows, c = rc
+    g = torch.Generator().manual_seed(rows + c)
+    x = (torch.randn(rows, c, generator=g) * 1.5 + 0.3).to(dtype)
+    gy = torch.randn(rows, c, generator=g).to(dtype)
+    w = 1 + 0.2 * torch.randn(c, generator=g)
+    b = 0.1 * torch.randn(c, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (c,), wr, br, 1e-5)
+    yr.backward(gy.double())
+    xg = x.to(DEV).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = M._LayerNormCL.apply(xg, wg, bg, 1e-5)
+    y.backward(gy.to(DEV))
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    np.testing.assert_allclose(y.detach().cpu().double().numpy(), yr.detach().numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(xg.grad.cpu().double().numpy(), xr.grad.numpy(), rtol=tol, atol=tol)
+    ptol = 1e-4 if dtype == torch.float32 else 3e-2
+    np.testing.assert_allclose(wg.grad.cpu().double().numpy(), wr.grad.numpy(), rtol=ptol, atol=ptol * float(wr.grad.abs().max()))
+    np.testing.assert_allclose(bg.grad.cpu().double().numpy(), br.grad.numpy(), rtol=ptol, atol=ptol * float(br.grad.abs().max()))

@@ -219,6 +219,93 @@ static int launch_layernorm(const void *x, const float *w, const float *b, void 
     return TRAMBA_OK;
 }
 
+// LayerNorm backward (training), channels-last rows: a wave walks RPW rows, all C channels in registers.
+//   xh = (x - mean) * rstd,  g = dy * gamma
+//   dx = rstd * (g - mean_C(g) - xh * mean_C(g * xh)),   dgamma += dy * xh,   dbeta += dy
+// mean / rstd are recomputed from x (cheaper than storing them); dgamma / dbeta accumulate over the wave's rows
+// in registers and leave as ONE partial row per wave, part[wave][0 = dgamma, 1 = dbeta][C]; the caller sums the
+// partial rows (fp32 atomics from ~4096 waves onto C addresses serialised in L2: 500 us per call, 10x the rest).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void layernorm_bwd_cl_kernel(const T *__restrict__ x, const T *__restrict__ dy,
+                                                              const float *__restrict__ w, T *__restrict__ dx,
+                                                              float *__restrict__ part, long rows, int C, float eps,
+                                                              int rpw)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long r0 = wave * rpw;
+    if (r0 >= rows) return;   // wave-uniform, no barriers
+    const int nit = (C + kWave * V - 1) / (kWave * V);
+    float gam[kNormMaxIt][V], gw[kNormMaxIt][V], gb[kNormMaxIt][V];
+#pragma unroll
+    for (int it = 0; it < kNormMaxIt; ++it)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int c = (it * kWave + lane) * V + v;
+            gam[it][v] = (it < nit && c < C) ? w[c] : 0.f;
+            gw[it][v] = 0.f;
+            gb[it][v] = 0.f;
+        }
+    const long rend = r0 + rpw < rows ? r0 + rpw : rows;
+    for (long r = r0; r < rend; ++r) {
+        float xv[kNormMaxIt][V], gv[kNormMaxIt][V];
+#pragma unroll
+        for (int it = 0; it < kNormMaxIt; ++it) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) xv[it][v] = gv[it][v] = 0.f;
+            if (it < nit) {
+                const int c0 = (it * kWave + lane) * V;
+                if (c0 + V <= C) {
+                    load_pack<T, V>(x + r * C + c0, xv[it]);
+                    load_pack<T, V>(dy + r * C + c0, gv[it]);
+                }
+            }
+        }
+        float mean, rstd;
+        wave_layernorm<V>(xv, nit, C, lane, eps, mean, rstd);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < kNormMaxIt; ++it)
+            if (it < nit)
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const bool ok = (it * kWave + lane) * V + v < C;
+                    const float xh = ok ? (xv[it][v] - mean) * rstd : 0.f;
+                    const float g = gv[it][v] * gam[it][v];
+                    xv[it][v] = xh;          // keep the normalised value
+                    s1 += g;
+                    s2 = fmaf(g, xh, s2);
+                    gw[it][v] = fmaf(gv[it][v], xh, gw[it][v]);
+                    gb[it][v] += gv[it][v];
+                }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int it = 0; it < kNormMaxIt; ++it)
+            if (it < nit) {
+                const int c0 = (it * kWave + lane) * V;
+                if (c0 + V <= C) {
+                    float o[V];
+#pragma unroll
+                    for (int v = 0; v < V; ++v) o[v] = rstd * (gv[it][v] * gam[it][v] - s1 - xv[it][v] * s2);
+                    store_pack<T, V>(dx + r * C + c0, o);
+                }
+            }
+    }
+    float *pw = part + wave * 2 * C;
+#pragma unroll
+    for (int it = 0; it < kNormMaxIt; ++it)
+        if (it < nit)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int c = (it * kWave + lane) * V + v;
+                if (c < C) {
+                    pw[c] = gw[it][v];
+                    pw[C + c] = gb[it][v];
+                }
+            }
+}
+
 template <typename T>
 static int launch_rowdot(const void *x, const float *w, float bias, float *y, long rows, int c, hipStream_t s)
 {
@@ -472,8 +559,9 @@ __global__ __launch_bounds__(256) void dwconv4_cl_kernel(const T *__restrict__ x
 // Weight / bias gradient of the depth-wise stencil (training): gw[tap][c] += sum over pixels of
 // gy[b,h,w,c] * x[b,h+dy-R,w+dx-R,c], gb[c] += sum gy.  Lanes = channel pairs, a wave owns RPW image rows
 // of one 128-channel tile and walks them 4 columns at a time (the forward kernel's register reuse with the
-// roles swapped: the accumulators are indexed by tap), then adds its ks*ks partial sums to global memory
-// with fp32 atomics (gw / gb zero-filled by the caller).
+// roles swapped: the accumulators are indexed by tap), then writes its ks*ks + 1 partial sums as one row of
+// part[wave-slot][ks*ks + 1][C] (last plane = bias); the caller sums the rows (atomics onto ks*ks*C addresses from
+// thousands of waves serialise in L2).
 template <typename T>
 __device__ __forceinline__ dw_v2f dw_load2(__amdgpu_buffer_rsrc_t r, unsigned voff)
 {
@@ -488,8 +576,7 @@ __device__ __forceinline__ dw_v2f dw_load2(__amdgpu_buffer_rsrc_t r, unsigned vo
 
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void dwconv_wgrad_cl_kernel(const T *__restrict__ x, const T *__restrict__ gy,
-                                                             float *__restrict__ gw, float *__restrict__ gb, int H,
-                                                             int W, int C, int RPW)
+                                                             float *__restrict__ part, int H, int W, int C, int RPW)
 {
     constexpr int V = 2, R = KS / 2, TW = 4, NI = TW + KS - 1;
     const int lane = threadIdx.x & (kWave - 1);
@@ -498,7 +585,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_cl_kernel(const T *__restric
     const bool cok = c0 + V <= C;
     const int row0 = (blockIdx.y * 4 + wv) * RPW;       // first image row of this wave
     const int b = blockIdx.z;
-    if (row0 >= H) return;                               // wave-uniform; no barriers in this kernel
+    // (waves past the last row still run: their slot must hold zeros, not stale memory)
     const unsigned colb = (unsigned)C * (unsigned)sizeof(T), rowb = (unsigned)W * colb;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * H * W * C, (unsigned)H * rowb);
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(gy + (long)b * H * W * C, (unsigned)H * rowb);
@@ -549,16 +636,17 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_cl_kernel(const T *__restric
         }
     }
     if (!cok) return;
+    // slot = (image, row group, wave): gridDim.y * 4 row slots per image
+    float *p = part + (((long)b * gridDim.y + blockIdx.y) * 4 + wv) * (long)(KS * KS + 1) * C + c0;
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
         for (int dx = 0; dx < KS; ++dx) {
-            float *p = gw + (long)(dy * KS + dx) * C + c0;
-            atomicAdd(p, acc[dy][dx].x);
-            atomicAdd(p + 1, acc[dy][dx].y);
+            p[(long)(dy * KS + dx) * C] = acc[dy][dx].x;
+            p[(long)(dy * KS + dx) * C + 1] = acc[dy][dx].y;
         }
-    atomicAdd(gb + c0, accb.x);
-    atomicAdd(gb + c0 + 1, accb.y);
+    p[(long)(KS * KS) * C] = accb.x;
+    p[(long)(KS * KS) * C + 1] = accb.y;
 }
 
 template <typename T, int KS>
@@ -603,6 +691,40 @@ extern "C" int tramba_layernorm_cl(const void *x, const float *w, const float *b
     TRAMBA_CHECK(aligned16(x) && aligned16(y), "layernorm_cl: tensors must be 16-byte aligned");
     TRAMBA_DISPATCH_DTYPE(dtype, T,
         return launch_layernorm<T>(x, w, b, y, rows, c, eps, act, 1, 1, 1, (hipStream_t)stream));
+    return TRAMBA_OK;
+}
+
+static long ln_bwd_rows_per_wave(long rows)
+{
+    long rpw = rows / 4096;   // ~4096+ waves in flight
+    return rpw < 1 ? 1 : (rpw > 32 ? 32 : rpw);
+}
+
+extern "C" int64_t tramba_layernorm_bwd_parts(int64_t rows)
+{
+    if (rows <= 0) return 0;
+    const long rpw = ln_bwd_rows_per_wave(rows);
+    return (rows + rpw - 1) / rpw;
+}
+
+extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const float *w, void *dx, float *part,
+                                       int64_t rows, int c, float eps, int dtype, void *stream)
+{
+    TRAMBA_CHECK(x && dy && w && dx && part, "layernorm_bwd_cl: null tensor");
+    TRAMBA_CHECK(rows > 0 && c > 0, "layernorm_bwd_cl: empty shape");
+    TRAMBA_CHECK(aligned16(x) && aligned16(dy) && aligned16(dx), "layernorm_bwd_cl: tensors must be 16-byte aligned");
+    const int v = (c % 4 == 0) ? 4 : ((c % 2 == 0) ? 2 : 1);
+    TRAMBA_CHECK((c + kWave * v - 1) / (kWave * v) <= kNormMaxIt, "layernorm_bwd_cl: C=%d too large", c);
+    hipStream_t s = (hipStream_t)stream;
+    const long rpw = ln_bwd_rows_per_wave(rows);
+    const long waves = (rows + rpw - 1) / rpw;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    TRAMBA_DISPATCH_DTYPE(dtype, T, {
+        if (v == 4) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 4>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
+        else if (v == 2) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 2>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
+        else hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 1>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
+    });
+    TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
 
@@ -656,21 +778,30 @@ extern "C" int tramba_dw_pack(const float *w, const float *bias, const float *w3
     return TRAMBA_OK;
 }
 
-extern "C" int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *gw, float *gb, int batch, int h, int wd,
-                                      int c, int ks, int dtype, void *stream)
+static int dw_wgrad_rpw(int h) { return h >= 48 ? 4 : 1; }
+
+extern "C" int64_t tramba_dwconv_wgrad_parts(int batch, int h)
 {
-    TRAMBA_CHECK(x && gy && gw && gb, "dwconv_wgrad_cl: null tensor");
+    if (batch <= 0 || h <= 0) return 0;
+    const int rpw = dw_wgrad_rpw(h);
+    return (int64_t)batch * ((h + 4 * rpw - 1) / (4 * rpw)) * 4;
+}
+
+extern "C" int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *part, int batch, int h, int wd, int c,
+                                      int ks, int dtype, void *stream)
+{
+    TRAMBA_CHECK(x && gy && part, "dwconv_wgrad_cl: null tensor");
     TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0, "dwconv_wgrad_cl: empty shape");
     TRAMBA_CHECK(ks == 3 || ks == 5 || ks == 7, "dwconv_wgrad_cl: kernel size %d unsupported (3,5,7)", ks);
     TRAMBA_CHECK(c % 2 == 0, "dwconv_wgrad_cl: C=%d must be even", c);
     TRAMBA_CHECK(batch <= 65535 && (double)h * wd * c * 4.0 < 2147483648.0, "dwconv_wgrad_cl: shape exceeds this build's limits");
     hipStream_t s = (hipStream_t)stream;
-    const int rpw = h >= 48 ? 4 : 1;
+    const int rpw = dw_wgrad_rpw(h);
     dim3 grid((unsigned)((c / 2 + kWave - 1) / kWave), (unsigned)((h + 4 * rpw - 1) / (4 * rpw)), (unsigned)batch), block(256);
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
-        if (ks == 3) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 3>), grid, block, 0, s, (const T *)x, (const T *)gy, gw, gb, h, wd, c, rpw);
-        else if (ks == 5) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 5>), grid, block, 0, s, (const T *)x, (const T *)gy, gw, gb, h, wd, c, rpw);
-        else hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 7>), grid, block, 0, s, (const T *)x, (const T *)gy, gw, gb, h, wd, c, rpw);
+        if (ks == 3) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 3>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw);
+        else if (ks == 5) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 5>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw);
+        else hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 7>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw);
     });
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;

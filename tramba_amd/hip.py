@@ -46,12 +46,15 @@ SIGNATURES = {
     "tramba_ss2d_scan_cl": (c_int, [c_vp] * 9 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
+    "tramba_layernorm_bwd_parts": (c_i64, [c_i64]),
+    "tramba_layernorm_bwd_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_f, c_int, c_vp]),
     "tramba_shuffle_norm_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_shuffle_norm_head_cl": (c_int, [c_vp] * 4 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_rowdot_cl": (c_int, [c_vp, c_vp, c_f, c_vp, c_i64, c_int, c_int, c_vp]),
     "tramba_dw_pack": (c_int, [c_vp] * 8 + [c_int] * 2 + [c_vp]),
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
-    "tramba_dwconv_wgrad_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
+    "tramba_dwconv_wgrad_parts": (c_i64, [c_int, c_int]),
+    "tramba_dwconv_wgrad_cl": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_conv3x3s2_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
@@ -338,6 +341,19 @@ def layernorm_cl(x, w, b, eps=1e-5, act=ACT_NONE):
     return y
 
 
+def layernorm_bwd_cl(x, dy, w, eps=1e-5):
+    """x, dy: (..., C) contiguous -> (dx like x, dw (C) f32, db (C) f32)."""
+    _dev(x, dy, w)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    dx = torch.empty_like(x)
+    part = torch.empty((lib().tramba_layernorm_bwd_parts(rows), 2, c), dtype=torch.float32, device=x.device)
+    _check(lib().tramba_layernorm_bwd_cl(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(part), rows, c, eps, dt(x), _stream()),
+           "layernorm_bwd_cl")
+    s = part.sum(dim=0)
+    return dx, s[0], s[1]
+
+
 def shuffle_norm_cl(x, w, b, p, eps=1e-5):
     """x: (B, H, W, P*P*C) -> (B, H*P, W*P, C), pixel-shuffle + LayerNorm over C."""
     _dev(x, w, b)
@@ -400,11 +416,11 @@ def dwconv_wgrad_cl(x, gy, ks):
     bb, h, wd, c = x.shape
     if gy.shape != x.shape or gy.dtype != x.dtype:
         raise TrambaHipError("dwconv_wgrad_cl: x / gy mismatch")
-    gw = torch.zeros((ks * ks, c), dtype=torch.float32, device=x.device)
-    gb = torch.zeros((c,), dtype=torch.float32, device=x.device)
-    _check(lib().tramba_dwconv_wgrad_cl(_ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), bb, h, wd, c, ks, dt(x), _stream()),
+    part = torch.empty((lib().tramba_dwconv_wgrad_parts(bb, h), ks * ks + 1, c), dtype=torch.float32, device=x.device)
+    _check(lib().tramba_dwconv_wgrad_cl(_ptr(x), _ptr(gy), _ptr(part), bb, h, wd, c, ks, dt(x), _stream()),
            "dwconv_wgrad_cl")
-    return gw, gb
+    s = part.sum(dim=0)
+    return s[:ks * ks], s[ks * ks]
 
 
 def dct_split_cl(x, wx, wy):

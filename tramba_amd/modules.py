@@ -37,6 +37,8 @@ GEMM_BACKEND = os.environ.get("TRAMBA_GEMM", "hip")
 # dtype of the (B,K,L,D) scan output between the fused scan and the merge kernel in inference:
 # "f32" mirrors the reference's oflex fp32 output, "act" stores it in the activation dtype
 YS_DTYPE = os.environ.get("TRAMBA_YS", "f32")
+# training-path LayerNorm: "hip" = tramba_layernorm_cl / tramba_layernorm_bwd_cl, "torch" = F.layer_norm in fp32
+TRAIN_NORM_BACKEND = os.environ.get("TRAMBA_TRAIN_NORM", "hip")
 
 
 def to_cl(x: torch.Tensor) -> torch.Tensor:
@@ -221,12 +223,33 @@ class Linear2d(nn.Linear):
                                              unexpected_keys, error_msgs)
 
 
+class _LayerNormCL(torch.autograd.Function):
+    """LayerNorm over the last dim with autograd, both directions HIP (training path): no fp32 round trip of the
+    activation, dgamma / dbeta by in-kernel accumulation + atomics."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        wf = w.detach().float().contiguous()
+        ctx.save_for_backward(x, wf)
+        ctx.eps = eps
+        return hip.layernorm_cl(x, wf, b.detach().float().contiguous(), eps, hip.ACT_NONE)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wf = ctx.saved_tensors
+        dx, dw, db = hip.layernorm_bwd_cl(x, gy.contiguous().to(x.dtype), wf, ctx.eps)
+        return dx, dw, db, None
+
+
 class LayerNorm2d(nn.LayerNorm):
     """LayerNorm over C of an NCHW tensor (modules.py:22-27) -- no permutes needed in channels-last."""
 
     def _forward_cl(self, x, act=hip.ACT_NONE):
         if _infer(x, self.weight):
             return hip.layernorm_cl(x, _f32(self.weight), _f32(self.bias), self.eps, act)
+        if x.is_cuda and TRAIN_NORM_BACKEND == "hip":
+            return _act_torch(_LayerNormCL.apply(x, self.weight, self.bias, self.eps), act)
         y = F.layer_norm(x.float(), self.normalized_shape, self.weight.float(), self.bias.float(), self.eps)
         return _act_torch(y, act).to(x.dtype)
 
