@@ -401,3 +401,78 @@ def test_layernorm_training_path_matches_autograd(dtype, rc):
     ptol = 1e-4 if dtype == torch.float32 else 3e-2
     np.testing.assert_allclose(wg.grad.cpu().double().numpy(), wr.grad.numpy(), rtol=ptol, atol=ptol * float(wr.grad.abs().max()))
     np.testing.assert_allclose(bg.grad.cpu().double().numpy(), br.grad.numpy(), rtol=ptol, atol=ptol * float(br.grad.abs().max()))
+
+
+def _ref_core_fp64(x, xdbl, table, dt_w, dt_bias, a_neg, ds, r):
+    """forward_corev2's scan + merge restated in fp64 torch ops (sequential in l), differentiable."""
+    b, l, d = x.shape
+    k = table.shape[0]
+    rg = xdbl.shape[-1] // k
+    r8 = rg - 4
+    xd = xdbl.view(b, l, k, rg)
+    ym = torch.zeros(b, l, d, dtype=torch.float64)
+    for i in range(k):
+        idx = table[i].long()
+        u = x[:, idx, :]
+        rows = xd[:, idx, i, :]
+        raw = rows[..., :r] @ dt_w[i].t()
+        bv, cv = rows[..., r8], rows[..., r8 + 1]
+        dt = F.softplus(raw + dt_bias[i])
+        a = torch.exp(dt * a_neg[i])
+        h = torch.zeros(b, d, dtype=torch.float64)
+        ys = []
+        for t in range(l):
+            h = a[:, t] * h + dt[:, t] * bv[:, t, None] * u[:, t]
+            ys.append(cv[:, t, None] * h + ds[i] * u[:, t])
+        ym = ym.index_add(1, idx, torch.stack(ys, 1))
+    return ym
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fam,h,d,r,b", [("raster", 12, 64, 4, 2), ("helix", 12, 32, 8, 1), ("window", 24, 40, 3, 1),
+                                         ("dilation", 16, 96, 16, 2), ("raster", 24, 64, 40, 1)])
+def test_ss2d_core_training_gradients(dtype, fam, h, d, r, b):
+    """_SS2DCoreCL (fused forward + tramba_ss2d_scan_bwd_cl + projection GEMMs) against fp64 autograd of the
+    restated graph: merged output and the gradients of x, the x_proj rows, dt_w, dt_bias, A and D."""
+    from tramba_amd import modules as M
+    H = hip()
+    dev = torch.device(DEV)
+    order = H.scan_order(fam, h, h, dev)
+    k, l = order.k, h * h
+    rg = H.ss2d_group_stride(r)
+    g = torch.Generator().manual_seed(h * d + r)
+    x = torch.randn(b, l, d, generator=g).to(dtype)
+    xdbl = torch.zeros(b, l, k, rg)
+    xdbl[..., :r] = 0.5 * torch.randn(b, l, k, r, generator=g)
+    xdbl[..., rg - 4:rg - 2] = torch.randn(b, l, k, 2, generator=g)
+    xdbl = xdbl.view(b, l, k * rg)
+    dt_w = torch.randn(k, d, r, generator=g) * r ** -0.5
+    dt_b = torch.randn(k, d, generator=g) * 0.5 - 1.0
+    a_neg = -(torch.rand(k, d, generator=g) * 0.8 + 0.2)
+    ds = 1 + 0.1 * torch.randn(k, d, generator=g)
+    gym = torch.randn(b, l, d, generator=g)
+    # reference
+    leaves = [t.double().requires_grad_(True) for t in (x.float(), xdbl, dt_w, dt_b, a_neg, ds)]
+    ymr = _ref_core_fp64(leaves[0], leaves[1], order.table.cpu(), leaves[2], leaves[3], leaves[4], leaves[5], r)
+    ymr.backward(gym.double())
+    # device
+    dl = [x.to(dev).requires_grad_(True), xdbl.to(dev).requires_grad_(True), dt_w.to(dev).requires_grad_(True),
+          dt_b.reshape(-1).to(dev).requires_grad_(True), a_neg.reshape(-1).to(dev).requires_grad_(True),
+          ds.reshape(-1).to(dev).requires_grad_(True)]
+    ym = M._SS2DCoreCL.apply(*dl, order)
+    ym.backward(gym.to(dev))
+    f32 = dtype == torch.float32
+
+    def close(got, want, name, rel):
+        got, want = got.detach().double().cpu().reshape(want.shape), want.detach()
+        scale = float(want.abs().max()) + 1e-12
+        err = float((got - want).abs().max()) / scale
+        assert err < rel, (name, err)
+
+    close(ym, ymr, "ym", 2e-4 if f32 else 2e-2)
+    close(dl[0].grad, leaves[0].grad, "gx", 3e-4 if f32 else 3e-2)
+    close(dl[1].grad, leaves[1].grad, "gxdbl", 5e-4 if f32 else 5e-2)
+    close(dl[2].grad, leaves[2].grad, "gdt_w", 5e-4 if f32 else 5e-2)
+    close(dl[3].grad, leaves[3].grad, "gbias", 5e-4 if f32 else 5e-2)
+    close(dl[4].grad, leaves[4].grad, "gA", 5e-4 if f32 else 5e-2)
+    close(dl[5].grad, leaves[5].grad, "gD", 5e-4 if f32 else 5e-2)

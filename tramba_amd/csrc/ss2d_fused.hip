@@ -253,7 +253,7 @@ struct ScanWave {
     // dt_proj on the matrix core + per-element decay / input terms.  nvalid = positions of this tile
     // inside the sequence (>= 32: all of them)
     __device__ __forceinline__ void terms(const TileOps<T, NK> &cur, const float (&Bp)[16], int nvalid, float (&a)[16],
-                                          float (&bb)[16], float (&uf)[16]) const
+                                          float (&bb)[16], float (&uf)[16], float *tl = nullptr) const
     {
 #pragma unroll
         for (int r = 0; r < 16; ++r) uf[r] = raw_to_f<T>(cur.u[r]);
@@ -291,6 +291,10 @@ struct ScanWave {
             const v2f bt = t * bu;
             bb[r] = bt.x;
             bb[r + 1] = bt.y;
+            if (tl) {   // (backward only; the pointer is a compile-time null in the forward kernels)
+                tl[r] = t.x;
+                tl[r + 1] = t.y;
+            }
         }
     }
 
@@ -481,6 +485,257 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     if (s0 < nsuper) step(std::integral_constant<int, 0>{}, s0);
     if constexpr (NS > 2) {
         if (s0 + 1 < nsuper) step(std::integral_constant<int, 1>{}, s0 + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the fused channels-last scan (training).  Same decomposition as ss2d_scan_cl_kernel -- a
+// workgroup of W waves owns 32 channels of one direction, tiles of 32 positions, dt_proj recomputed on the
+// matrix core from the gathered x_proj rows -- run twice over the sequence:
+//   sweep 1 (left to right)  the state entering every tile -> hst (B,K,NT,D), a small scratch
+//   sweep 2 (right to left)  per tile: forward replay for h, then the adjoint recurrence
+//        gh_l = C_l gy_l + z_{l+1},   z_l = a_l gh_l          (z: the adjoint carried leftwards)
+//     with the same run / half-wave / wave fold as the forward, mirrored.
+// gy is the gradient of the MERGED output gathered through the table (ys' gradient is never materialised).
+// Outputs: gu (B,K,L,D) = dL/d(gathered x), graw (B,K,L,D) = dL/d(dt_raw = x_proj ranks . dt_w) in sequence
+// order (the small projections around them are left to batched GEMMs), gB / gC (B,K,L) summed over channels
+// (LDS transpose + atomics over the D/32 channel tiles), gpar (B,K,3,D) = per-channel dA, dD, dbias.
+template <typename T, int NK, bool SPLIT>
+__global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
+    const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
+    const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
+    const float *__restrict__ Ds, const float *__restrict__ gym, T *__restrict__ gu, T *__restrict__ graw,
+    float *__restrict__ gB, float *__restrict__ gC, float *__restrict__ gpar, float *__restrict__ hst, int L, int D,
+    int K, int R, int W)
+{
+    constexpr int kTS = 36;   // LDS row stride (floats) of the position-sum transposes: 16-byte aligned rows
+    __shared__ float agg[2][kMaxW][2][kTP];
+    __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];
+    __shared__ __attribute__((aligned(16))) float tr[kMaxW][kTP][kTS];
+    __shared__ float red[kMaxW][3][kTP];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int c = blockIdx.x * kTP + r32;
+    const bool cok = c < D;
+    const int cc_ = cok ? c : D - 1;
+    const int RG = xdbl_group_stride(R);
+    const int PC = K * RG;
+
+    ScanWave<T, NK, SPLIT> w;
+    w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + cc_, R, RG, PC, D, lane, cc_, &stage[wv][0][0]);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
+    const __amdgpu_buffer_rsrc_t rp =
+        make_rsrc(xdbl + (long)b * L * PC + (long)k * RG, ((unsigned)(L - 1) * PC + RG) * 4u);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(gym + (long)b * L * D, (unsigned)L * (unsigned)D * 4u);
+    const unsigned orow = (unsigned)D * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(gu + ((long)b * K + k) * L * D, (unsigned)L * orow);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(graw + ((long)b * K + k) * L * D, (unsigned)L * orow);
+    const int32_t *tk = table + (long)k * L;
+
+    const int span = W * kTP;
+    const int nsuper = (L + span - 1) / span;
+    float *hs = hst + ((long)b * K + k) * (long)(nsuper * W) * D;
+
+    for (int i = threadIdx.x; i < 2 * kMaxW * kTP; i += blockDim.x) {   // rows of absent waves: identity
+        const int bq = i / kTP;
+        if (bq % kMaxW >= W) {
+            agg[bq / kMaxW][bq % kMaxW][0][i % kTP] = 1.f;
+            agg[bq / kMaxW][bq % kMaxW][1][i % kTP] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    auto load_idx = [&](int s) -> int {
+        const int l = s * span + wv * kTP + r32;
+        return tk[l < L ? l : L - 1];
+    };
+
+    // ---- sweep 1: the state entering every tile
+    {
+        float carry = 0.f;
+        for (int s = 0; s < nsuper; ++s) {
+            TileOps<T, NK> cur;
+            w.fetch(rx, rp, load_idx(s), cur);
+            const int l0 = s * span + wv * kTP;
+            float Bp[16], Cp[16], a[16], bb[16], uf[16], preA[4], preH[4], runA, runH;
+            w.stage_bc(cur, Bp, Cp, false);
+            w.terms(cur, Bp, L - l0, a, bb, uf);
+            w.prefix(a, bb, preA, preH, runA, runH);
+            const int buf = s & 1;
+            if (hi == 0) {
+                agg[buf][wv][0][r32] = runA;
+                agg[buf][wv][1][r32] = runH;
+            }
+            __syncthreads();
+            float h = carry, hin = carry;
+#pragma unroll
+            for (int q = 0; q < kMaxW; ++q) {
+                if (q == wv) hin = h;
+                h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
+            }
+            carry = h;
+            if (hi == 0 && cok) hs[(long)(s * W + wv) * D + c] = hin;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- sweep 2: right to left
+    float zc = 0.f;                         // adjoint entering the current super-chunk from the right
+    float accA = 0.f, accD = 0.f, accb = 0.f;
+    float *trw = &tr[wv][0][0];
+    for (int s = nsuper - 1; s >= 0; --s) {
+        TileOps<T, NK> cur;
+        w.fetch(rx, rp, load_idx(s), cur);
+        const int l0 = s * span + wv * kTP;
+        const int nvalid = L - l0;
+        // gradient rows of my 16 positions: the x-row byte offsets staged by fetch() scale to fp32 rows
+        float gy[16];
+        {
+            float xo[16];
+            w.read_stage4(0, xo);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned off = __builtin_bit_cast(unsigned, xo[r]) / (unsigned)sizeof(T) * 4u + (unsigned)cc_ * 4u;
+                const bool ok = (r & 3) + 8 * (r >> 2) + 4 * hi < nvalid;
+                gy[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, ok ? off : kOutOfRange, 0, 0));
+            }
+        }
+        float Bp[16], Cp[16], a[16], bb[16], uf[16], tl[16], preA[4], preH[4], tA, tH;
+        w.stage_bc(cur, Bp, Cp, true);
+        w.terms(cur, Bp, nvalid, a, bb, uf, tl);
+        w.prefix(a, bb, preA, preH, tA, tH);
+        const float hin = hs[(long)(s * W + wv) * D + cc_];
+        // forward replay: h after / before every element
+        float hh[16], hp[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float hcur = fmaf(preA[g], hin, preH[g]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hp[4 * g + q] = hcur;
+                hcur = fmaf(a[4 * g + q], hcur, bb[4 * g + q]);
+                hh[4 * g + q] = hcur;
+            }
+        }
+        // adjoint run aggregates (zero entering from the right of the run), right to left inside a run
+        float cg[16], sa[4], sz[4];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cg[r] = Cp[r] * gy[r];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float pa = 1.f, pz = 0.f;
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                pz = a[4 * g + q] * (cg[4 * g + q] + pz);
+                pa *= a[4 * g + q];
+            }
+            sa[g] = pa;
+            sz[g] = pz;
+        }
+        // runs right to left: 2g+1 (upper half-wave) before 2g (lower); (RA, RZ) = everything to the right so far
+        float qA[4], qZ[4], RA = 1.f, RZ = 0.f;
+#pragma unroll
+        for (int g = 3; g >= 0; --g) {
+            float la, lz, ua, uz;
+            half_swap(sa[g], la, ua);
+            half_swap(sz[g], lz, uz);
+            const float mA = ua * RA, mZ = fmaf(ua, RZ, uz);     // after the upper run
+            qA[g] = hi ? RA : mA;
+            qZ[g] = hi ? RZ : mZ;
+            RZ = fmaf(la, mZ, lz);
+            RA = la * mA;
+        }
+        const int buf = s & 1;
+        if (hi == 0) {
+            agg[buf][wv][0][r32] = RA;
+            agg[buf][wv][1][r32] = RZ;
+        }
+        __syncthreads();
+        float z = zc, zin = zc;
+#pragma unroll
+        for (int q = kMaxW - 1; q >= 0; --q) {
+            if (q == wv) zin = z;
+            z = fmaf(agg[buf][q][0][r32], z, agg[buf][q][1][r32]);
+        }
+        zc = z;
+        // replay right to left, emit
+        const bool full = blockIdx.x * kTP + kTP <= D && l0 + kTP <= L;
+        const unsigned ov = (unsigned)((l0 + 4 * hi) * D + cc_) * (unsigned)sizeof(T);
+        float eb[16], ec[16];
+#pragma unroll
+        for (int g = 3; g >= 0; --g) {
+            float zr = fmaf(qA[g], zin, qZ[g]);
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                const int r = 4 * g + q;
+                const float gh = cg[r] + zr;
+                zr = a[r] * gh;
+                const float dtv = tl[r] * 0.693147180559945f;                 // dt
+                const float gdt = gh * fmaf(a[r] * w.An, hp[r], Bp[r] * uf[r] * 1.44269504088896f);
+                const float gr = gdt * (1.f - __builtin_amdgcn_exp2f(-tl[r]));   // softplus' = 1 - exp(-dt)
+                const float guv = fmaf(w.Dk, gy[r], gh * (tl[r] * Bp[r]));       // dt*B = t * (B ln2)
+                eb[r] = gh * dtv * uf[r];
+                ec[r] = gy[r] * hh[r];
+                accA = fmaf(gh * hp[r], a[r] * dtv, accA);
+                accD = fmaf(gy[r], uf[r], accD);
+                accb += gr;
+                const int p0 = q + 8 * g + 4 * hi;
+                const unsigned vo = (full || (cok && p0 < nvalid)) ? ov : kOutOfRange;
+                buf_store_elem<T>(ru, vo, (unsigned)(q + 8 * g) * orow, guv);
+                buf_store_elem<T>(rr, vo, (unsigned)(q + 8 * g) * orow, gr);
+            }
+        }
+        // position sums over this tile's 32 channels: transpose through LDS (16 channels per lane, then pair the
+        // half-waves), once for gB and once for gC
+        float sbc[2];
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pos = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                trw[pos * kTS + r32] = cok ? (which == 0 ? eb[r] : ec[r]) : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            float sv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = *reinterpret_cast<const float4 *>(trw + r32 * kTS + 16 * hi + 4 * j);
+                sv += (v.x + v.y) + (v.z + v.w);
+            }
+            __builtin_amdgcn_wave_barrier();
+            sbc[which] = sv + __shfl_xor(sv, 32, 64);
+        }
+        if (hi == 0 && l0 + r32 < L) {
+            atomicAdd(gB + ((long)b * K + k) * L + l0 + r32, sbc[0]);
+            atomicAdd(gC + ((long)b * K + k) * L + l0 + r32, sbc[1]);
+        }
+    }
+    // ---- per-channel sums: two half-waves, then the W waves
+    accA += __shfl_xor(accA, 32, 64);
+    accD += __shfl_xor(accD, 32, 64);
+    accb += __shfl_xor(accb, 32, 64);
+    if (hi == 0) {
+        red[wv][0][r32] = accA;
+        red[wv][1][r32] = accD;
+        red[wv][2][r32] = accb;
+    }
+    __syncthreads();
+    if (wv == 0 && hi == 0 && cok) {
+        float sA = 0.f, sD = 0.f, sb2 = 0.f;
+        for (int q = 0; q < W; ++q) {
+            sA += red[q][0][r32];
+            sD += red[q][1][r32];
+            sb2 += red[q][2][r32];
+        }
+        float *gp = gpar + ((long)b * K + k) * 3 * D + c;
+        gp[0] = sA;
+        gp[D] = sD;
+        gp[2 * D] = sb2;
     }
 }
 
@@ -846,9 +1101,17 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_cl_kernel(
 #pragma unroll
                     for (int v = 0; v < V; ++v) acc[it][v] += t[j][it][v];
     }
+    T *orow = y + pix * D;
+    if (eps < 0.f) {   // merge only (CrossMerge without out_norm: the training path and gradient merges)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c0 = (it * kWave + lane) * V;
+            if (c0 + V <= D) store_pack<T, V>(orow + c0, acc[it]);
+        }
+        return;
+    }
     float mean, rstd;
     wave_layernorm<V>(acc, NIT, D, lane, eps, mean, rstd);
-    T *orow = y + pix * D;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int c0 = (it * kWave + lane) * V;
@@ -1078,12 +1341,63 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     return TRAMBA_OK;
 }
 
+extern "C" size_t tramba_ss2d_scan_bwd_workspace(int batch, int l, int d, int k)
+{
+    if (batch <= 0 || l <= 0 || d <= 0 || k <= 0) return 0;
+    const size_t ntile = ((size_t)l + kTP - 1) / kTP + kMaxW;   // tiles rounded up to whole super-chunks
+    return (size_t)batch * k * ntile * d * sizeof(float);
+}
+
+extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
+                                       const float *dt_bias, const float *A, const float *Ds, const float *gym,
+                                       void *gu, void *graw, float *gB, float *gC, float *gpar, void *workspace,
+                                       size_t workspace_bytes, int batch, int l, int d, int k, int r, int dtype,
+                                       void *stream)
+{
+    TRAMBA_CHECK(x && xdbl && table && dt_w && dt_bias && A && Ds && gym && gu && graw && gB && gC && gpar && workspace,
+                 "ss2d_scan_bwd_cl: null tensor");
+    TRAMBA_CHECK(batch > 0 && l > 0 && d > 0 && k > 0 && r > 0, "ss2d_scan_bwd_cl: empty shape");
+    TRAMBA_CHECK(batch <= 65535 && k <= 65535 && r <= 64, "ss2d_scan_bwd_cl: B, K or dt_rank exceeds this build's limits");
+    TRAMBA_CHECK(aligned16(xdbl) && aligned16(workspace), "ss2d_scan_bwd_cl: xdbl / workspace must be 16-byte aligned");
+    TRAMBA_CHECK(workspace_bytes >= tramba_ss2d_scan_bwd_workspace(batch, l, d, k), "ss2d_scan_bwd_cl: workspace too small");
+    TRAMBA_CHECK(((double)l + 1024.0) * d * 4.0 < 2147483648.0 && (double)l * k * rg_bytes(r) < 2147483648.0,
+                 "ss2d_scan_bwd_cl: L*D too large for 32-bit offsets");
+    hipStream_t s = (hipStream_t)stream;
+    const int nk = (r + 15) / 16;
+    const int ct = (d + kTP - 1) / kTP;
+    int W = kMaxW;   // the kernel holds ~1 wave per SIMD: size W for one resident wavefront of work
+    while (W > 1 && (long)batch * k * ct * W > 1024) W >>= 1;
+    if (W > (l + kTP - 1) / kTP) W = (l + kTP - 1) / kTP;
+    dim3 grid(ct, k, batch), block(W * kWave);
+#define BWD_(T, NK_, SP_)                                                                                        \
+    hipLaunchKernelGGL((ss2d_scan_bwd_cl_kernel<T, NK_, SP_>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w,   \
+                       dt_bias, A, Ds, gym, (T *)gu, (T *)graw, gB, gC, gpar, (float *)workspace, l, d, k, r, W)
+#define BWD_NK_(T, SP_)                \
+    switch (nk) {                      \
+    case 1: BWD_(T, 1, SP_); break;    \
+    case 2: BWD_(T, 2, SP_); break;    \
+    case 3: BWD_(T, 3, SP_); break;    \
+    default: BWD_(T, 4, SP_); break;   \
+    }
+    if (dtype == TRAMBA_F32) { BWD_NK_(float, true) }
+    else if (dtype == TRAMBA_BF16) { BWD_NK_(__hip_bfloat16, false) }
+    else if (dtype == TRAMBA_F16) { BWD_NK_(__half, false) }
+    else {
+        set_error("ss2d_scan_bwd_cl: bad dtype %d", dtype);
+        return TRAMBA_ERR_ARG;
+    }
+#undef BWD_NK_
+#undef BWD_
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
 extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr, const int32_t *inv_idx,
                                          const float *ln_w, const float *ln_b, void *y, int batch, int l,
                                          int d, int k, float eps, int act, int ys_dtype, int dtype,
                                          void *stream)
 {
-    TRAMBA_CHECK(ys && inv_ptr && inv_idx && ln_w && ln_b && y, "ss2d_merge_norm_cl: null tensor");
+    TRAMBA_CHECK(ys && inv_ptr && inv_idx && y && (eps < 0.f || (ln_w && ln_b)), "ss2d_merge_norm_cl: null tensor");
     TRAMBA_CHECK(batch > 0 && l > 0 && d > 0 && k > 0, "ss2d_merge_norm_cl: empty shape");
     TRAMBA_CHECK(ys_dtype == TRAMBA_F32 || ys_dtype == dtype, "ss2d_merge_norm_cl: ys must be f32 or dtype");
     hipStream_t s = (hipStream_t)stream;
@@ -1098,12 +1412,13 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
     // Streaming form (measured, scripts/bench_scan.py): wins where one batch covers a pixel (K <= 4), the row
     // is at most two wave iterations and the map is large enough to fill the chip with 16-pixel waves
     // (6 TB/s on 96x96 D=256); elsewhere one wave per pixel is faster.
-    const bool stream_form = k <= 4 && nit <= 2 && npix >= 8192 && (double)k * l * d * 4.0 < 4294967296.0;
+    const bool sum_only = eps < 0.f;   // no LayerNorm: only the per-pixel form implements it
+    const bool stream_form = !sum_only && k <= 4 && nit <= 2 && npix >= 8192 && (double)k * l * d * 4.0 < 4294967296.0;
     const int pw = 16;
     const int nchunk = (l + pw - 1) / pw;
     const long nwaves = (long)batch * nchunk;
     // split-row form: a wide row (>= 4 wave iterations) on a map too small to fill the chip one wave per pixel
-    const bool split_form = !stream_form && nit >= 4 && npix <= 16384;
+    const bool split_form = !sum_only && !stream_form && nit >= 4 && npix <= 16384;
     dim3 grid(stream_form ? (unsigned)((nwaves + 3) / 4) : (split_form ? (unsigned)npix : (unsigned)((npix + 3) / 4))),
         block(256);
 #define GO_(TY, T, V_, N_)                                                                                    \

@@ -44,6 +44,8 @@ SIGNATURES = {
     "tramba_ss2d_group_stride": (c_int, [c_int]),
     "tramba_ss2d_scan_workspace": (ctypes.c_size_t, [c_int] * 4),
     "tramba_ss2d_scan_cl": (c_int, [c_vp] * 9 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
+    "tramba_ss2d_scan_bwd_workspace": (ctypes.c_size_t, [c_int] * 4),
+    "tramba_ss2d_scan_bwd_cl": (c_int, [c_vp] * 14 + [ctypes.c_size_t] + [c_int] * 6 + [c_vp]),
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_layernorm_bwd_parts": (c_i64, [c_i64]),
@@ -319,6 +321,37 @@ def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch
                                      _ptr(Ds), _ptr(ys), _ptr(ws), ws_bytes, b, l, d, k, r, dt(x), dt(ys), _stream()),
            "ss2d_scan_cl")
     return ys
+
+
+def ss2d_merge_sum_cl(ys, order: ScanOrder, out_dtype):
+    """ys (B, K, L, D) in sequence order -> (B, L, D): CrossMerge alone (no norm), fixed summation order."""
+    _dev(ys)
+    b, k, l, d = ys.shape
+    y = torch.empty((b, l, d), dtype=out_dtype, device=ys.device)
+    _check(lib().tramba_ss2d_merge_norm_cl(_ptr(ys), _ptr(order.inv_ptr), _ptr(order.inv_idx), None, None, _ptr(y), b, l,
+                                           d, k, -1.0, ACT_NONE, dt(ys), dt(y), _stream()), "ss2d_merge_sum_cl")
+    return y
+
+
+def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym):
+    """Backward of ss2d_scan_cl + merge.  gym (B, L, D) f32 = gradient of the merged map.
+    Returns gu, graw (B,K,L,D) x.dtype, gB, gC (B,K,L) f32, gpar (B,K,3,D) f32 (dA, dD, dbias per channel)."""
+    _dev(x, xdbl, dt_w, dt_bias, A, Ds, gym)
+    b, l, d = x.shape
+    k, r = order.k, dt_w.shape[-1]
+    if gym.dtype != torch.float32 or gym.shape != x.shape:
+        raise TrambaHipError("ss2d_scan_bwd_cl: gym must be f32 (B, L, D)")
+    gu = torch.empty((b, k, l, d), dtype=x.dtype, device=x.device)
+    graw = torch.empty_like(gu)
+    gB = torch.zeros((b, k, l), dtype=torch.float32, device=x.device)
+    gC = torch.zeros_like(gB)
+    gpar = torch.empty((b, k, 3, d), dtype=torch.float32, device=x.device)
+    ws_bytes = lib().tramba_ss2d_scan_bwd_workspace(b, l, d, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    _check(lib().tramba_ss2d_scan_bwd_cl(_ptr(x), _ptr(xdbl), _ptr(order.table), _ptr(dt_w), _ptr(dt_bias), _ptr(A),
+                                         _ptr(Ds), _ptr(gym), _ptr(gu), _ptr(graw), _ptr(gB), _ptr(gC), _ptr(gpar),
+                                         _ptr(ws), ws_bytes, b, l, d, k, r, dt(x), _stream()), "ss2d_scan_bwd_cl")
+    return gu, graw, gB, gC, gpar
 
 
 def ss2d_merge_norm_cl(ys, order: ScanOrder, ln_w, ln_b, eps, act, out_dtype):

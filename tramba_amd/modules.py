@@ -39,6 +39,9 @@ GEMM_BACKEND = os.environ.get("TRAMBA_GEMM", "hip")
 YS_DTYPE = os.environ.get("TRAMBA_YS", "f32")
 # training-path LayerNorm: "hip" = tramba_layernorm_cl / tramba_layernorm_bwd_cl, "torch" = F.layer_norm in fp32
 TRAIN_NORM_BACKEND = os.environ.get("TRAMBA_TRAIN_NORM", "hip")
+# training-path SS2D core: "hip" = fused channels-last scan forward + backward, "plugin" = the reference's graph
+# through the scan / merge plugin classes and selective_scan_cuda_oflex
+TRAIN_SCAN_BACKEND = os.environ.get("TRAMBA_TRAIN_SCAN", "hip")
 
 
 def to_cl(x: torch.Tensor) -> torch.Tensor:
@@ -446,6 +449,72 @@ def D_init(d_inner, copies=-1, device=None, merge=True):
 
 
 # ----------------------------------------------------------------------------- SS2D
+class _LinearF32Out(torch.autograd.Function):
+    """x (.., K) activations dtype, w (N, K) fp32 parameter-like -> (.., N) fp32 from the GEMM's fp32 accumulators
+    (the x_proj rows feed softplus / exp: keeping them unrounded matters).  Backward = two plain GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        wa = w.to(x.dtype).contiguous()
+        ctx.save_for_backward(x, wa)
+        ctx.wdtype = w.dtype
+        return hip.linear_cl(x.contiguous(), wa, out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wa = ctx.saved_tensors
+        ga = g.to(x.dtype)
+        gx = torch.matmul(ga, wa) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.matmul(ga.reshape(-1, ga.shape[-1]).t(), x.reshape(-1, x.shape[-1])).to(ctx.wdtype)
+        return gx, gw
+
+
+class _SS2DCoreCL(torch.autograd.Function):
+    """scan gather + dt_proj + selective scan + CrossMerge of forward_corev2 (vmamba.py:230-262) on channels-last
+    tensors with autograd, both directions HIP (training path): forward = the inference kernels, backward =
+    tramba_ss2d_scan_bwd_cl (adjoint recurrence, gradients in sequence order) + the small projections as batched
+    GEMMs.  x (B,L,D); xdbl (B,L,K*RG) f32; dt_w (K,D,R), dt_bias (K*D), a_neg (K*D) = -exp(A_logs), ds (K*D) f32.
+    Returns the merged map (B,L,D) f32 (before out_norm)."""
+
+    @staticmethod
+    def forward(ctx, x, xdbl, dt_w, dt_bias, a_neg, ds, order):
+        x = x.contiguous()
+        xdbl = xdbl.contiguous()
+        dt_w, dt_bias, a_neg, ds = (t.detach().float().contiguous() for t in (dt_w, dt_bias, a_neg, ds))
+        ys = hip.ss2d_scan_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, torch.float32)
+        ctx.save_for_backward(x, xdbl, dt_w, dt_bias, a_neg, ds)
+        ctx.order = order
+        return hip.ss2d_merge_sum_cl(ys, order, torch.float32)
+
+    @staticmethod
+    def backward(ctx, gym):
+        x, xdbl, dt_w, dt_bias, a_neg, ds = ctx.saved_tensors
+        order = ctx.order
+        b, l, d = x.shape
+        k, r = order.k, dt_w.shape[-1]
+        rg = hip.ss2d_group_stride(r)
+        r8 = rg - 4
+        gu, graw, g_b, g_c, gpar = hip.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds,
+                                                       gym.contiguous().float())
+        gx = hip.ss2d_merge_sum_cl(gu, order, x.dtype)
+        tbl = order.table.long()
+        xd = xdbl.view(b, l, k, rg)
+        ranks = torch.stack([xd[:, tbl[i], i, :r] for i in range(k)], dim=1)            # (B,K,L,R) f32
+        cd = graw.dtype
+        g_dtw = torch.einsum("bkld,bklr->kdr", graw, ranks.to(cd)).float()
+        g_ranks = torch.einsum("bkld,kdr->bklr", graw, dt_w.to(cd)).float()
+        g_xd = torch.zeros_like(xd)
+        for i in range(k):
+            g_xd[:, :, i, :r].index_add_(1, tbl[i], g_ranks[:, i])
+            g_xd[:, :, i, r8].index_add_(1, tbl[i], g_b[:, i])
+            g_xd[:, :, i, r8 + 1].index_add_(1, tbl[i], g_c[:, i])
+        gp = gpar.sum(dim=0)                                                              # (K,3,D)
+        return (gx, g_xd.view(b, l, k * rg), g_dtw, gp[:, 2].reshape(-1), gp[:, 0].reshape(-1), gp[:, 1].reshape(-1),
+                None)
+
+
 class SS2D(nn.Module):
     """vmamba.py:18-323, forward_type v2 / channel_first / disable_z (the only configuration the
     shipped models use).  ``scan`` / ``merge`` / ``k_group`` are the reference's plugin API."""
@@ -521,6 +590,25 @@ class SS2D(nn.Module):
                                    self.out_norm.eps, hip.ACT_GELU, x.dtype)
         return y.view(b, h, w, d)
 
+    def _train_fused_ok(self, x):
+        return (TRAIN_SCAN_BACKEND == "hip" and x.is_cuda and self.d_state == 1 and self.dt_rank <= 64
+                and getattr(self.scan, "_tramba_family", None) is not None
+                and getattr(self.merge, "_tramba_family", None) == self.scan._tramba_family
+                and self.scan._tramba_k == self.k_group)
+
+    def _core_train_cl(self, x):
+        """Training path of forward_corev2 without leaving channels-last: x_proj once in spatial order (autograd
+        GEMM), then _SS2DCoreCL, out_norm (HIP LayerNorm autograd) and GELU."""
+        b, h, w, d = x.shape
+        order = hip.scan_order(self.scan._tramba_family, h, w, x.device)
+        xf = x.reshape(b, h * w, d)
+        xdbl = _LinearF32Out.apply(xf, hip.pad_x_proj_weight(self.x_proj_weight.float()))
+        a_neg = -torch.exp(self.A_logs.float()).reshape(-1)
+        ym = _SS2DCoreCL.apply(xf, xdbl, self.dt_projs_weight.float(), self.dt_projs_bias.float().reshape(-1), a_neg,
+                               self.Ds.float(), order)
+        y = self.out_norm._forward_cl(ym.view(b, h, w, d), act=hip.ACT_GELU)
+        return y.to(x.dtype)
+
     def _core_plugin_cl(self, x):
         """Reference graph (vmamba.py:230-273) with the scan classes as plugins; autograd-capable."""
         b, h, w, d = x.shape
@@ -552,7 +640,12 @@ class SS2D(nn.Module):
                 x = F.silu(_dwconv_train_cl(x, self.conv2d))
         else:
             x = F.silu(x)
-        y = self._core_fused_cl(x) if self._fused_ok(x) else self._core_plugin_cl(x)
+        if self._fused_ok(x):
+            y = self._core_fused_cl(x)
+        elif self._train_fused_ok(x):
+            y = self._core_train_cl(x)
+        else:
+            y = self._core_plugin_cl(x)
         return self.dropout(self.out_proj._forward_cl(y, residual=residual))
 
     def forward(self, x):
