@@ -503,8 +503,9 @@ class _SS2DCoreCL(torch.autograd.Function):
         xd = xdbl.view(b, l, k, rg)
         ranks = torch.stack([xd[:, tbl[i], i, :r] for i in range(k)], dim=1)            # (B,K,L,R) f32
         cd = graw.dtype
-        g_dtw = torch.einsum("bkld,bklr->kdr", graw, ranks.to(cd)).float()
-        g_ranks = torch.einsum("bkld,kdr->bklr", graw, dt_w.to(cd)).float()
+        # batched GEMMs on views (einsum would first copy the K-fold graw into its own layout)
+        g_dtw = torch.matmul(graw.transpose(-1, -2), ranks.to(cd)).float().sum(dim=0)       # (K,D,R)
+        g_ranks = torch.matmul(graw, dt_w.to(cd).unsqueeze(0)).float()                       # (B,K,L,R)
         g_xd = torch.zeros_like(xd)
         for i in range(k):
             g_xd[:, :, i, :r].index_add_(1, tbl[i], g_ranks[:, i])
