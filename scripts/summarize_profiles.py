@@ -2,6 +2,7 @@
 """Distil gpurun_out/<tag>/ (written by scripts/collect_profiles.sh on the MI355X box) into profiles/.
 
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (MIOpen find-mode kernels dropped)
+  profiles/<tag>_train_kernel_stats.csv  the same for 3 training steps (scripts/profile_train.py)
   profiles/<tag>_bench.json         the bench.py line (and the --train line)
   profiles/<tag>_traffic.json       HBM bytes per launch of the two scan kernels from the PMC passes:
                                     traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB -- on gfx950 FETCH_SIZE counts
@@ -25,6 +26,14 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()
     w.writerows(rows)
+
+tstats = glob.glob(os.path.join(src, "trace_train", "*", "*kernel_stats.csv"))
+if tstats:   # 3 training steps (scripts/profile_train.py): fwd + bwd + Adam, batch 8
+    trows = [r for r in csv.DictReader(open(tstats[0])) if "naive_conv" not in r["Name"]]
+    with open(os.path.join(dst, f"{tag}_train_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(trows[0].keys()))
+        w.writeheader()
+        w.writerows(trows)
 
 lines = {}
 for name in ("bench", "bench_train"):

@@ -534,17 +534,19 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
     // lean kernel: whole 64-deep K steps, and a 64-row operand panel within 32-bit byte offsets
     static const bool no_lean = getenv("TRAMBA_GEMM_LEAN") && strcmp(getenv("TRAMBA_GEMM_LEAN"), "0") == 0;
     const bool lean_ok = !no_lean && k % 64 == 0 && (double)k * 2.0 * 128.0 < 2147483648.0;
+    const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
     if (force_big || (big >= 2048 && k >= 1024)) {
         dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
         hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2, CONV>), grid, block, 0, s, (const T *)x,
                            (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);
-    } else if (!CONV && lean_ok && k <= 128) {
+    } else if (!CONV && lean_ok && !(k >= 1024 && tiles64 <= 320)) {
+        // 2-stage ring, 82 VGPRs: 5-6 resident blocks per CU hide the shallower prefetch (measured on the model's
+        // 18 shapes, scripts/bench_gemm.py: 2.45 -> 2.20 ms per forward against the generic kernel)
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
         hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 1>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
                            (const T *)res, (TO *)y, m, n, k, act);
-    } else if (!CONV && lean_ok && k >= 1024) {
-        // (the 4-stage lean kernel holds 168 VGPRs against the generic kernel's 140: it wins where the K loop is
-        //  long and blocks are few, and loses a resident block per CU on the short-K, many-block layers)
+    } else if (!CONV && lean_ok) {
+        // long K on a grid of about one block per CU: nothing else hides the load latency, so 4 stages (168 VGPRs)
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
         hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 3>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
                            (const T *)res, (TO *)y, m, n, k, act);
