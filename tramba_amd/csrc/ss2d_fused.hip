@@ -744,8 +744,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
 // per-sequence chain.  A sequence of one (b, k, 32-channel tile) is cut into NSEG segments of NT
 // tiles; every WAVE owns one segment and walks its tiles alone.
 //   PASS 0  reduces the segment to its (decay, state) pair            -> agg   (B,K,NSEG,D) float2
-//   carry   a tiny kernel scans the NSEG pairs of each channel         -> carry (B,K,NSEG,D) float
-//   PASS 1  recomputes the segment from its carry-in and streams y out
+//   PASS 1  folds the preceding segments' pairs into its carry-in, recomputes the segment and streams y out
 // The per-element terms are evaluated twice (~1.6x the arithmetic of the chained kernel), but the
 // launch has B*K*(D/32)*NSEG independent waves instead of B*K*(D/32) serial chains of 8 waves, so the
 // whole chip is busy: 2-3x faster on this model's shapes.  Segments of one sequence are independent,
@@ -766,22 +765,6 @@ __host__ inline SegPlan seg_plan(int l, long rowtiles)
     p.nt = nt;
     p.nseg = (p.ntiles + nt - 1) / nt;
     return p;
-}
-
-__global__ __launch_bounds__(256) void ss2d_seg_carry_kernel(const float2 *__restrict__ agg, float *__restrict__ carry,
-                                                            long nchain, int nseg, int D)
-{
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (b*K + k) * D + c
-    if (i >= nchain) return;
-    const long bk = i / D;
-    const int c = (int)(i % D);
-    float run = 0.f;
-    for (int sgm = 0; sgm < nseg; ++sgm) {
-        const long o = (bk * nseg + sgm) * D + c;
-        const float2 ah = agg[o];
-        carry[o] = run;
-        run = fmaf(ah.x, run, ah.y);
-    }
 }
 
 template <typename T, typename TY, int NK, bool SPLIT, int PASS>
@@ -843,7 +826,23 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
 
     float runA = 1.f, runH = 0.f;  // PASS 0: aggregate of the segment so far
     float hin = 0.f;               // PASS 1: state entering the current tile
-    if (PASS == 1 && carry) hin = carry[(((long)b * K + k) * NSEG + sgm) * D + cc_];
+    if (PASS == 1 && NSEG > 1) {
+        // carry-in = fold of the preceding segments' (decay, state) pairs: <= NSEG independent 8-byte loads per lane
+        // and a short fma chain, instead of a separate latency-bound carry-scan launch between the two passes
+        const float2 *ag = agg + ((long)b * K + k) * NSEG * D + cc_;
+        int s2 = 0;
+        for (; s2 + 8 <= sgm; s2 += 8) {
+            float2 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ag[(long)(s2 + j) * D];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hin = fmaf(v[j].x, hin, v[j].y);
+        }
+        for (; s2 < sgm; ++s2) {
+            const float2 v = ag[(long)s2 * D];
+            hin = fmaf(v.x, hin, v.y);
+        }
+    }
     const bool cfull = ctile * kTP + kTP <= D;
 
     const int ntp = (NT + NS - 1) / NS * NS;  // whole ring trips; padding tiles run on the identity
@@ -1295,7 +1294,7 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     const bool use_seg = workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) &&
                          (forced == 1 || (forced == 0 && seg_wins));
     if (use_seg) {
-        // ---- wave-segment form: pass 0 -> carry scan -> pass 1 (single pass when one segment suffices)
+        // ---- wave-segment form: pass 0 -> pass 1 (single pass when one segment suffices)
         TRAMBA_CHECK(aligned16(workspace), "ss2d_scan_cl: workspace must be 16-byte aligned");
         const long nwaves = (long)batch * k * ct * p.nseg;
         float2 *agg = reinterpret_cast<float2 *>(workspace);
@@ -1310,9 +1309,6 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
                        ct, p.nt, p.nseg, nwaves)
         if (p.nseg > 1) {
             BY_DTYPE_(SEG0_)
-            const long nchain = (long)batch * k * d;
-            hipLaunchKernelGGL(ss2d_seg_carry_kernel, dim3((unsigned)((nchain + 255) / 256)), dim3(256), 0, s, agg,
-                               carry, nchain, p.nseg, d);
         }
         BY_DTYPE_(SEG1_)
 #undef SEG0_
