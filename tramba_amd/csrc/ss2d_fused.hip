@@ -556,9 +556,11 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     // ---- sweep 1: the state entering every tile
     {
         float carry = 0.f;
+        int idx_cur = load_idx(0);
         for (int s = 0; s < nsuper; ++s) {
             TileOps<T, NK> cur;
-            w.fetch(rx, rp, load_idx(s), cur);
+            w.fetch(rx, rp, idx_cur, cur);
+            idx_cur = load_idx(s + 1 < nsuper ? s + 1 : s);   // next tile's index vector rides behind the gathers
             const int l0 = s * span + wv * kTP;
             float Bp[16], Cp[16], a[16], bb[16], uf[16], preA[4], preH[4], runA, runH;
             w.stage_bc(cur, Bp, Cp, false);
@@ -588,9 +590,11 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     float zc = 0.f;                         // adjoint entering the current super-chunk from the right
     float accA = 0.f, accD = 0.f, accb = 0.f;
     float *trw = &tr[wv][0][0];
+    int idx_rev = load_idx(nsuper - 1);
     for (int s = nsuper - 1; s >= 0; --s) {
         TileOps<T, NK> cur;
-        w.fetch(rx, rp, load_idx(s), cur);
+        w.fetch(rx, rp, idx_rev, cur);
+        idx_rev = load_idx(s > 0 ? s - 1 : 0);
         const int l0 = s * span + wv * kTP;
         const int nvalid = L - l0;
         // gradient rows of my 16 positions: the x-row byte offsets staged by fetch() scale to fp32 rows
@@ -1361,8 +1365,8 @@ extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const i
     hipStream_t s = (hipStream_t)stream;
     const int nk = (r + 15) / 16;
     const int ct = (d + kTP - 1) / kTP;
-    int W = kMaxW;   // the kernel holds ~1 wave per SIMD: size W for one resident wavefront of work
-    while (W > 1 && (long)batch * k * ct * W > 1024) W >>= 1;
+    int W = kMaxW;   // ~220-250 VGPRs: 2 waves per SIMD = 2048 wave slots; size W for one resident wavefront of work
+    while (W > 1 && (long)batch * k * ct * W > 2048) W >>= 1;
     if (W > (l + kTP - 1) / kTP) W = (l + kTP - 1) / kTP;
     dim3 grid(ct, k, batch), block(W * kWave);
 #define BWD_(T, NK_, SP_)                                                                                        \
