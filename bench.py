@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (no 2:1 sparsity)
 
 
 def pmc_traffic(key):
@@ -221,17 +222,20 @@ def main():
 
     # ---- roofline of the dominant kernel: eager pass of the same steps with HIP events around
     #      every launch of the fused scan kernel (events cannot live inside a captured graph)
-    roof = roof_b = cpu = None
+    roof = roof_b = roof_g = cpu = None
     if rank == 0:
         from tramba_amd import models as _models
         overlap_was = _models.OVERLAP_BRANCHES
         _models.OVERLAP_BRANCHES = False      # one stream: a launch is timed alone, like the rocprofv3 trace
         hip.profile_enable(hip.PROF_SCAN_FUSED, True)
+        hip.profile_enable(hip.PROF_GEMM, True)
         nrep = min(args.steps, 10)
         for _ in range(nrep):
             step()
         n, ms, nbytes = hip.profile_read(hip.PROF_SCAN_FUSED)
+        ng, msg, flops = hip.profile_read(hip.PROF_GEMM)
         hip.profile_enable(hip.PROF_SCAN_FUSED, False)
+        hip.profile_enable(hip.PROF_GEMM, False)
         _models.OVERLAP_BRANCHES = overlap_was
         gbs = nbytes / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "ss2d_scan_cl_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
@@ -241,6 +245,12 @@ def main():
                 "note": "achieved = sum of algorithmic bytes / sum of HIP-event time over the fused-scan launches of "
                         "a step (single-stream eager pass, so each launch runs alone); traffic = PMC bytes of the "
                         "largest launch (Helix 96x96)"}
+        tfs = flops / (msg * 1e-3) / 1e12
+        roof_g = {"bound": "mfma", "kernel": "linear_lean_kernel / linear_tiled_kernel (1x1-conv projections)",
+                  "achieved": round(tfs, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_PEAK_TFS, 4),
+                  "traffic": None, "launches": ng, "avg_us": round(msg / ng * 1e3, 2), "ms_per_step": round(msg / nrep, 3),
+                  "note": "2*M*N*K of every tramba_linear_cl launch of a step / their HIP-event time; these GEMMs are "
+                          "small (M = 576..36864, K <= 4096): LDS- and latency-bound, far from the dense MFMA peak"}
         roof_b = boundary_scan_roofline(dtype)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.img)
@@ -262,7 +272,7 @@ def main():
                        "launch": ("hipGraph replay" if graph is not None else "eager") +
                                  (", decoder guide branches on a side stream"
                                   if os.environ.get("TRAMBA_OVERLAP", "1") != "0" else "")},
-            "roofline": roof, "roofline_boundary": roof_b, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_boundary": roof_b, "roofline_gemm": roof_g, "cpu_baseline": cpu,
         }
         if train_obj is not None:
             line["train"] = train_obj

@@ -66,12 +66,14 @@ int tramba_abi_version(void);
  * roofline figure).  enable=1 brackets every launch of kernel class `which` with events on
  * the launch stream; tramba_profile_read() synchronises those events and returns the
  * number of launches, writing the summed duration in milliseconds and the summed ALGORITHMIC
- * bytes of those launches (DESIGN.md states the per-kernel formula). */
+ * work of those launches: bytes for the scan classes, flop (2*M*N*K) for TRAMBA_PROF_GEMM
+ * (DESIGN.md states the per-kernel formula). */
 int tramba_profile_enable(int which, int enable);
 int tramba_profile_read(int which, double *total_ms, double *total_bytes);
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1
-#define TRAMBA_PROF_COUNT 2
+#define TRAMBA_PROF_GEMM 2          /* tramba_linear_cl (1x1-conv projections) */
+#define TRAMBA_PROF_COUNT 3
 
 /* ------------------------------------------------------------------ scan-order tables (host) */
 /* Number of directions K of a family. */

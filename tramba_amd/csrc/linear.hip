@@ -619,6 +619,7 @@ extern "C" int tramba_linear_cl(const void *x, const void *w, const float *bias,
     const long gy = (m + 127) / 128, gx = (n + 127) / 128;
     TRAMBA_CHECK(gy <= 65535, "linear_cl: M=%ld exceeds grid limits", (long)m);
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(TRAMBA_PROF_GEMM, s, 2.0 * (double)m * n * k);
     dim3 grid((unsigned)gx, (unsigned)gy), block(256);
     const int vec = (k % 8 == 0) && aligned16(x) && aligned16(w);
     const bool tiled = vec && dtype != TRAMBA_F32 && aligned16(y) && (residual == nullptr || aligned16(residual)) &&

@@ -20,7 +20,7 @@ ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 SCAN_RASTER, SCAN_LINE, SCAN_HELIX, SCAN_WINDOW, SCAN_DILATION = range(5)
 FAMILY = {"raster": SCAN_RASTER, "line": SCAN_LINE, "helix": SCAN_HELIX, "window": SCAN_WINDOW,
           "dilation": SCAN_DILATION}
-PROF_SCAN_BOUNDARY, PROF_SCAN_FUSED = 0, 1
+PROF_SCAN_BOUNDARY, PROF_SCAN_FUSED, PROF_GEMM = 0, 1, 2
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
