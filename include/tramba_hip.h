@@ -52,7 +52,8 @@ typedef enum {
     TRAMBA_SCAN_DILATION = 4  /* K=4, param = dilation rate (0 = 4) */
 } tramba_scan_family;
 
-typedef enum { TRAMBA_ACT_NONE = 0, TRAMBA_ACT_SILU = 1, TRAMBA_ACT_GELU = 2 } tramba_act;
+typedef enum { TRAMBA_ACT_NONE = 0, TRAMBA_ACT_SILU = 1, TRAMBA_ACT_GELU = 2,
+               TRAMBA_ACT_SIGMOID_GATE = 3 /* GEMM epilogue only: y = sigmoid(acc + bias) * residual */ } tramba_act;
 
 #define TRAMBA_OK 0
 #define TRAMBA_ERR_ARG (-1)
@@ -198,6 +199,11 @@ int tramba_dct_split_cl(const void *x, const float *wx, const float *wy, float *
  * last.  MFMA path for f16/bf16. */
 int tramba_linear_cl(const void *x, const void *w, const float *bias, const void *residual, void *y,
                      int64_t m, int n, int k, int act, int dtype, int out_dtype, void *stream);
+/* Same with the K dimension of x split over two tensors, x = [x1 (M, k1) | x2 (M, k - k1)]: Linear2d applied to
+ * torch.cat((x1, x2), dim=-1) without materialising the concatenation (decoder concat_back_dim, Trambav6.py:124;
+ * FreqSS2Dv6, freq_mamba.py:52).  16-bit dtypes, k1 % 64 == 0 and (k - k1) % 64 == 0. */
+int tramba_linear2_cl(const void *x1, const void *x2, int k1, const void *w, const float *bias, const void *residual,
+                      void *y, int64_t m, int n, int k, int act, int dtype, int out_dtype, void *stream);
 
 /* ------------------------------------------------------------------ dense convs of the VMamba stem */
 /* Implicit-GEMM 3x3 / stride 2 / pad 1 convolution on a channels-last map (patch_embed[5] and the three

@@ -476,3 +476,24 @@ def test_ss2d_core_training_gradients(dtype, fam, h, d, r, b):
     close(dl[3].grad, leaves[3].grad, "gbias", 5e-4 if f32 else 5e-2)
     close(dl[4].grad, leaves[4].grad, "gA", 5e-4 if f32 else 5e-2)
     close(dl[5].grad, leaves[5].grad, "gD", 5e-4 if f32 else 5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(2304, 512, 512, 512), (300, 128, 64, 192), (9216, 256, 256, 256), (1000, 72, 128, 64)])
+def test_linear2_cl_matches_concatenated_gemm(dtype, cfg):
+    """tramba_linear2_cl(x1, x2) == tramba_linear_cl(cat(x1, x2)) bit for bit (same K order, same kernel), with the
+    bias / GELU / residual epilogue and with the sigmoid gate (freq_mamba.py:52-56)."""
+    m, n, k1, k2 = cfg
+    H = hip()
+    g = torch.Generator().manual_seed(m + n + k1)
+    x1 = torch.randn(m, k1, generator=g).to(dtype).to(DEV)
+    x2 = torch.randn(m, k2, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(n, k1 + k2, generator=g) * (k1 + k2) ** -0.5).to(dtype).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(m, n, generator=g).to(dtype).to(DEV)
+    xc = torch.cat((x1, x2), dim=-1)
+    assert torch.equal(H.linear2_cl(x1, x2, w, bias, res, 2), H.linear_cl(xc, w, bias, res, 2))
+    assert torch.equal(H.linear2_cl(x1, x2, w, None, None, 0, torch.float32), H.linear_cl(xc, w, None, None, 0, torch.float32))
+    gate = H.linear2_cl(x1, x2, w, None, res, H.ACT_SIGMOID_GATE)
+    want = torch.sigmoid(xc.double() @ w.double().T) * res.double()
+    np.testing.assert_allclose(gate.cpu().double().numpy(), want.cpu().numpy(), rtol=2e-2, atol=2e-2)

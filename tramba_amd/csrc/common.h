@@ -125,6 +125,7 @@ __device__ __forceinline__ float apply_act(float x, int act)
 {
     if (act == TRAMBA_ACT_SILU) return siluf_(x);
     if (act == TRAMBA_ACT_GELU) return geluf_(x);
+    if (act == TRAMBA_ACT_SIGMOID_GATE) return sigmoidf_(x);   // the caller multiplies by the gated tensor
     return x;
 }
 

@@ -193,7 +193,7 @@ __device__ __forceinline__ void tile_epilogue(acc16_t (&acc)[BM / 64][BN / 64], 
                 float rv[CPL];
                 load_pack<T, CPL>(res + grow * N + gcol, rv);
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) o[q] += rv[q];
+                for (int q = 0; q < CPL; ++q) o[q] = act == TRAMBA_ACT_SIGMOID_GATE ? o[q] * rv[q] : o[q] + rv[q];
             }
             store_pack<TO, CPL>(y + grow * N + gcol, o);
         } else {
@@ -201,7 +201,10 @@ __device__ __forceinline__ void tile_epilogue(acc16_t (&acc)[BM / 64][BN / 64], 
             for (int q = 0; q < CPL; ++q) {
                 if (gcol + q < N) {
                     float t = apply_act(o[q] + (bias ? bias[gcol + q] : 0.f), act);
-                    if (res) t += Cvt<T>::to_f(res[grow * N + gcol + q]);
+                    if (res) {
+                        const float rv = Cvt<T>::to_f(res[grow * N + gcol + q]);
+                        t = act == TRAMBA_ACT_SIGMOID_GATE ? t * rv : t + rv;
+                    }
                     y[grow * N + gcol + q] = Cvt<TO>::from_f(t);
                 }
             }
@@ -395,8 +398,9 @@ template <typename T, typename TO, int BM, int BN, int PF>
 __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ x, const T *__restrict__ w,
                                                          const float *__restrict__ bias,
                                                          const T *__restrict__ res, TO *__restrict__ y, long M,
-                                                         int N, int K, int act)
+                                                         int N, int K, int act, const T *__restrict__ x2, int K1)
 {
+    // x2 != nullptr: A = [x (M, K1) | x2 (M, K - K1)], both halves whole K steps (no concatenation in memory)
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_PER_T = BM * (kBK / 8) / 256, B_PER_T = BN * (kBK / 8) / 256;
     constexpr int TILE_BYTES = (BM + BN) * kBK * 2;
@@ -422,15 +426,20 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
     const unsigned rowb = (unsigned)K * 2u;   // bytes per operand row
     const long mrows = M - m0 < BM ? M - m0 : BM;
     const int nrows = N - n0 < BN ? N - n0 : BN;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(x + m0 * K, (unsigned)mrows * rowb);
+    const int ka = x2 ? K1 : K;                       // row length of the first A source
+    const unsigned rowa = (unsigned)ka * 2u, rowa2 = (unsigned)(K - ka) * 2u;
+    const int nk1 = ka / kBK;                         // K steps served by the first source
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(x + m0 * ka, (unsigned)mrows * rowa);
+    const __amdgpu_buffer_rsrc_t ra2 = make_rsrc(x2 ? x2 + m0 * (K - ka) : x, x2 ? (unsigned)mrows * rowa2 : 0u);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(w + (long)n0 * K, (unsigned)nrows * rowb);
 
     // loop-invariant per-thread offsets: global (row*K + 8c elements) and LDS (swizzled chunk)
-    unsigned ag[A_PER_T], bg[B_PER_T], al[A_PER_T], bl[B_PER_T];
+    unsigned ag[A_PER_T], ag2[A_PER_T], bg[B_PER_T], al[A_PER_T], bl[B_PER_T];
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
         const int q = tid + i * 256, row = q >> 3, c = q & 7;
-        ag[i] = (unsigned)row * rowb + (unsigned)c * 16u;
+        ag[i] = (unsigned)row * rowa + (unsigned)c * 16u;
+        ag2[i] = (unsigned)row * rowa2 + (unsigned)c * 16u;
         al[i] = (unsigned)(row * 128 + swz_chunk(row, c) * 16);
     }
 #pragma unroll
@@ -463,8 +472,14 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
     struct Stage { v4u_t a[A_PER_T], b[B_PER_T]; };
     auto gload = [&](int kt, Stage &st) {   // a K step past the end reads the following rows / zeros: never used
         const unsigned so = (unsigned)kt * (kBK * 2);
+        // A comes from the first source for kt < nk1, from the second after it: a block-uniform SELECT of
+        // descriptor, scalar offset and per-thread offset (not a branch around the loads)
+        const bool first = kt < nk1;
+        const __amdgpu_buffer_rsrc_t rsel = first ? ra : ra2;
+        const unsigned soa = first ? so : so - (unsigned)nk1 * (kBK * 2);
 #pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) st.a[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, ag[i], so, 0);
+        for (int i = 0; i < A_PER_T; ++i)
+            st.a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsel, first ? ag[i] : ag2[i], soa, 0);
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) st.b[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, bg[i], so, 0);
     };
@@ -524,7 +539,8 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
 // count and K are large.  TRAMBA_GEMM_TILE=128x128 forces it (tuning aid).
 template <typename T, typename TO, bool CONV = false>
 static void launch_tiled(const void *x, const void *w, const float *bias, const void *res, void *y, long m, int n,
-                         int k, int act, hipStream_t s, ConvGeom cg = ConvGeom{0, 0, 0, 0, 0})
+                         int k, int act, hipStream_t s, ConvGeom cg = ConvGeom{0, 0, 0, 0, 0},
+                         const void *x2 = nullptr, int k1 = 0)
 {
     static const bool force_big = [] {
         const char *e = getenv("TRAMBA_GEMM_TILE");
@@ -535,7 +551,7 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
     static const bool no_lean = getenv("TRAMBA_GEMM_LEAN") && strcmp(getenv("TRAMBA_GEMM_LEAN"), "0") == 0;
     const bool lean_ok = !no_lean && k % 64 == 0 && (double)k * 2.0 * 128.0 < 2147483648.0;
     const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
-    if (force_big || (big >= 2048 && k >= 1024)) {
+    if (!x2 && (force_big || (big >= 2048 && k >= 1024))) {
         dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
         hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2, CONV>), grid, block, 0, s, (const T *)x,
                            (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);
@@ -544,12 +560,12 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
         // 18 shapes, scripts/bench_gemm.py: 2.45 -> 2.20 ms per forward against the generic kernel)
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
         hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 1>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
-                           (const T *)res, (TO *)y, m, n, k, act);
+                           (const T *)res, (TO *)y, m, n, k, act, (const T *)x2, k1);
     } else if (!CONV && lean_ok) {
         // long K on a grid of about one block per CU: nothing else hides the load latency, so 4 stages (168 VGPRs)
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
         hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 3>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
-                           (const T *)res, (TO *)y, m, n, k, act);
+                           (const T *)res, (TO *)y, m, n, k, act, (const T *)x2, k1);
     } else if (k <= 128) {  // 1-2 K steps: a 2-stage ring, no padded dummy steps
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
         hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 64, 64, 1, CONV>), grid, block, 0, s, (const T *)x,
@@ -657,6 +673,32 @@ extern "C" int tramba_linear_cl(const void *x, const void *w, const float *bias,
     } else {
         set_error("linear_cl: bad dtype %d", dtype);
         return TRAMBA_ERR_ARG;
+    }
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_linear2_cl(const void *x1, const void *x2, int k1, const void *w, const float *bias,
+                                 const void *residual, void *y, int64_t m, int n, int k, int act, int dtype,
+                                 int out_dtype, void *stream)
+{
+    TRAMBA_CHECK(x1 && x2 && w && y, "linear2_cl: null tensor");
+    TRAMBA_CHECK(m > 0 && n > 0 && k > 0 && k1 > 0 && k1 < k, "linear2_cl: empty shape");
+    TRAMBA_CHECK(dtype == TRAMBA_BF16 || dtype == TRAMBA_F16, "linear2_cl: 16-bit dtypes only");
+    TRAMBA_CHECK(out_dtype == dtype || out_dtype == TRAMBA_F32, "linear2_cl: out dtype must be dtype or f32");
+    TRAMBA_CHECK(k1 % 64 == 0 && (k - k1) % 64 == 0, "linear2_cl: both K parts must be multiples of 64 (%d + %d)", k1, k - k1);
+    TRAMBA_CHECK(aligned16(x1) && aligned16(x2) && aligned16(w) && aligned16(y) && (residual == nullptr || aligned16(residual)),
+                 "linear2_cl: tensors must be 16-byte aligned");
+    TRAMBA_CHECK((m + 63) / 64 <= 65535 && (double)k * 2.0 * 128.0 < 2147483648.0, "linear2_cl: shape exceeds this build's limits");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(TRAMBA_PROF_GEMM, s, 2.0 * (double)m * n * k);
+    const ConvGeom nocg{0, 0, 0, 0, 0};
+    if (dtype == TRAMBA_BF16) {
+        if (out_dtype == TRAMBA_F32) launch_tiled<__hip_bfloat16, float>(x1, w, bias, residual, y, m, n, k, act, s, nocg, x2, k1);
+        else launch_tiled<__hip_bfloat16, __hip_bfloat16>(x1, w, bias, residual, y, m, n, k, act, s, nocg, x2, k1);
+    } else {
+        if (out_dtype == TRAMBA_F32) launch_tiled<__half, float>(x1, w, bias, residual, y, m, n, k, act, s, nocg, x2, k1);
+        else launch_tiled<__half, __half>(x1, w, bias, residual, y, m, n, k, act, s, nocg, x2, k1);
     }
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;

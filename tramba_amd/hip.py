@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libtramba_hip.so")
 
 F32, F16, BF16 = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_SIGMOID_GATE = 0, 1, 2, 3
 SCAN_RASTER, SCAN_LINE, SCAN_HELIX, SCAN_WINDOW, SCAN_DILATION = range(5)
 FAMILY = {"raster": SCAN_RASTER, "line": SCAN_LINE, "helix": SCAN_HELIX, "window": SCAN_WINDOW,
           "dilation": SCAN_DILATION}
@@ -59,6 +59,7 @@ SIGNATURES = {
     "tramba_dwconv_wgrad_cl": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_linear2_cl": (c_int, [c_vp, c_vp, c_int] + [c_vp] * 4 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_conv3x3s2_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
     "tramba_stem_conv_ln_gelu": (c_int, [c_vp] * 6 + [c_int] * 3 + [c_f, c_int, c_int, c_vp]),
 }
@@ -482,6 +483,21 @@ def linear_cl(x, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
         raise TrambaHipError("linear_cl: weight dtype/shape mismatch")
     _check(lib().tramba_linear_cl(_ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), m, n, k, act, dt(x),
                                   dt(y), _stream()), "linear_cl")
+    return y
+
+
+def linear2_cl(x1, x2, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
+    """Linear2d on torch.cat((x1, x2), dim=-1) without the concatenation: x1 (..., K1), x2 (..., K2), w (N, K1+K2)."""
+    _dev(x1, x2, w, bias, residual)
+    k1, k2 = x1.shape[-1], x2.shape[-1]
+    n = w.shape[0]
+    m = x1.numel() // k1
+    if x2.shape[:-1] != x1.shape[:-1] or w.shape[1] != k1 + k2 or w.dtype != x1.dtype or x2.dtype != x1.dtype:
+        raise TrambaHipError("linear2_cl: operand shapes / dtypes do not match")
+    out_dtype = x1.dtype if out_dtype is None else out_dtype
+    y = torch.empty(x1.shape[:-1] + (n,), dtype=out_dtype, device=x1.device)
+    _check(lib().tramba_linear2_cl(_ptr(x1), _ptr(x2), k1, _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), m, n, k1 + k2,
+                                   act, dt(x1), dt(y), _stream()), "linear2_cl")
     return y
 
 

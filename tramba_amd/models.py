@@ -123,7 +123,7 @@ class VSSMDecoder(nn.Module):
                     mid.record_stream(torch.cuda.current_stream())
                 else:
                     mid = self.guide_layers[s]._forward_cl(skips_cl[-(s + 2)])
-                x = self.concat_back_dim[s]._forward_cl(torch.cat((x, mid), dim=-1))
+                x = self.concat_back_dim[s]._forward_cat_cl(x, mid)
                 for blk in self.stage_layers[s].blocks:
                     x = blk._forward_cl(x)
             if self.deep_supervision or s == n - 1:

@@ -36,6 +36,7 @@ from .ops import (CrossMerge, CrossMerge_Dilation, CrossMerge_Line, CrossMerge_W
 GEMM_BACKEND = os.environ.get("TRAMBA_GEMM", "hip")
 # dtype of the (B,K,L,D) scan output between the fused scan and the merge kernel in inference:
 # "f32" mirrors the reference's oflex fp32 output, "act" stores it in the activation dtype
+TWO_SOURCE_GEMM = os.environ.get("TRAMBA_CAT_GEMM", "1") != "0"   # 0: materialise torch.cat before concat_back_dim
 YS_DTYPE = os.environ.get("TRAMBA_YS", "f32")
 # training-path LayerNorm: "hip" = tramba_layernorm_cl / tramba_layernorm_bwd_cl, "torch" = F.layer_norm in fp32
 TRAIN_NORM_BACKEND = os.environ.get("TRAMBA_TRAIN_NORM", "hip")
@@ -212,6 +213,19 @@ class Linear2d(nn.Linear):
         if residual is not None:
             y = y + residual
         return y if out_dtype is None else y.to(out_dtype)
+
+    def _forward_cat_cl(self, x1, x2, act=hip.ACT_NONE, residual=None, out_dtype=None):
+        """Linear2d(torch.cat((x1, x2), dim=-1)) -- in 16-bit inference the K loop reads the two tensors in turn
+        (tramba_linear2_cl), so the concatenation never exists.  act = ACT_SIGMOID_GATE multiplies by `residual`."""
+        if (TWO_SOURCE_GEMM and _infer(x1, x2, self.weight) and GEMM_BACKEND == "hip" and x1.dtype != torch.float32
+                and x1.dtype == x2.dtype
+                and x1.shape[-1] % 64 == 0 and x2.shape[-1] % 64 == 0):
+            w = self.weight if self.weight.dtype == x1.dtype else self.weight.to(x1.dtype)
+            return hip.linear2_cl(x1.contiguous(), x2.contiguous(), w.detach(), _f32(self.bias), residual, act, out_dtype)
+        gate = act == hip.ACT_SIGMOID_GATE
+        y = self._forward_cl(torch.cat((x1, x2), dim=-1), act=hip.ACT_NONE if gate else act,
+                             residual=None if gate else residual, out_dtype=out_dtype)
+        return torch.sigmoid(y) * residual if gate else y
 
     def forward(self, x):
         _need_device(x)
@@ -800,8 +814,8 @@ class FreqSS2Dv6(nn.Module):
         low = self.l_expand._forward_cl(low)
         hifi = self.h_ssm._forward_cl(high)
         lofi = self.l_ssm._forward_cl(low)
-        attn = self.concat_back_dim._forward_cl(torch.cat((hifi, lofi), dim=-1))
-        return torch.sigmoid(attn) * x
+        # x * sigmoid(W [hifi | lofi]): two-source GEMM with the gate in its epilogue (freq_mamba.py:52-56)
+        return self.concat_back_dim._forward_cat_cl(hifi, lofi, act=hip.ACT_SIGMOID_GATE, residual=x)
 
     def forward(self, x):
         _need_device(x)
