@@ -205,6 +205,13 @@ int tramba_linear_cl(const void *x, const void *w, const float *bias, const void
 int tramba_linear2_cl(const void *x1, const void *x2, int k1, const void *w, const float *bias, const void *residual,
                       void *y, int64_t m, int n, int k, int act, int dtype, int out_dtype, void *stream);
 
+/* The whole last decoder stage in one kernel (FinalPatchExpand_X4 + seg_layers[-1], Trambav6.py:132-137):
+ * y (B, H*P, W*P) f32 = head(LayerNorm_128(pixel_shuffle_P(x @ w^T))).  x (B, H, W, Cin) dtype, w (P*P*128, Cin) dtype
+ * (the expand Linear2d, no bias), ln_w / ln_b / head_w (128) f32.  16-bit dtypes, Cin % 64 == 0. */
+int tramba_expand_norm_head_cl(const void *x, const void *w, const float *ln_w, const float *ln_b,
+                               const float *head_w, float head_b, float *y, int batch, int h, int wd, int cin, int p,
+                               float eps, int dtype, void *stream);
+
 /* ------------------------------------------------------------------ dense convs of the VMamba stem */
 /* Implicit-GEMM 3x3 / stride 2 / pad 1 convolution on a channels-last map (patch_embed[5] and the three
  * downsample convs, Models/vmamba.py:454,486): x (B, Hin, Win, Cin) -> y (B, ceil(Hin/2), ceil(Win/2), Cout).

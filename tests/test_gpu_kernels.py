@@ -319,6 +319,29 @@ def test_shuffle_norm_head_cl(dtype, cfg):
                                atol=2e-2 if dtype != torch.float32 else 1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(2, 6, 7, 128, 4), (1, 5, 5, 64, 2), (4, 96, 96, 128, 4), (1, 13, 3, 192, 1)])
+def test_expand_norm_head_cl(dtype, cfg):
+    """The whole final decoder stage in one kernel == expand GEMM -> pixel shuffle -> LayerNorm(128) -> 1x1 head
+    (Trambav6.py:132-137), in fp64 on the same 16-bit inputs; and close to the three-kernel product path."""
+    b, h, wd, cin, p = cfg
+    H = hip()
+    g = torch.Generator().manual_seed(h * cin + p)
+    x = torch.randn(b, h, wd, cin, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(p * p * 128, cin, generator=g) * cin ** -0.5).to(dtype).to(DEV)
+    lw, lb = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV), (0.1 * torch.randn(128, generator=g)).to(DEV)
+    hw = (torch.randn(128, generator=g) * 128 ** -0.5).to(DEV)
+    got = H.expand_norm_head_cl(x, w, lw, lb, hw, 0.4, p)
+    assert got.shape == (b, h * p, wd * p)
+    xe = x.double() @ w.double().T
+    y = xe.view(b, h, wd, p, p, 128).permute(0, 1, 3, 2, 4, 5).reshape(b, h * p, wd * p, 128)
+    y = F.layer_norm(y, (128,), lw.double(), lb.double(), 1e-5)
+    ref = y @ hw.double() + 0.4
+    np.testing.assert_allclose(got.cpu().double().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4)
+    unfused = H.shuffle_norm_head_cl(H.linear_cl(x, w), lw, lb, hw, 0.4, p)
+    np.testing.assert_allclose(got.cpu().numpy(), unfused.cpu().numpy(), rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(2, 12, 64, 3), (1, 24, 130, 7), (2, 9, 32, 5), (1, 48, 256, 7)])
 def test_dwconv_training_path_matches_autograd(dtype, cfg):

@@ -383,6 +383,97 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
     tile_epilogue<T, TO, BM, BN>(acc, lds, bias, res, y, M, N, act, m0, n0);
 }
 
+// Epilogue of the LAST decoder stage fused into its expand GEMM (Trambav6.py:132-137): the GEMM's N axis is
+// P*P groups of C = 128 channels, group g of input pixel (h, w) being output pixel (h*P + g/P, w*P + g%P).  With
+// BN = 128 a block tile holds whole groups, so LayerNorm over the group and the 1x1 head (C -> 1) run on the
+// accumulators: y (B, H*P, W*P) f32 = <LN(acc), head_w> + head_b.  Neither the (M, 2048) expand output nor the
+// (B, 384, 384, 128) normalised map is ever written (2 x 151 MB at batch 4) or read back.
+struct LnHead {
+    const float *ln_w, *ln_b, *head_w;
+    float head_b, eps;
+    int H, W, P;       // input map H x W, pixel-shuffle factor
+    float *out;        // (B, H*P, W*P)
+};
+
+template <typename T, int BM>
+__device__ __forceinline__ void tile_epilogue_ln_head(acc16_t (&acc)[BM / 64][2], unsigned char *lds, const LnHead hd,
+                                                      long M, long m0, int n0)
+{
+    constexpr int BN = 128, TM = BM / 64, TN = 2, WM = BM / 2, WN = BN / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hi = lane >> 5;
+    // row stride BN + 16 floats (== 64 B mod 256): the 16 lanes of one ds_read_b128 pass (4 rows x 4 lanes) hit 16
+    // different 16-byte bank groups
+    constexpr int LDE = BN + 16;
+    float *ep = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                ep[row * LDE + wn * WN + j * 32 + r32] = acc[i][j][r];
+            }
+    __syncthreads();
+    // 4 lanes per row; lane `sub` owns the float4 chunks sub, sub + 4, ... (channels 16 j + 4 sub + e)
+    const int sub = tid & 3;
+    float gam[32], bet[32], hw[32];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 16 * j + 4 * sub;
+        const float4 a = *reinterpret_cast<const float4 *>(hd.ln_w + c);
+        const float4 b = *reinterpret_cast<const float4 *>(hd.ln_b + c);
+        const float4 h = *reinterpret_cast<const float4 *>(hd.head_w + c);
+        gam[4 * j] = a.x; gam[4 * j + 1] = a.y; gam[4 * j + 2] = a.z; gam[4 * j + 3] = a.w;
+        bet[4 * j] = b.x; bet[4 * j + 1] = b.y; bet[4 * j + 2] = b.z; bet[4 * j + 3] = b.w;
+        hw[4 * j] = h.x; hw[4 * j + 1] = h.y; hw[4 * j + 2] = h.z; hw[4 * j + 3] = h.w;
+    }
+    const int g = n0 / BN;                         // group of this tile
+#pragma unroll
+    for (int it = 0; it < BM / 64; ++it) {
+        const int row = it * 64 + (tid >> 2);
+        const long grow = m0 + row;
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 t = *reinterpret_cast<const float4 *>(ep + row * LDE + 16 * j + 4 * sub);
+            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        }
+        float s1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) s1 += v[q];
+        s1 += __shfl_xor(s1, 1, 64);
+        s1 += __shfl_xor(s1, 2, 64);
+        const float mean = s1 * (1.f / 128.f);
+        float s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const float d = v[q] - mean;
+            s2 = fmaf(d, d, s2);
+        }
+        s2 += __shfl_xor(s2, 1, 64);
+        s2 += __shfl_xor(s2, 2, 64);
+        const float rstd = rsqrtf(s2 * (1.f / 128.f) + hd.eps);
+        float dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const float yn = (v[q] - mean) * rstd * gam[q] + bet[q];
+            dot = fmaf(yn, hw[q], dot);   // fp32 throughout: no 16-bit rounding between GEMM, norm and head
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        if (sub == 0 && grow < M) {
+            const unsigned pix = (unsigned)grow;                     // (b*H + h)*W + w, M < 2^31 host-checked
+            const unsigned wi = pix % (unsigned)hd.W, bh = pix / (unsigned)hd.W;
+            const unsigned hh = bh % (unsigned)hd.H, bb = bh / (unsigned)hd.H;
+            const long o = ((long)bb * (hd.H * hd.P) + (hh * hd.P + g / hd.P)) * (long)(hd.W * hd.P) + (wi * hd.P + g % hd.P);
+            hd.out[o] = dot + hd.head_b;
+        }
+    }
+}
+
 // Lean form of the tile kernel for the plain GEMM with K % 64 == 0 (every 1x1 convolution of the model).
 // The generic kernel spends ~37 VALU instructions per K step on addresses, clamps and masks -- more issue
 // time than its 4 MFMAs -- and these GEMMs run ~1 wave per SIMD, so that time is exposed.  Here:
@@ -394,11 +485,12 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
 //   * exactly nk steps run (ring trips + a statically indexed tail), so no zero-padded dummy steps.
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 
-template <typename T, typename TO, int BM, int BN, int PF>
+template <typename T, typename TO, int BM, int BN, int PF, bool LNHEAD = false>
 __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ x, const T *__restrict__ w,
                                                          const float *__restrict__ bias,
                                                          const T *__restrict__ res, TO *__restrict__ y, long M,
-                                                         int N, int K, int act, const T *__restrict__ x2, int K1)
+                                                         int N, int K, int act, const T *__restrict__ x2, int K1,
+                                                         LnHead hd = LnHead{})
 {
     // x2 != nullptr: A = [x (M, K1) | x2 (M, K - K1)], both halves whole K steps (no concatenation in memory)
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -531,7 +623,12 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
     for (int ui = 0; ui < NS - 1; ++ui)
         if (kt0 + ui < nk) kstep(kt0 + ui, ui & 1, pipe[ui % NS], pipe[(ui + 1) % NS]);
 
-    tile_epilogue<T, TO, BM, BN>(acc, lds, bias, res, y, M, N, act, m0, n0);
+    if constexpr (LNHEAD) {
+        static_assert(BN == 128, "one tile = whole 128-channel groups");
+        tile_epilogue_ln_head<T, BM>(acc, lds, hd, M, m0, n0);
+    } else {
+        tile_epilogue<T, TO, BM, BN>(acc, lds, bias, res, y, M, N, act, m0, n0);
+    }
 }
 
 // Tile choice: 64x64 (3 K-tiles in flight) wins on every GEMM of this model (M = 576..36864, N <= 4096,
@@ -699,6 +796,35 @@ extern "C" int tramba_linear2_cl(const void *x1, const void *x2, int k1, const v
     } else {
         if (out_dtype == TRAMBA_F32) launch_tiled<__half, float>(x1, w, bias, residual, y, m, n, k, act, s, nocg, x2, k1);
         else launch_tiled<__half, __half>(x1, w, bias, residual, y, m, n, k, act, s, nocg, x2, k1);
+    }
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_expand_norm_head_cl(const void *x, const void *w, const float *ln_w, const float *ln_b,
+                                          const float *head_w, float head_b, float *y, int batch, int h, int wd, int cin,
+                                          int p, float eps, int dtype, void *stream)
+{
+    TRAMBA_CHECK(x && w && ln_w && ln_b && head_w && y, "expand_norm_head_cl: null tensor");
+    TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && cin > 0 && p > 0, "expand_norm_head_cl: empty shape");
+    TRAMBA_CHECK(dtype == TRAMBA_BF16 || dtype == TRAMBA_F16, "expand_norm_head_cl: 16-bit dtypes only");
+    TRAMBA_CHECK(cin % 64 == 0, "expand_norm_head_cl: Cin=%d must be a multiple of 64", cin);
+    TRAMBA_CHECK(aligned16(x) && aligned16(w), "expand_norm_head_cl: tensors must be 16-byte aligned");
+    const long m = (long)batch * h * wd;
+    const int n = p * p * 128;   // the fused epilogue is written for 128-channel groups (Tramba-V / -R final stage)
+    TRAMBA_CHECK(m < 2147483647L && (m + 63) / 64 <= 65535, "expand_norm_head_cl: too many pixels");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(TRAMBA_PROF_GEMM, s, 2.0 * (double)m * n * cin);
+    const LnHead hd{ln_w, ln_b, head_w, head_b, eps, h, wd, p, y};
+    dim3 grid((unsigned)(n / 128), (unsigned)((m + 63) / 64)), block(256);
+    if (dtype == TRAMBA_BF16) {
+        using T = __hip_bfloat16;
+        hipLaunchKernelGGL((linear_lean_kernel<T, T, 64, 128, 1, true>), grid, block, 0, s, (const T *)x, (const T *)w,
+                           (const float *)nullptr, (const T *)nullptr, (T *)nullptr, m, n, cin, 0, (const T *)nullptr, 0, hd);
+    } else {
+        using T = __half;
+        hipLaunchKernelGGL((linear_lean_kernel<T, T, 64, 128, 1, true>), grid, block, 0, s, (const T *)x, (const T *)w,
+                           (const float *)nullptr, (const T *)nullptr, (T *)nullptr, m, n, cin, 0, (const T *)nullptr, 0, hd);
     }
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;

@@ -60,6 +60,7 @@ SIGNATURES = {
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_linear2_cl": (c_int, [c_vp, c_vp, c_int] + [c_vp] * 4 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_expand_norm_head_cl": (c_int, [c_vp] * 5 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_conv3x3s2_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
     "tramba_stem_conv_ln_gelu": (c_int, [c_vp] * 6 + [c_int] * 3 + [c_f, c_int, c_int, c_vp]),
 }
@@ -407,6 +408,18 @@ def shuffle_norm_head_cl(x, w, b, head_w, head_b: float, p, eps=1e-5):
     y = torch.empty((bb, h * p, wd * p), dtype=torch.float32, device=x.device)
     _check(lib().tramba_shuffle_norm_head_cl(_ptr(x), _ptr(w), _ptr(b), _ptr(head_w), float(head_b), _ptr(y), bb, h, wd,
                                              c, p, eps, dt(x), _stream()), "shuffle_norm_head_cl")
+    return y
+
+
+def expand_norm_head_cl(x, w, ln_w, ln_b, head_w, head_b: float, p, eps=1e-5):
+    """x (B,H,W,Cin) 16-bit, w (P*P*128, Cin) -> (B, H*P, W*P) f32: expand GEMM + pixel shuffle + LayerNorm(128) + head."""
+    _dev(x, w, ln_w, ln_b, head_w)
+    bb, h, wd, cin = x.shape
+    if w.shape != (p * p * 128, cin) or w.dtype != x.dtype or ln_w.numel() != 128 or head_w.numel() != 128:
+        raise TrambaHipError("expand_norm_head_cl: needs 128-channel groups and a (P*P*128, Cin) weight")
+    y = torch.empty((bb, h * p, wd * p), dtype=torch.float32, device=x.device)
+    _check(lib().tramba_expand_norm_head_cl(_ptr(x), _ptr(w), _ptr(ln_w), _ptr(ln_b), _ptr(head_w), float(head_b), _ptr(y),
+                                            bb, h, wd, cin, p, eps, dt(x), _stream()), "expand_norm_head_cl")
     return y
 
 

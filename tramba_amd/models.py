@@ -20,6 +20,8 @@ from .ops import CrossMerge_Line, CrossScan_Line
 
 # Independent branches of the inference graph on separate HIP streams (TRAMBA_OVERLAP=0 disables).
 OVERLAP_BRANCHES = os.environ.get("TRAMBA_OVERLAP", "1") != "0"
+# Last decoder stage (expand GEMM + pixel shuffle + LayerNorm + head) as ONE kernel (TRAMBA_FUSED_FINAL=0 disables).
+FUSED_FINAL_STAGE = os.environ.get("TRAMBA_FUSED_FINAL", "1") != "0"
 _side_streams = {}
 
 
@@ -98,6 +100,12 @@ class VSSMDecoder(nn.Module):
         LayerNorm + the 1x1 head, so the (B, 4H, 4W, C) map is never materialised (Trambav6.py:132-137)."""
         fin, conv = self.expand_layers[-1], self.seg_layers[-1]
         if _infer(x_low, conv.weight) and isinstance(self.stage_layers[-1], nn.Identity) and fin.output_dim % 8 == 0:
+            if (x_low.dtype != torch.float32 and fin.output_dim == 128 and x_low.shape[-1] % 64 == 0
+                    and fin.expand.bias is None and FUSED_FINAL_STAGE):
+                y = hip.expand_norm_head_cl(x_low, fin.expand.weight.to(x_low.dtype), hip._f32(fin.norm.weight),
+                                            hip._f32(fin.norm.bias), hip._f32(conv.weight).view(-1), _bias_scalar(conv),
+                                            fin.scale, fin.norm.eps)
+                return y.unsqueeze(1)
             xe = fin.expand._forward_cl(x_low)
             y = hip.shuffle_norm_head_cl(xe, hip._f32(fin.norm.weight), hip._f32(fin.norm.bias),
                                          hip._f32(conv.weight).view(-1), _bias_scalar(conv), fin.scale, fin.norm.eps)
