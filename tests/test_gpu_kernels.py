@@ -177,6 +177,30 @@ def test_linear_cl(dtype, mnk):
     np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol * max(1.0, float(want.abs().max())))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mnk", [(576, 512, 1024), (2304, 512, 2048), (600, 200, 4096), (2304, 1024, 512), (1000, 520, 1024),
+                                 (2304, 136, 1024), (70, 64, 1280)])
+def test_linear_cl_small_grid_long_k(dtype, mnk):
+    """The 24x24 / 12x12 stages' GEMMs (about one tile per CU, K up to 4096; deep prefetch ring): fp64 on the same
+    16-bit inputs, ragged M / N included, bitwise reproducible, and the two-source A operand on the same path."""
+    m, n, k = mnk
+    H = hip()
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) + torch.arange(k)[None, :] * 0.002).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dtype).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(m, n, generator=g).to(dtype).to(DEV)
+    base = x.double() @ w.double().T
+    got = H.linear_cl(x, w, None, None, 0, torch.float32)
+    np.testing.assert_allclose(got.cpu().double().numpy(), base.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(base.abs().max()))
+    assert torch.equal(got, H.linear_cl(x, w, None, None, 0, torch.float32))
+    want = F.gelu(base + bias.double()) + res.double()
+    got = H.linear_cl(x, w, bias, res, 2)
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.cpu().numpy(), rtol=2e-2, atol=2e-2 * max(1.0, float(want.abs().max())))
+    k1 = 64 * ((k // 64) // 3)                                   # two-source A operand through the same path
+    assert torch.equal(H.linear2_cl(x[:, :k1].contiguous(), x[:, k1:].contiguous(), w, bias, res, 2), got)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("fam", ["raster", "helix", "window", "dilation"])
 @pytest.mark.parametrize("cfg", [(2, 12, 32, 2), (1, 24, 64, 4), (1, 16, 40, 3), (1, 48, 128, 8), (1, 12, 96, 40), (1, 24, 32, 64), (2, 96, 64, 8),
