@@ -224,6 +224,23 @@ int tramba_stem_conv_ln_gelu(const void *img, const float *w, const float *bias,
                              const float *ln_b, void *y, int batch, int h, int wd, float eps,
                              int img_dtype, int dtype, void *stream);
 
+/* ------------------------------------------------------------------ evaluation (train.py:101-139 test_one_epoch) */
+/* Per-image statistics of saliency maps against their masks, from which MAE, F-measure, E-measure and S-measure of
+ * Evaluation/metrics.py follow without the maps leaving the GPU.  pred (B, H, W) f32 = sigmoid(logits) (NOT yet
+ * min-max normalised: the kernel does Evaluation/metrics.py:13-19 itself); gt (B, H, W) u8, 0 / 1.
+ * ints (B, TRAMBA_EVAL_NINT) i64: [0] mask area, [1] sum g*col, [2] sum g*row, [3] cx, [4] cy (S-measure centroid, 1-based
+ *   split point as metrics.py:201-212), [5] / [6] pixels >= adaptive threshold inside / outside the mask, [7] H*W,
+ *   [8 .. 264) histogram of uint8(p*255) inside the mask, [264 .. 520) outside.
+ * dbl (B, TRAMBA_EVAL_NDBL) f64: [0] min, [1] max of pred, [2] sum p, [3] sum |p - g|, [4] [5] sum p, p^2 inside the mask,
+ *   [6] [7] sum (1-p), (1-p)^2 outside, [8 + 4q + {0,1,2,3}] sum p, p^2, g, p*g over quadrant q (LT, RT, LB, RB),
+ *   [24] the adaptive threshold, [32 + 3q + {0,1,2}] centred sums over quadrant q: (p - mean p)^2, (g - mean g)^2,
+ *   (p - mean p)(g - mean g), [44] sum (p - mean)^2 inside the mask, [45] sum ((1-p) - mean)^2 outside;
+ *   p = normalised prediction.  NaN where a region is empty, as numpy gives. */
+#define TRAMBA_EVAL_NINT 520
+#define TRAMBA_EVAL_NDBL 48
+int tramba_saliency_stats(const float *pred, const unsigned char *gt, long long *ints, double *dbl, int batch, int h,
+                          int w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

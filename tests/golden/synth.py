@@ -69,3 +69,38 @@ def synth_input(tag: str, shape, scale=1.0) -> torch.Tensor:
 
 
 DCT_KEYS = ("DCT2D.dct_x.weight", "DCT2D.dct_y.weight")
+
+
+# --------------------------------------------------------------------------- saliency-metric cases
+def metric_cases():
+    """(name, pred float32 (h, w) in [0, 1], gt float32 (h, w) of 0/1) for the evaluation-metric fixtures: smooth
+    blobs with noise (the usual case), an empty mask, a full mask, a constant prediction, a non-square map and a
+    prediction that is already binary.  Closed-form in the case name, like every other synthetic input here."""
+    def blob(name, h, w, n, sharp):
+        rs = _rs(name)
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        z = np.zeros((h, w))
+        for _ in range(n):
+            cy, cx = rs.uniform(0.15, 0.85) * h, rs.uniform(0.15, 0.85) * w
+            sy, sx = rs.uniform(0.05, 0.25) * h, rs.uniform(0.05, 0.25) * w
+            z += rs.uniform(0.5, 1.5) * np.exp(-((yy - cy) ** 2 / (2 * sy * sy) + (xx - cx) ** 2 / (2 * sx * sx)))
+        return z * sharp, rs
+
+    cases = []
+    for name, h, w in (("blobs_a", 96, 96), ("blobs_b", 120, 72), ("blobs_c", 384, 384)):
+        z, rs = blob("metric_" + name, h, w, 3, 1.0)
+        gt = (z > 0.55).astype(np.float32)
+        logit = 6.0 * (z - 0.55) + 1.2 * rs.standard_normal((h, w)) + 0.8 * np.sin(np.arange(w) / 7.0)[None, :]
+        pred = (1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+        cases.append((name, pred, gt))
+    z, rs = blob("metric_empty", 64, 64, 2, 1.0)
+    pred = (1.0 / (1.0 + np.exp(-(3.0 * (z - 0.8) + 0.5 * rs.standard_normal((64, 64)))))).astype(np.float32)
+    cases.append(("empty_gt", pred, np.zeros((64, 64), np.float32)))
+    cases.append(("full_gt", pred, np.ones((64, 64), np.float32)))
+    z, rs = blob("metric_const", 48, 80, 2, 1.0)
+    cases.append(("const_pred", np.full((48, 80), 0.37, np.float32), (z > 0.5).astype(np.float32)))
+    z, rs = blob("metric_binary", 72, 72, 3, 1.0)
+    gt = (z > 0.6).astype(np.float32)
+    flip = rs.random_sample((72, 72)) < 0.08
+    cases.append(("binary_pred", np.where(flip, 1.0 - gt, gt).astype(np.float32), gt))
+    return cases

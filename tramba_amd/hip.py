@@ -53,6 +53,7 @@ SIGNATURES = {
     "tramba_shuffle_norm_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_shuffle_norm_head_cl": (c_int, [c_vp] * 4 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_rowdot_cl": (c_int, [c_vp, c_vp, c_f, c_vp, c_i64, c_int, c_int, c_vp]),
+    "tramba_saliency_stats": (c_int, [c_vp] * 4 + [c_int] * 3 + [c_vp]),
     "tramba_dw_pack": (c_int, [c_vp] * 8 + [c_int] * 2 + [c_vp]),
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
     "tramba_dwconv_wgrad_parts": (c_i64, [c_int, c_int]),
@@ -421,6 +422,24 @@ def expand_norm_head_cl(x, w, ln_w, ln_b, head_w, head_b: float, p, eps=1e-5):
     _check(lib().tramba_expand_norm_head_cl(_ptr(x), _ptr(w), _ptr(ln_w), _ptr(ln_b), _ptr(head_w), float(head_b), _ptr(y),
                                             bb, h, wd, cin, p, eps, dt(x), _stream()), "expand_norm_head_cl")
     return y
+
+
+EVAL_NINT, EVAL_NDBL = 520, 48
+
+
+def saliency_stats(pred, gt):
+    """pred (B, H, W) f32 = sigmoid(logits), gt (B, H, W) bool / u8 -> (ints (B, 520) i64, dbl (B, 48) f64) on the
+    device: the per-image statistics behind MAE / F / E / S-measure (layout: include/tramba_hip.h)."""
+    if pred.dtype != torch.float32 or pred.dim() != 3 or gt.shape != pred.shape:
+        raise TrambaHipError("saliency_stats: pred must be (B, H, W) float32 and gt the same shape")
+    pred = pred.contiguous()
+    g8 = (gt if gt.dtype == torch.bool else gt != 0).contiguous().view(torch.uint8)
+    _dev(pred, g8)
+    b, h, w = pred.shape
+    ints = torch.empty((b, EVAL_NINT), dtype=torch.int64, device=pred.device)
+    dbl = torch.empty((b, EVAL_NDBL), dtype=torch.float64, device=pred.device)
+    _check(lib().tramba_saliency_stats(_ptr(pred), _ptr(g8), _ptr(ints), _ptr(dbl), b, h, w, _stream()), "saliency_stats")
+    return ints, dbl
 
 
 def rowdot_cl(x, w, bias: float):
