@@ -179,3 +179,118 @@ def tramba_r(sd, x):
     outs = resnet50_encoder(SD(sd, "encoder."), x)
     skips = [x] + list(outs[1:-1][::-1])
     return vssm_decoder(SD(sd, "decoder."), skips)
+
+
+# ----------------------------------------------------------------------------- Tramba-P (PVTv2-b4)
+def _tok_ln(p: SD, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), p("weight"), p("bias"), eps)
+
+
+def _tok_lin(p: SD, x):
+    return F.linear(x, p("weight"), p("bias") if p.has("bias") else None)
+
+
+def _pvt_attention(p: SD, x, h, w, heads, sr):
+    """pvtv2_encoder.py:95-116: softmax(q k^T / sqrt(hd)) v with k, v from the sr-strided conv of the map."""
+    b, n, c = x.shape
+    hd = c // heads
+    q = _tok_lin(p.sub("q"), x).reshape(b, n, heads, hd).transpose(1, 2)
+    if sr > 1:
+        m = F.conv2d(x.transpose(1, 2).reshape(b, c, h, w), p("sr.weight"), p("sr.bias"), stride=sr)
+        x = _tok_ln(p.sub("norm"), m.flatten(2).transpose(1, 2), 1e-5)       # `self.norm = nn.LayerNorm(dim)`: default eps
+    kv = _tok_lin(p.sub("kv"), x).reshape(b, -1, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(q @ kv[0].transpose(-2, -1) * hd ** -0.5, dim=-1)
+    return _tok_lin(p.sub("proj"), (att @ kv[1]).transpose(1, 2).reshape(b, n, c))
+
+
+def _pvt_mlp(p: SD, x, h, w):
+    """pvtv2_encoder.py:47-54, 373-384."""
+    b, n, _ = x.shape
+    y = _tok_lin(p.sub("fc1"), x)
+    c = y.shape[-1]
+    y = F.conv2d(y.transpose(1, 2).reshape(b, c, h, w), p("dwconv.dwconv.weight"), p("dwconv.dwconv.bias"), padding=1, groups=c)
+    return _tok_lin(p.sub("fc2"), F.gelu(y.flatten(2).transpose(1, 2)))
+
+
+def pvt_v2_b4_encoder(p: SD, x):
+    """pvtv2_encoder.py:321-358 with the b4 configuration (:433-439); returns [stage1..stage4] NCHW (shallow first)."""
+    heads, srs, depths = (1, 2, 5, 8), (8, 4, 2, 1), (3, 8, 27, 3)
+    outs = []
+    for s in range(4):
+        pe = p.sub(f"patch_embed{s + 1}")
+        k = pe("proj.weight").shape[-1]
+        x = F.conv2d(x, pe("proj.weight"), pe("proj.bias"), stride=4 if s == 0 else 2, padding=k // 2)
+        b, c, h, w = x.shape
+        x = _tok_ln(pe.sub("norm"), x.flatten(2).transpose(1, 2), 1e-5)      # OverlapPatchEmbed's own LayerNorm: default eps
+        for i in range(depths[s]):
+            blk = p.sub(f"block{s + 1}.{i}")
+            x = x + _pvt_attention(blk.sub("attn"), _tok_ln(blk.sub("norm1"), x, 1e-6), h, w, heads[s], srs[s])
+            x = x + _pvt_mlp(blk.sub("mlp"), _tok_ln(blk.sub("norm2"), x, 1e-6), h, w)
+        x = _tok_ln(p.sub(f"norm{s + 1}"), x, 1e-6).reshape(b, h, w, c).permute(0, 3, 1, 2)
+        outs.append(x)
+    return outs
+
+
+def tramba_p(sd, x):
+    """Trambav6_enc.py:208-217: the encoder returns deepest first, skips += outs[::-1]."""
+    return vssm_decoder(SD(sd, "decoder."), [x] + pvt_v2_b4_encoder(SD(sd, "encoder."), x))
+
+
+# ----------------------------------------------------------------------------- Tramba-S (Swin-B, window 12, 384)
+def _swin_windows(x, ws):
+    b, h, w, c = x.shape
+    return x.reshape(b, h // ws, ws, w // ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, c)
+
+
+def _swin_block(p: SD, x, res, heads, ws, shift):
+    """swin_encoder.py:236-273 + 116-147."""
+    b, l, c = x.shape
+    if res <= ws:
+        ws, shift = res, 0
+    y = _tok_ln(p.sub("norm1"), x, 1e-5).reshape(b, res, res, c)
+    if shift:
+        y = torch.roll(y, (-shift, -shift), (1, 2))
+    win = _swin_windows(y, ws)                                                          # (B*nW, N, C)
+    n, hd = ws * ws, c // heads
+    qkv = _tok_lin(p.sub("attn.qkv"), win).reshape(-1, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    att = (qkv[0] * hd ** -0.5) @ qkv[1].transpose(-2, -1)
+    bias = p("attn.relative_position_bias_table")[p("attn.relative_position_index").reshape(-1)].reshape(n, n, heads)
+    att = att + bias.permute(2, 0, 1)[None]
+    if shift:
+        mask = p("attn_mask")                                                           # (nW, N, N), 0 / -100
+        nw = mask.shape[0]
+        att = (att.reshape(b, nw, heads, n, n) + mask[None, :, None]).reshape(-1, heads, n, n)
+    out = (torch.softmax(att, -1) @ qkv[2]).transpose(1, 2).reshape(-1, n, c)
+    out = _tok_lin(p.sub("attn.proj"), out)
+    out = out.reshape(b, res // ws, res // ws, ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(b, res, res, c)
+    if shift:
+        out = torch.roll(out, (shift, shift), (1, 2))
+    x = x + out.reshape(b, l, c)
+    return x + _tok_lin(p.sub("mlp.fc2"), F.gelu(_tok_lin(p.sub("mlp.fc1"), _tok_ln(p.sub("norm2"), x, 1e-5))))
+
+
+def swin_b_encoder(p: SD, x, depths=(2, 2, 18, 2), heads=(4, 8, 16, 32), ws=12):
+    """swin_encoder.py:563-594: features before every layer plus the last layer's output, returned deepest first."""
+    x = F.conv2d(x, p("patch_embed.proj.weight"), p("patch_embed.proj.bias"), stride=4)
+    b, c, res, _ = x.shape
+    x = _tok_ln(p.sub("patch_embed.norm"), x.flatten(2).transpose(1, 2), 1e-5)
+    feats = []
+    for li, depth in enumerate(depths):
+        feats.append(x.reshape(b, res, res, -1).permute(0, 3, 1, 2))
+        for i in range(depth):
+            x = _swin_block(p.sub(f"layers.{li}.blocks.{i}"), x, res, heads[li], ws, 0 if i % 2 == 0 else ws // 2)
+        if li < len(depths) - 1:                                                        # PatchMerging, :310-331
+            c = x.shape[-1]
+            g = x.reshape(b, res, res, c)
+            g = torch.cat([g[:, 0::2, 0::2], g[:, 1::2, 0::2], g[:, 0::2, 1::2], g[:, 1::2, 1::2]], -1).reshape(b, -1, 4 * c)
+            dn = p.sub(f"layers.{li}.downsample")
+            x = F.linear(_tok_ln(dn.sub("norm"), g, 1e-5), dn("reduction.weight"))
+            res //= 2
+    feats.append(x.reshape(b, res, res, -1).permute(0, 3, 1, 2))
+    return feats[::-1]
+
+
+def tramba_s(sd, x):
+    """Trambav6_enc.py:208-211: skips += outs[1:][::-1] (the last layer's output is not used)."""
+    outs = swin_b_encoder(SD(sd, "encoder."), x)
+    return vssm_decoder(SD(sd, "decoder."), [x] + list(outs[1:][::-1]))

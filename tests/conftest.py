@@ -27,6 +27,17 @@ def golden_meta():
         return json.load(f)
 
 
+@pytest.fixture(scope="session")
+def golden_enc():
+    return np.load(os.path.join(GOLDEN, "golden_enc.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_enc_meta():
+    with open(os.path.join(GOLDEN, "golden_enc_meta.json")) as f:
+        return json.load(f)
+
+
 def has_gpu():
     import torch
     return torch.cuda.is_available()

@@ -69,6 +69,8 @@ def synth_input(tag: str, shape, scale=1.0) -> torch.Tensor:
 
 
 DCT_KEYS = ("DCT2D.dct_x.weight", "DCT2D.dct_y.weight")
+# constants of the architecture (never synthesised): the DCT bases, Swin's shifted-window masks and index tables
+CONST_KEYS = DCT_KEYS + ("attn_mask", "relative_position_index")
 
 
 # --------------------------------------------------------------------------- saliency-metric cases

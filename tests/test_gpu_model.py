@@ -14,7 +14,7 @@ DEV = "cuda"
 
 def _load_synth(module, dtype=torch.float32):
     sd = module.state_dict()
-    new = synth.synth_state_dict(((k, v.shape) for k, v in sd.items()), keep=synth.DCT_KEYS)
+    new = synth.synth_state_dict(((k, v.shape) for k, v in sd.items()), keep=synth.CONST_KEYS)
     for k in sd:
         if k not in new:
             new[k] = sd[k]
@@ -173,6 +173,45 @@ def test_tramba_r_256_against_oracle():
     assert [tuple(o.shape) for o in got] == [(1, 1, 32, 32), (1, 1, 64, 64), (1, 1, 256, 256)]
     for g, w in zip(got, want):
         np.testing.assert_allclose(g.cpu().numpy(), w.numpy(), rtol=2e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("tag,name", [("s", "Tramba-S-TSOD"), ("p", "Tramba-P-TSOD")])
+def test_tramba_s_p_match_reference_golden(golden_enc, tag, name):
+    """Tramba-S (Swin-B) / Tramba-P (PVTv2-b4), SURVEY 8f-4: fp32 against the reference's forward; the encoder's
+    reference-style NCHW outputs (deepest first) and the token-major features the decoder consumes agree; bf16
+    inference keeps the MAE."""
+    import tramba_amd as ta
+    m = _load_synth(ta.bulid_model_enc(name))
+    x = synth.synth_input(f"g5_{tag}", (1, 3, 384, 384)).to(DEV)
+    with torch.no_grad():
+        feats = m.encoder(x)
+        outs = m(x)
+    for i, f in enumerate(feats):
+        pooled = torch.nn.functional.avg_pool2d(f.float(), f.shape[-1] // 6).cpu().numpy()
+        np.testing.assert_allclose(pooled, golden_enc[f"g5_{tag}_enc{i}_pool"], rtol=2e-3, atol=5e-4)
+    assert [tuple(o.shape) for o in outs] == [(1, 1, 24, 24), (1, 1, 48, 48), (1, 1, 96, 96), (1, 1, 384, 384)]
+    for i in range(3):
+        np.testing.assert_allclose(outs[i].cpu().numpy(), golden_enc[f"g5_{tag}_out{i}"], rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(outs[3][:, :, 160:224, 160:224].cpu().numpy(), golden_enc[f"g5_{tag}_out3_crop"], rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(torch.nn.functional.avg_pool2d(outs[3], 8).cpu().numpy(), golden_enc[f"g5_{tag}_out3_pool8"],
+                               rtol=2e-3, atol=1e-3)
+    gt = (synth.synth_input("g5_gt", (384, 384)) > 0.5).numpy()
+    mae32 = oo.mae_metric(torch.sigmoid(outs[3])[0, 0].cpu().numpy(), gt)
+    m16 = ta.prepare_inference(m, torch.bfloat16)
+    with torch.no_grad():
+        o16 = m16(x)
+    assert abs(oo.mae_metric(torch.sigmoid(o16[3])[0, 0].cpu().numpy(), gt) - mae32) < 1e-3
+    # training-mode graph (stock torch ops) gives the same numbers as the HIP inference path, DropPath off
+    m32 = _load_synth(ta.bulid_model_enc(name))
+    for mod in m32.modules():
+        if isinstance(mod, ta.DropPath):
+            mod.drop_prob = 0.0
+    m32.train()
+    xg = x.clone().requires_grad_(True)
+    og = m32(xg)
+    np.testing.assert_allclose(og[2].detach().cpu().numpy(), golden_enc[f"g5_{tag}_out2"], rtol=5e-3, atol=2e-3)
+    og[3].mean().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all() and float(xg.grad.abs().sum()) > 0
 
 
 def test_level0_extension_signature_matches_reference_call_sites():

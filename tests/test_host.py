@@ -73,6 +73,17 @@ def test_state_dict_manifests_match_reference(golden_meta):
     assert sum(p.numel() for p in mr.parameters()) == golden_meta["G6_tramba_r_params"]
 
 
+@pytest.mark.parametrize("tag,name", [("s", "Tramba-S-TSOD"), ("p", "Tramba-P-SOD")])
+def test_encoder_variant_manifests_match_reference(golden_enc_meta, tag, name):
+    """Swin-B / PVTv2-b4 in front of the decoder (Trambav6_enc.py:167-192): same names, shapes (buffers included)
+    and parameter count, so the ImageNet encoder checkpoints and Tramba-S / Tramba-P checkpoints load by name."""
+    import tramba_amd as ta
+    m = ta.bulid_model_enc(name)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == {k: s for k, s in golden_enc_meta[f"G6_tramba_{tag}"]}
+    assert sum(p.numel() for p in m.parameters()) == golden_enc_meta[f"G6_tramba_{tag}_params"]
+    assert all(n.startswith("encoder.") for n, _ in m.named_parameters() if "encoder" in n)      # train.py:266-269
+
+
 def test_linear2d_accepts_conv_checkpoints():
     import tramba_amd as ta
     lin = ta.Linear2d(8, 4, bias=False)
@@ -85,6 +96,8 @@ def test_get_model_build_surface():
     import types
     import tramba_amd as ta
     args = types.SimpleNamespace(img_size=384, pretrained_path="")
-    assert isinstance(ta.build("Tramba-R-TSOD", args), ta.BaseUMambaEnc)
+    for name in ("Tramba-R-TSOD", "Tramba-S-TSOD", "Tramba-P-SOD"):            # get_model.py:2-31
+        assert isinstance(ta.build(name, args), ta.BaseUMambaEnc)
     with pytest.raises(NotImplementedError):
-        ta.build("Tramba-S-TSOD", args)
+        ta.build("BaseUMamba-SOD", args)
+    assert ta.build("no-such-model", args) is None

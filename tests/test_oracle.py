@@ -196,6 +196,34 @@ def test_tramba_r_full_forward(golden, golden_meta):
     np.testing.assert_allclose(outs[2][:, :, 160:224, 160:224].numpy(), golden["g5_r_out2_crop"], rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("tag,fn", [("s", "tramba_s"), ("p", "tramba_p")])
+def test_tramba_s_p_full_forward(golden_enc, golden_enc_meta, tag, fn):
+    """Swin-B / PVTv2-b4 encoders + decoder against the reference's own forward (tests/golden/make_golden_enc.py)."""
+    import tramba_amd as ta
+    torch.set_grad_enabled(False)
+    try:
+        manifest = golden_enc_meta[f"G6_tramba_{tag}"]
+        sd = synth.synth_state_dict(manifest, keep=synth.CONST_KEYS)
+        consts = ta.bulid_model_enc("Tramba-S-TSOD" if tag == "s" else "Tramba-P-TSOD").state_dict()   # masks, index tables, DCT
+        for name, _ in manifest:
+            if name not in sd:
+                sd[name] = consts[name]
+        x = synth.synth_input(f"g5_{tag}", (1, 3, 384, 384))
+        outs = getattr(om, fn)(sd, x)
+        enc = (om.swin_b_encoder if tag == "s" else lambda p, v: om.pvt_v2_b4_encoder(p, v)[::-1])(om.SD(sd, "encoder."), x)
+    finally:
+        torch.set_grad_enabled(True)
+    for i, f in enumerate(enc):
+        np.testing.assert_allclose(torch.nn.functional.avg_pool2d(f, f.shape[-1] // 6).numpy(), golden_enc[f"g5_{tag}_enc{i}_pool"],
+                                   rtol=1e-3, atol=2e-4)
+    assert [tuple(o.shape) for o in outs] == [(1, 1, 24, 24), (1, 1, 48, 48), (1, 1, 96, 96), (1, 1, 384, 384)]
+    for i in range(3):
+        np.testing.assert_allclose(outs[i].numpy(), golden_enc[f"g5_{tag}_out{i}"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(outs[3][:, :, 160:224, 160:224].numpy(), golden_enc[f"g5_{tag}_out3_crop"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(torch.nn.functional.avg_pool2d(outs[3], 8).numpy(), golden_enc[f"g5_{tag}_out3_pool8"],
+                               rtol=1e-3, atol=2e-4)
+
+
 # --------------------------------------------------------------------------- G7 loss / metric
 def test_loss_and_metric_known_answers(golden_meta):
     pred = synth.synth_input("g7_pred", (2, 1, 24, 24), scale=2.0)

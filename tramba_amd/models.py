@@ -279,31 +279,47 @@ class ResNet(nn.Module):
 
 
 class BaseUMambaEnc(nn.Module):
-    """Trambav6_enc.py:162-231.  Tramba-R (ResNet50) is built in; the Swin-B / PVTv2-b4 encoders of
-    Tramba-S / Tramba-P are outside this round's scope and raise."""
+    """Trambav6_enc.py:162-231: Tramba-R (ResNet50), Tramba-S (Swin-B, window 12, 384) and Tramba-P (PVTv2-b4) in
+    front of the same decoder.  The reference reads the encoders' ImageNet checkpoints from hard-coded paths at
+    construction; here `pretrained_path` is optional (a checkpoint of the whole model is loaded by the caller,
+    test_TSOD.py:38)."""
 
     def __init__(self, enc_type, decoder_args, pretrained_path=None):
         super().__init__()
         self.enc_type = enc_type
         self.compute_dtype = None
-        if enc_type in ("Tramba-R-TSOD", "Tramba-R-SOD"):
+        kind = enc_type.split("-")[1] if enc_type.count("-") == 2 else ""
+        if kind == "R" and enc_type.startswith("Tramba-"):
             self.encoder = ResNet(pretrained_path=pretrained_path)
-            decoder_args = dict(decoder_args, features_per_stage=[256, 512, 1024], depths=[2, 2, 2],
-                                concat_from_below=True)
-            self.decoder = VSSMDecoder(**decoder_args)
-        elif enc_type in ("Tramba-S-TSOD", "Tramba-S-SOD", "Tramba-P-TSOD", "Tramba-P-SOD"):
-            raise NotImplementedError(f"{enc_type}: Swin-B / PVTv2 encoders are not part of the MI355X hot path yet")
+            feats, depths = [256, 512, 1024], [2, 2, 2]
+        elif kind == "S" and enc_type.startswith("Tramba-"):
+            from .encoders import SwinTransformer
+            self.encoder = SwinTransformer(img_size=384, embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32),
+                                           window_size=12)
+            _load_encoder(self.encoder, pretrained_path, key="model")
+            feats, depths = [128, 256, 512, 1024], [2, 2, 2, 2]
+        elif kind == "P" and enc_type.startswith("Tramba-"):
+            from .encoders import pvt_v2_b4
+            self.encoder = pvt_v2_b4()
+            _load_encoder(self.encoder, pretrained_path)
+            feats, depths = [64, 128, 320, 512], [2, 2, 2, 2]
         else:
             raise ValueError(f"Unsupported encoder type: {enc_type}")
+        self.kind = kind
+        self.decoder = VSSMDecoder(**dict(decoder_args, features_per_stage=feats, depths=depths, concat_from_below=True))
 
     def forward(self, x):
         _need_device(x)
         if self.compute_dtype is not None:
             x = x.to(self.compute_dtype)
-        xc = x.contiguous(memory_format=torch.channels_last)
-        outs = self.encoder(xc)
-        skips = [x] + [to_cl(o) for o in outs[1:-1][::-1]]  # Trambav6_enc.py:212-213
-        out = self.decoder._forward_cl(skips)
+        if self.kind == "R":
+            outs = self.encoder(x.contiguous(memory_format=torch.channels_last))
+            feats = [to_cl(o) for o in outs[1:-1][::-1]]              # Trambav6_enc.py:212-213
+        elif self.kind == "S":
+            feats = self.encoder.features_cl(x, last=False)          # :210-211 (the last stage's output is never read)
+        else:
+            feats = self.encoder.features_cl(x)                      # :214-215
+        out = self.decoder._forward_cl([x] + feats)
         if self.compute_dtype is not None:
             out = [o.float() for o in out]
         return out
@@ -318,6 +334,20 @@ class BaseUMambaEnc(nn.Module):
     def unfreeze_encoder(self):
         for p in self.encoder.parameters():
             p.requires_grad = True
+
+
+def _load_encoder(encoder, path, key=None):
+    """Trambav6_enc.py:177-179, 188-190: keep the checkpoint entries the encoder has, load them strictly by name."""
+    if not path:
+        return
+    import os
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    sd = torch.load(path, map_location="cpu")
+    sd = sd[key] if key and key in sd else sd
+    own = encoder.state_dict()
+    own.update({k: v for k, v in sd.items() if k in own})
+    encoder.load_state_dict(own)
 
 
 def bulid_model_enc(enc_type, deep_supervision=True, img_size=384, pretrained_path=None):
