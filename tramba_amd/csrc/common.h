@@ -42,6 +42,23 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// ---- XCD-aware work order ----
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2) in linear block-id order.  This maps the
+// block to the work item (i0 fastest, then i1, then i2; extents = the grid's) such that every XCD takes one CONTIGUOUS
+// run of the item list, in order: neighbouring items -- which share cache lines, halo rows or operand panels -- then
+// meet in one L2 instead of being fetched by several.
+__device__ __forceinline__ void xcd_work_item(unsigned &i0, unsigned &i1, unsigned &i2)
+{
+    const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned q = nblk >> 3, r = nblk & 7, xcd = lin & 7, slot = lin >> 3;
+    const unsigned t = xcd * q + (xcd < r ? xcd : r) + slot;
+    i0 = t % gridDim.x;
+    const unsigned u = t / gridDim.x;
+    i1 = u % gridDim.y;
+    i2 = u / gridDim.y;
+}
+
 // ---- dtype traits ----
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {

@@ -472,13 +472,17 @@ __global__ __launch_bounds__(256) void dwconv4_cl_kernel(const T *__restrict__ x
     // grid (x: channel-group x column-tile items of one row, y: row, z: image): no 64-bit index arithmetic (the
     // flat-index form spent ~3k cycles per wave in three emulated 64-bit divisions)
     const int cg = C / V, wtiles = (W + TW - 1) / TW;
-    unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware: each XCD takes a contiguous band of rows, so the KS - 1 halo rows an output row shares with its
+    // neighbours are re-read from ONE L2 (plain order: a row's readers sit on ~4 XCDs, each fetching the line again)
+    unsigned bx_, h_, b_;
+    xcd_work_item(bx_, h_, b_);
+    unsigned item = bx_ * blockDim.x + threadIdx.x;
     const bool live = item < (unsigned)(cg * wtiles);
     if (!live) item = (unsigned)(cg * wtiles) - 1u;   // keep the wave whole: dead lanes recompute the last item, never store
     const int c0 = (int)(item % (unsigned)cg) * V;
     const int w0 = (int)(item / (unsigned)cg) * TW;
-    const int h = blockIdx.y;
-    const int b = blockIdx.z;
+    const int h = (int)h_;
+    const int b = (int)b_;
 
     const unsigned rowb = (unsigned)W * (unsigned)C * (unsigned)sizeof(T);   // bytes per image row
     const unsigned colb = (unsigned)C * (unsigned)sizeof(T);                // bytes per pixel

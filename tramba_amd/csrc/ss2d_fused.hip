@@ -363,6 +363,12 @@ struct ScanWave {
     }
 };
 
+// XCD-aware work order of the chained kernels (xcd_work_item, common.h).  With the plain (x = channel tile) order the
+// channel tiles of ONE sequence sit on 8 different XCDs: every gathered token row is then fetched as 64-byte halves of
+// 128-byte lines by two different L2s (PMC: 2.2x the algorithmic bytes on the Helix launch, 1.09x with the remap), and
+// the x_proj rows 8 times.  Channel tile fastest inside an XCD's run: the tiles sharing lines run side by side on one
+// XCD and the second reader hits in its L2.
+
 template <typename T, typename TY, int NK, bool SPLIT>
 __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
@@ -375,8 +381,10 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, hi = lane >> 5;
-    const int k = blockIdx.y, b = blockIdx.z;
-    const int c = blockIdx.x * kTP + r32;
+    unsigned ct_, k_, b_;
+    xcd_work_item(ct_, k_, b_);
+    const int k = (int)k_, b = (int)b_, ctile = (int)ct_;
+    const int c = ctile * kTP + r32;
     const bool cok = c < D;
     const int cc_ = cok ? c : D - 1;
     const int RG = xdbl_group_stride(R);
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         }
     }
     __syncthreads();
-    const bool cfull = blockIdx.x * kTP + kTP <= D;  // block-uniform: no channel masking needed
+    const bool cfull = ctile * kTP + kTP <= D;  // block-uniform: no channel masking needed
     float carry = 0.f;
     // one super-chunk; STI = ring slot of tile s (compile-time: the ring must be indexed statically)
     auto step = [&](auto sti_c, int s) {
@@ -517,8 +525,10 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, hi = lane >> 5;
-    const int k = blockIdx.y, b = blockIdx.z;
-    const int c = blockIdx.x * kTP + r32;
+    unsigned ct_, k_, b_;
+    xcd_work_item(ct_, k_, b_);
+    const int k = (int)k_, b = (int)b_, ctile = (int)ct_;
+    const int c = ctile * kTP + r32;
     const bool cok = c < D;
     const int cc_ = cok ? c : D - 1;
     const int RG = xdbl_group_stride(R);
@@ -668,7 +678,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
         }
         zc = z;
         // replay right to left, emit
-        const bool full = blockIdx.x * kTP + kTP <= D && l0 + kTP <= L;
+        const bool full = ctile * kTP + kTP <= D && l0 + kTP <= L;
         const unsigned ov = (unsigned)((l0 + 4 * hi) * D + cc_) * (unsigned)sizeof(T);
         float eb[16], ec[16];
 #pragma unroll
@@ -786,6 +796,9 @@ __global__ __launch_bounds__(256) void ss2d_seg_kernel(
     if (gid >= nwaves) return;  // wave-uniform, the kernel has no barriers
     // (32-bit: nwaves < 2^31, host-checked -- emulated 64-bit divisions cost hundreds of instructions per wave)
     const unsigned g32 = (unsigned)gid;
+    // (segment fastest.  Channel-tile fastest -- the 4 waves of a block reading neighbouring 64-byte pieces of the same
+    // rows -- was measured 4.6 % SLOWER on the replay pass: the waves of a block then all fold the same number of
+    // preceding segments, and the long folds bunch up on some CUs.)
     const int sgm = (int)(g32 % (unsigned)NSEG);
     unsigned rt = g32 / (unsigned)NSEG;
     const int ctile = (int)(rt % (unsigned)CT);
