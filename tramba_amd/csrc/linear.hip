@@ -139,6 +139,29 @@ struct ConvGeom {
     int hin, win, cin, hout, wout;
 };
 
+// The tile kernels issue their MFMAs with the operands SWAPPED (weight fragment first): the 32x32 accumulator of a
+// wave then holds, per lane, ONE output row m (= lane & 31) and 16 output columns in four groups of 4 consecutive ones
+// (n = 8g + 4(lane >> 5) + 0..3).  Dropping it into the fp32 staging tile is four 16-byte LDS writes per lane instead of
+// sixteen 4-byte ones, and with a row stride of BN + 4 floats the 16 lanes of a write pass hit 16 different bank groups
+// (the plain orientation wrote 2-way conflicting 4-byte columns: a quarter of the tall GEMMs' LDS time).
+template <int BM, int BN>
+__device__ __forceinline__ void acc_to_lds(acc16_t (&acc)[BM / 64][BN / 64], float *ep)
+{
+    constexpr int TM = BM / 64, TN = BN / 64, WM = BM / 2, WN = BN / 2, LDE = BN + 4;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float *dst = ep + (wm * WM + i * 32 + r32) * LDE + wn * WN + j * 32 + 8 * g + 4 * hi;
+                *reinterpret_cast<float4 *>(dst) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            }
+}
+
 // Epilogue through LDS, block-wide (shared by the tile kernels): see the comment inside.
 template <typename T, typename TO, int BM, int BN>
 __device__ __forceinline__ void tile_epilogue(acc16_t (&acc)[BM / 64][BN / 64], unsigned char *lds,
@@ -152,17 +175,9 @@ __device__ __forceinline__ void tile_epilogue(acc16_t (&acc)[BM / 64][BN / 64], 
     // ---- epilogue through LDS, block-wide: the four waves drop their accumulators into one BM x BN fp32
     // tile, then all 256 threads stream it out as 16-byte stores covering whole rows (a wave-private
     // 32-column epilogue wrote 64-byte half lines with 8-byte stores: ~1 TB/s on the output-bound layers)
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int LDE = BN + 4;
     float *ep = reinterpret_cast<float *>(lds);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                ep[row * BN + wn * WN + j * 32 + r32] = acc[i][j][r];
-            }
+    acc_to_lds<BM, BN>(acc, ep);
     __syncthreads();
     constexpr int CPL = 8;                 // columns per lane: 16 bytes of a 16-bit output row
     constexpr int LPRW = BN / CPL;         // lanes per row
@@ -176,8 +191,8 @@ __device__ __forceinline__ void tile_epilogue(acc16_t (&acc)[BM / 64][BN / 64], 
         if (grow >= M || gcol >= N) continue;
         float o[CPL];
         {
-            const float4 v0 = *reinterpret_cast<const float4 *>(ep + row * BN + cl);
-            const float4 v1 = *reinterpret_cast<const float4 *>(ep + row * BN + cl + 4);
+            const float4 v0 = *reinterpret_cast<const float4 *>(ep + row * LDE + cl);
+            const float4 v1 = *reinterpret_cast<const float4 *>(ep + row * LDE + cl + 4);
             o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
         }
         if (gcol + CPL <= N && (N & 7) == 0) {
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
     constexpr int A_CHUNKS = BM * (kBK / 8), B_CHUNKS = BN * (kBK / 8);
     constexpr int A_PER_T = A_CHUNKS / 256, B_PER_T = B_CHUNKS / 256;
     constexpr int TILE_BYTES = (BM + BN) * kBK * 2;
-    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int EPI_BYTES = BM * (BN + 4) * 4;
     constexpr int LDS_BYTES = 2 * TILE_BYTES > EPI_BYTES ? 2 * TILE_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(b[j], a[i], acc[i][j]);   // swapped: see acc_to_lds
         }
         lstore(kt + 1, store_from);
         __syncthreads();
@@ -403,19 +418,9 @@ __device__ __forceinline__ void tile_epilogue_ln_head(acc16_t (&acc)[BM / 64][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, hi = lane >> 5;
-    // row stride BN + 16 floats (== 64 B mod 256): the 16 lanes of one ds_read_b128 pass (4 rows x 4 lanes) hit 16
-    // different 16-byte bank groups
-    constexpr int LDE = BN + 16;
+    constexpr int LDE = BN + 4;
     float *ep = reinterpret_cast<float *>(lds);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                ep[row * LDE + wn * WN + j * 32 + r32] = acc[i][j][r];
-            }
+    acc_to_lds<BM, BN>(acc, ep);
     __syncthreads();
     // 4 lanes per row; lane `sub` owns the float4 chunks sub, sub + 4, ... (channels 16 j + 4 sub + e)
     const int sub = tid & 3;
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_PER_T = BM * (kBK / 8) / 256, B_PER_T = BN * (kBK / 8) / 256;
     constexpr int TILE_BYTES = (BM + BN) * kBK * 2;
-    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int EPI_BYTES = BM * (BN + 4) * 4;
     constexpr int LDS_BYTES = 2 * TILE_BYTES > EPI_BYTES ? 2 * TILE_BYTES : EPI_BYTES;
     constexpr int NS = PF + 1;
     static_assert(NS % 2 == 0, "the LDS buffer parity must be a compile-time constant");
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(b[j], a[i], acc[i][j]);   // swapped: see acc_to_lds
         }
         lstore(par ^ 1, store_from);
         __syncthreads();
