@@ -112,11 +112,24 @@ def boundary_scan_roofline(dtype):
     for _ in range(5):
         hip.selective_scan_fwd(u, delta, A, B, C, D, bias, True, True, want_ckpt=False)
     torch.cuda.synchronize()
+    # algorithmic bytes of one launch from the library's own accounting ...
     hip.profile_enable(hip.PROF_SCAN_BOUNDARY, True)
-    for _ in range(20):
-        hip.selective_scan_fwd(u, delta, A, B, C, D, bias, True, True, want_ckpt=False)
-    n, ms, nbytes = hip.profile_read(hip.PROF_SCAN_BOUNDARY)
+    hip.selective_scan_fwd(u, delta, A, B, C, D, bias, True, True, want_ckpt=False)
+    _, _, bytes_per_launch = hip.profile_read(hip.PROF_SCAN_BOUNDARY)
     hip.profile_enable(hip.PROF_SCAN_BOUNDARY, False)
+    # ... and the average launch duration from ONE pair of HIP events around n back-to-back launches on the launch
+    # stream (a pair per launch adds the event markers' own ~8 us of serialisation to a 60 us kernel and no longer
+    # agrees with the rocprofv3 kernel trace)
+    n = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        hip.selective_scan_fwd(u, delta, A, B, C, D, bias, True, True, want_ckpt=False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    nbytes = bytes_per_launch * n
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "selective_scan_fwd_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
