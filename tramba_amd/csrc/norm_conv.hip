@@ -306,6 +306,101 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cl_kernel(const T *__restri
             }
 }
 
+// Short rows (C <= 64 * V, a multiple of V): LPR lanes per row, 64 / LPR rows of a wave in flight at once, 16-byte
+// accesses -- the one-row-per-wave form above is latency-bound there (rows of 128 channels keep half a wave idle and
+// every row waits for four dependent wave reductions): 1.27 ms for the 384x384 map of the last decoder stage at batch 8.
+// Same contract: the wave owns rows [wave * rpw, +rpw) and leaves ONE partial (dgamma, dbeta) row.
+template <typename T, int V, int LPR>
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const T *__restrict__ x, const T *__restrict__ dy,
+                                                                const float *__restrict__ w, T *__restrict__ dx,
+                                                                float *__restrict__ part, long rows, int C, float eps,
+                                                                int rpw)
+{
+    constexpr int RPW = kWave / LPR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long r0 = wave * rpw;
+    if (r0 >= rows) return;   // wave-uniform, no barriers
+    const long rend = r0 + rpw < rows ? r0 + rpw : rows;
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int c0 = sub * V;
+    const bool cok = c0 + V <= C;
+    float gam[V], gw[V], gb[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        gam[v] = cok ? w[c0 + v] : 0.f;
+        gw[v] = 0.f;
+        gb[v] = 0.f;
+    }
+    const float inv_c = 1.f / (float)C;
+    for (long rb = r0; rb < rend; rb += RPW) {
+        const long r = rb + slot;
+        const bool ok = r < rend && cok;
+        float xv[V], gv[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) xv[v] = gv[v] = 0.f;
+        if (ok) {
+            load_pack<T, V>(x + r * C + c0, xv);
+            load_pack<T, V>(dy + r * C + c0, gv);
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) sm += xv[v];
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o, LPR);
+        const float mean = sm * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float t = cok ? xv[v] - mean : 0.f;
+            q = fmaf(t, t, q);
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, LPR);
+        const float rstd = rsqrtf(q * inv_c + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float xh = cok ? (xv[v] - mean) * rstd : 0.f;
+            const float g = gv[v] * gam[v];
+            xv[v] = xh;
+            s1 += g;
+            s2 = fmaf(g, xh, s2);
+            gw[v] = fmaf(gv[v], xh, gw[v]);    // rows past the end were loaded as zeros: they add nothing
+            gb[v] += gv[v];
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, LPR);
+            s2 += __shfl_xor(s2, o, LPR);
+        }
+        s1 *= inv_c;
+        s2 *= inv_c;
+        if (ok) {
+            float o_[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) o_[v] = rstd * (gv[v] * gam[v] - s1 - xv[v] * s2);
+            store_pack<T, V>(dx + r * C + c0, o_);
+        }
+    }
+    // fold the RPW row slots of the wave (lanes with equal `sub`), then slot 0 writes the partial row
+#pragma unroll
+    for (int o = LPR; o < kWave; o <<= 1)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            gw[v] += __shfl_xor(gw[v], o, kWave);
+            gb[v] += __shfl_xor(gb[v], o, kWave);
+        }
+    if (slot == 0 && cok) {
+        float *pw = part + wave * 2 * C;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            pw[c0 + v] = gw[v];
+            pw[C + c0 + v] = gb[v];
+        }
+    }
+}
+
 template <typename T>
 static int launch_rowdot(const void *x, const float *w, float bias, float *y, long rows, int c, hipStream_t s)
 {
@@ -723,6 +818,33 @@ extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const floa
     const long rpw = ln_bwd_rows_per_wave(rows);
     const long waves = (rows + rpw - 1) / rpw;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    // short rows: several rows per wave, 16-byte accesses (TRAMBA_LN_BWD=wave keeps the one-row-per-wave kernel)
+    static const bool rows_form = !(getenv("TRAMBA_LN_BWD") && strcmp(getenv("TRAMBA_LN_BWD"), "wave") == 0);
+    const int vm = dtype == TRAMBA_F32 ? 4 : 8;
+    if (rows_form && c % vm == 0 && c <= kWave * vm) {
+        int lpr = 1;
+        while (lpr < c / vm) lpr <<= 1;
+#define GOB_(T, V_, L_)                                                                                             \
+    hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, V_, L_>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, \
+                       part, (long)rows, c, eps, (int)rpw)
+#define BYL_(T, V_)                    \
+    switch (lpr) {                     \
+    case 1: GOB_(T, V_, 1); break;     \
+    case 2: GOB_(T, V_, 2); break;     \
+    case 4: GOB_(T, V_, 4); break;     \
+    case 8: GOB_(T, V_, 8); break;     \
+    case 16: GOB_(T, V_, 16); break;   \
+    case 32: GOB_(T, V_, 32); break;   \
+    default: GOB_(T, V_, 64); break;   \
+    }
+        if (dtype == TRAMBA_F32) { BYL_(float, 4) }
+        else if (dtype == TRAMBA_BF16) { BYL_(__hip_bfloat16, 8) }
+        else { BYL_(__half, 8) }
+#undef BYL_
+#undef GOB_
+        TRAMBA_LAUNCH_CHECK();
+        return TRAMBA_OK;
+    }
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
         if (v == 4) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 4>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
         else if (v == 2) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 2>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
