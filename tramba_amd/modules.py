@@ -513,18 +513,23 @@ class _SS2DCoreCL(torch.autograd.Function):
         gu, graw, g_b, g_c, gpar = hip.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds,
                                                        gym.contiguous().float())
         gx = hip.ss2d_merge_sum_cl(gu, order, x.dtype)
-        tbl = order.table.long()
-        xd = xdbl.view(b, l, k, rg)
-        ranks = torch.stack([xd[:, tbl[i], i, :r] for i in range(k)], dim=1)            # (B,K,L,R) f32
+        # row (l, k) of xdbl viewed as (B, L*K, RG) that sequence position (k, i) reads: table[k][i] * K + k.  One gather
+        # and one index_add_ over all K directions instead of 4 launches per direction (660 small kernels per step)
+        flat = getattr(order, "_flat_rows", None)
+        if flat is None or flat.device != x.device:
+            flat = (order.table.long() * k + torch.arange(k, device=x.device)[:, None]).reshape(-1)
+            order._flat_rows = flat
+        xdf = xdbl.view(b, l * k, rg)
+        ranks = xdf[:, flat, :r].view(b, k, l, r)                                          # (B,K,L,R) f32
         cd = graw.dtype
         # batched GEMMs on views (einsum would first copy the K-fold graw into its own layout)
         g_dtw = torch.matmul(graw.transpose(-1, -2), ranks.to(cd)).float().sum(dim=0)       # (K,D,R)
-        g_ranks = torch.matmul(graw, dt_w.to(cd).unsqueeze(0)).float()                       # (B,K,L,R)
-        g_xd = torch.zeros_like(xd)
-        for i in range(k):
-            g_xd[:, :, i, :r].index_add_(1, tbl[i], g_ranks[:, i])
-            g_xd[:, :, i, r8].index_add_(1, tbl[i], g_b[:, i])
-            g_xd[:, :, i, r8 + 1].index_add_(1, tbl[i], g_c[:, i])
+        g_seq = torch.zeros((b, k, l, rg), dtype=torch.float32, device=x.device)           # gradients in sequence order
+        g_seq[..., :r] = torch.matmul(graw, dt_w.to(cd).unsqueeze(0))                        # (B,K,L,R)
+        g_seq[..., r8] = g_b
+        g_seq[..., r8 + 1] = g_c
+        g_xd = torch.zeros_like(xdf)
+        g_xd.index_add_(1, flat, g_seq.view(b, k * l, rg))
         gp = gpar.sum(dim=0)                                                              # (K,3,D)
         return (gx, g_xd.view(b, l, k * rg), g_dtw, gp[:, 2].reshape(-1), gp[:, 0].reshape(-1), gp[:, 1].reshape(-1),
                 None)

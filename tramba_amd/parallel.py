@@ -4,8 +4,8 @@ The reference has no distributed code (`--parallel` only prints, run.py:46-50). 
 image, so the single exchange step is an all-reduce(SUM)/world of the gradients.  Design for xGMI
 (point-to-point links, ring collectives are per-link bound): few large flat buckets (default 32 MB)
 instead of one call per tensor, launched from autograd hooks in reverse registration order so RCCL
-works on bucket i while backward still produces bucket i+1; one flat buffer per bucket and the
-gradients are VIEWS into it (no gather/scatter copies).  Backend: "nccl" (= RCCL) on GPUs, "gloo" in
+works on bucket i while backward still produces bucket i+1; one flat buffer per bucket, filled by one
+multi-tensor copy when the bucket's last gradient arrives, after which the .grad fields are VIEWS into it.  Backend: "nccl" (= RCCL) on GPUs, "gloo" in
 the CPU tests.
 """
 import torch
@@ -50,34 +50,46 @@ class GradBucketReducer:
         self.prepare()
 
     def prepare(self):
-        """Zero the buckets and point every .grad at its slice; call before each backward
-        (it replaces optimizer.zero_grad())."""
+        """Call before each backward (it replaces optimizer.zero_grad()).  Gradients start as None, so autograd hands
+        each parameter a fresh tensor instead of launching one `+=` kernel per parameter into a zeroed bucket (673 adds
+        and as many slices of zero-fill per step on Tramba-V); a completed bucket is filled by ONE multi-tensor copy."""
         self._handles = []
         for bi, bucket in enumerate(self.buckets):
-            self.flat[bi].zero_()
             self._pending[bi] = len(bucket)
             for p in bucket:
-                p.grad = self._where[p][1]
+                p.grad = None
+
+    def _flush(self, bi):
+        """Every gradient of bucket `bi` exists (or its parameter was unused): move them into the flat buffer, point
+        .grad at the slices, start the all-reduce."""
+        bucket = self.buckets[bi]
+        views = [self._where[p][1] for p in bucket]
+        dst = [v for v, p in zip(views, bucket) if p.grad is not None and p.grad is not v]
+        src = [p.grad for v, p in zip(views, bucket) if p.grad is not None and p.grad is not v]
+        unused = [v for v, p in zip(views, bucket) if p.grad is None]
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if unused:
+            torch._foreach_zero_(unused)
+        for p, v in zip(bucket, views):
+            p.grad = v
+        if self.world > 1:
+            self._handles.append(dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad(self, p):
-        bi, view = self._where[p]
-        if p.grad is not view:  # autograd installed a fresh tensor: move it into the bucket
-            view.copy_(p.grad)
-            p.grad = view
+        bi, _ = self._where[p]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and self.world > 1:
-            self._handles.append(dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group,
-                                                 async_op=True))
+        if self._pending[bi] == 0:
+            self._flush(bi)
 
     def finish(self):
-        """Wait for the outstanding all-reduces, also reduce buckets whose hooks did not all fire
-        (parameters unused in this step), then average."""
+        """Flush buckets whose hooks did not all fire (parameters unused in this step), wait for the outstanding
+        all-reduces, then average."""
+        for bi, left in enumerate(self._pending):
+            if left > 0:
+                self._flush(bi)
+                self._pending[bi] = 0
         if self.world > 1:
-            for bi, left in enumerate(self._pending):
-                if left > 0:
-                    self._handles.append(dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group,
-                                                         async_op=True))
-                    self._pending[bi] = 0
             for h in self._handles:
                 h.wait()
             for flat in self.flat:
