@@ -795,8 +795,11 @@ extern "C" int tramba_layernorm_cl(const void *x, const float *w, const float *b
 
 static long ln_bwd_rows_per_wave(long rows)
 {
-    long rpw = rows / 4096;   // ~4096+ waves in flight
-    return rpw < 1 ? 1 : (rpw > 32 ? 32 : rpw);
+    // ~4096 waves on the large maps; never fewer than 8 rows per wave: every wave leaves a (2, C) partial row that the
+    // caller sums, and at one row per wave (24x24 maps) writing and summing the partials moved 2.7x the bytes of the
+    // backward itself
+    long rpw = rows / 4096;
+    return rpw < 8 ? 8 : (rpw > 128 ? 128 : rpw);
 }
 
 extern "C" int64_t tramba_layernorm_bwd_parts(int64_t rows)
