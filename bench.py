@@ -152,7 +152,7 @@ def bench_train(args, world, rank, dtype):
     b = args.train_batch
     x = torch.randn(b, 3, args.img, args.img, generator=torch.Generator().manual_seed(100 + rank)).cuda()
     y = (torch.rand(b, 1, args.img, args.img, generator=torch.Generator().manual_seed(200 + rank)) > 0.7).float().cuda()
-    steps, warm = max(3, args.steps // 4), 2
+    steps, warm = max(5, args.steps // 2), 3
     for _ in range(warm):
         train.train_step(model, opt, x, y, reducer=red)
     torch.cuda.synchronize()
