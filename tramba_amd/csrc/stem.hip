@@ -37,9 +37,11 @@ __global__ __launch_bounds__(256) void stem_conv_ln_gelu_kernel(const TI *__rest
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = bias[part * 16 + j];
-#pragma unroll
+    // (one input channel per trip, NOT unrolled: fully unrolled, hipcc hoists all 108 16-byte weight reads to the top
+    //  and parks them in AGPRs -- 242 v_accvgpr_read per thread and one wave per SIMD)
+#pragma unroll 1
     for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
+#pragma unroll 1
         for (int ky = 0; ky < 3; ++ky) {
             const int hy = 2 * ho + ky - 1;
 #pragma unroll
