@@ -145,7 +145,7 @@ def test_dwconv_and_dwms_cl(dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [(2, 12, 16), (1, 24, 40), (1, 48, 64), (1, 96, 128), (1, 16, 8)])
+@pytest.mark.parametrize("cfg", [(2, 12, 16), (1, 24, 40), (1, 48, 64), (1, 96, 128), (1, 16, 8), (1, 112, 72), (1, 192, 64), (2, 20, 200)])
 def test_dct_split_cl(dtype, cfg):
     b, n, c = cfg
     x = torch.randn(b, n, n, c).to(dtype)
