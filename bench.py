@@ -10,10 +10,14 @@ Inference shards by image: every rank runs an independent replica on its own bat
 collective ("weak" scaling); the barrier only brackets the timed region.
 
 Rank 0 prints ONE JSON line.  Extra objects on that line:
-  roofline      dominant HIP kernel of the step (the fused channels-last selective scan): algorithmic
-                bytes / HIP-event time of ITS launches inside the timed steps, against 8 TB/s HBM peak
-  roofline_boundary   the same for the reference-layout selective scan (the L0 drop-in op, 8 B/element
-                at bf16-in/fp32-out) on the largest call shape of this model
+  roofline      the dominant kernel launch of the step -- the fused channels-last selective scan on the Helix order at
+                96x96 (K = 8, D = 256, B = 4; 2 launches per forward, the largest single item): algorithmic bytes per
+                launch / average launch duration (one HIP-event pair around 20 back-to-back launches on the launch
+                stream), against 8 TB/s HBM peak; `traffic` = PMC bytes of the same launch (profiles/*_traffic.json)
+  roofline_fused_scan_all   every fused-scan launch of a forward (33, all shapes) timed inside an eager pass of the model
+  roofline_boundary   the reference-layout selective scan (the L0 drop-in op, 8 B/element at bf16-in/fp32-out, SURVEY
+                8d) on the largest call shape of this model
+  roofline_gemm       the 1x1-conv projections (MFMA): 2*M*N*K of every GEMM launch of a forward / their time
   cpu_baseline  the CPU oracle (a port of the reference forward, oracle/) timed on this host
 """
 import argparse
@@ -133,8 +137,36 @@ def boundary_scan_roofline(dtype):
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "selective_scan_fwd_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic("selective_scan_fwd_kernel@grid262144"),
+            "traffic": (pmc_traffic("selective_scan_fwd_kernel@grid262144") or {}).get("bytes"),
+            "traffic_detail": pmc_traffic("selective_scan_fwd_kernel@grid262144"),
             "shape": [nb, kd, l], "launches": n, "avg_us": round(ms / n * 1e3, 2)}
+
+
+def helix_scan_roofline(step, nrep):
+    """The Helix-SS2D launch of the fused scan kernel at the decoder's 96x96 stage (K = 8, D = 256, B = 4): the largest
+    single (kernel, shape) item of the forward (2 launches, ~0.24 ms of 5.3), timed INSIDE eager forwards of the model:
+    the library's launch profiler (one HIP-event pair per launch, on the launch stream) is restricted to launches
+    accounting for >= 300 MB, which only this shape does (335 MB; the next largest fused scan is 177 MB)."""
+    from tramba_amd import hip
+    hip.profile_min_units(hip.PROF_SCAN_FUSED, 300e6)
+    hip.profile_enable(hip.PROF_SCAN_FUSED, True)
+    for _ in range(nrep):
+        step()
+    n, ms, nbytes = hip.profile_read(hip.PROF_SCAN_FUSED)
+    hip.profile_enable(hip.PROF_SCAN_FUSED, False)
+    hip.profile_min_units(hip.PROF_SCAN_FUSED, 0.0)
+    if n == 0:
+        return None
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    pmc = pmc_traffic("ss2d_scan_cl_kernel@grid131072")
+    return {"bound": "hbm", "kernel": "ss2d_scan_cl_kernel (Helix-SS2D launch: 96x96, K=8, D=256, B=4, ys f32)",
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": pmc["bytes"] if pmc else None, "traffic_detail": pmc, "algorithmic_bytes": int(nbytes / n),
+            "launches": n, "avg_us": round(ms / n * 1e3, 2),
+            "note": "per launch: algorithmic bytes (x once + x_proj rows + ys) / average HIP-event duration of this "
+                    "shape's launches inside eager single-stream forwards of the model; traffic = PMC bytes of the same "
+                    "launch (separate FETCH_SIZE / WRITE_SIZE passes); all 33 fused-scan launches of a forward together: "
+                    "roofline_fused_scan_all"}
 
 
 def bench_train(args, world, rank, dtype):
@@ -235,7 +267,7 @@ def main():
 
     # ---- roofline of the dominant kernel: eager pass of the same steps with HIP events around
     #      every launch of the fused scan kernel (events cannot live inside a captured graph)
-    roof = roof_b = roof_g = cpu = None
+    roof = roof_all = roof_b = roof_g = cpu = None
     if rank == 0:
         from tramba_amd import models as _models
         overlap_was = _models.OVERLAP_BRANCHES
@@ -251,13 +283,14 @@ def main():
         hip.profile_enable(hip.PROF_GEMM, False)
         _models.OVERLAP_BRANCHES = overlap_was
         gbs = nbytes / (ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "ss2d_scan_cl_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic("ss2d_scan_cl_kernel@grid131072"), "launches": n,
-                "avg_us": round(ms / n * 1e3, 2), "ms_per_step": round(ms / nrep, 3),
-                "note": "achieved = sum of algorithmic bytes / sum of HIP-event time over the fused-scan launches of "
-                        "a step (single-stream eager pass, so each launch runs alone); traffic = PMC bytes of the "
-                        "largest launch (Helix 96x96)"}
+        roof_all = {"bound": "hbm", "kernel": "ss2d_scan_cl_kernel + ss2d_seg_kernel, all shapes", "achieved": round(gbs, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches": n, "avg_us": round(ms / n * 1e3, 2), "ms_per_step": round(ms / nrep, 3),
+                    "note": "sum of algorithmic bytes / sum of HIP-event time over every fused-scan launch of a step "
+                            "(single-stream eager pass, one event pair per launch)"}
+        _models.OVERLAP_BRANCHES = False
+        roof = helix_scan_roofline(step, nrep)
+        _models.OVERLAP_BRANCHES = overlap_was
         tfs = flops / (msg * 1e-3) / 1e12
         roof_g = {"bound": "mfma", "kernel": "linear_lean_kernel / linear_tiled_kernel (1x1-conv projections)",
                   "achieved": round(tfs, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_PEAK_TFS, 4),
@@ -285,7 +318,8 @@ def main():
                        "launch": ("hipGraph replay" if graph is not None else "eager") +
                                  (", decoder guide branches on a side stream"
                                   if os.environ.get("TRAMBA_OVERLAP", "1") != "0" else "")},
-            "roofline": roof, "roofline_boundary": roof_b, "roofline_gemm": roof_g, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_fused_scan_all": roof_all, "roofline_boundary": roof_b, "roofline_gemm": roof_g,
+            "cpu_baseline": cpu,
         }
         if train_obj is not None:
             line["train"] = train_obj

@@ -71,6 +71,9 @@ int tramba_abi_version(void);
  * (DESIGN.md states the per-kernel formula). */
 int tramba_profile_enable(int which, int enable);
 int tramba_profile_read(int which, double *total_ms, double *total_bytes);
+/* Time only the launches of class `which` that account for at least `min_units` bytes (flops): singles out one shape
+ * (e.g. the Helix 96x96 fused scan inside a model forward).  0 = every launch (default). */
+int tramba_profile_min_units(int which, double min_units);
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1
 #define TRAMBA_PROF_GEMM 2          /* tramba_linear_cl (1x1-conv projections) */

@@ -67,3 +67,11 @@ for k, v in traffic.items():
         v["what"], v["algorithmic_bytes"] = shapes[k]
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
+
+# per (kernel, grid) durations of the scan kernels in the single-stream trace: the Helix 96x96 launch that bench.py's
+# `roofline` object times is the grid=(4096,8) wg=512 row
+import subprocess
+tb = os.path.join(root, "scripts", "trace_by_grid.py")
+with open(os.path.join(dst, f"{tag}_scan_by_grid.txt"), "w") as f:
+    for pat in ("ss2d_s", "selective_scan"):
+        f.write(subprocess.run([sys.executable, tb, os.path.join(src, "trace"), pat], capture_output=True, text=True).stdout)

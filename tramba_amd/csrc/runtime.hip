@@ -23,6 +23,7 @@ void set_error(const char *fmt, ...)
 // ---------------------------------------------------------------- profiling
 struct ProfState {
     bool enabled = false;
+    double min_units = 0.0;   // launches accounting for fewer units (bytes / flops) are not timed
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double units = 0.0;
 };
@@ -31,7 +32,7 @@ static std::mutex g_prof_mu;
 
 ProfScope::ProfScope(int w, hipStream_t s, double units) : which(w), stream(s), on(false), start(nullptr)
 {
-    if (w < 0 || w >= TRAMBA_PROF_COUNT || !g_prof[w].enabled) return;
+    if (w < 0 || w >= TRAMBA_PROF_COUNT || !g_prof[w].enabled || units < g_prof[w].min_units) return;
     // never create events while the stream is capturing a graph
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
@@ -63,6 +64,14 @@ extern "C" int tramba_profile_enable(int which, int enable)
     TRAMBA_CHECK(which >= 0 && which < TRAMBA_PROF_COUNT, "profile class %d out of range", which);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof[which].enabled = enable != 0;
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_profile_min_units(int which, double min_units)
+{
+    TRAMBA_CHECK(which >= 0 && which < TRAMBA_PROF_COUNT, "profile class %d out of range", which);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof[which].min_units = min_units;
     return TRAMBA_OK;
 }
 

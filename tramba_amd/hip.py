@@ -32,6 +32,7 @@ SIGNATURES = {
     "tramba_abi_version": (c_int, []),
     "tramba_profile_enable": (c_int, [c_int, c_int]),
     "tramba_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "tramba_profile_min_units": (c_int, [c_int, ctypes.c_double]),
     "tramba_scan_family_k": (c_int, [c_int]),
     "tramba_default_window": (c_int, [c_int]),
     "tramba_scan_table": (c_int, [c_int, c_int, c_int, c_int, c_vp]),
@@ -200,6 +201,11 @@ def scan_order(family: str, h: int, w: int, device, param: int = 0) -> ScanOrder
 # ----------------------------------------------------------------------------- profiling
 def profile_enable(which: int, on: bool):
     _check(lib().tramba_profile_enable(which, int(on)), "profile_enable")
+
+
+def profile_min_units(which: int, min_units: float):
+    """time only launches accounting for at least `min_units` algorithmic bytes / flops (0 = all)"""
+    _check(lib().tramba_profile_min_units(which, float(min_units)), "profile_min_units")
 
 
 def profile_read(which: int):
