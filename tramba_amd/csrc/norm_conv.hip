@@ -697,40 +697,72 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_cl_kernel(const T *__restric
         for (int dx = 0; dx < KS; ++dx) acc[dy][dx] = dw_v2f{0.f, 0.f};
 
     const int rend = row0 + RPW < H ? row0 + RPW : H;
-    for (int h = row0; h < rend; ++h) {
-        for (int w0 = 0; w0 < W; w0 += TW) {
-            dw_v2f g[TW];
+    if constexpr (KS <= 3) {
+        // small stencil: every tap row unrolled -- all KS * NI loads of a column group are in flight together (one memory
+        // latency per group instead of one per tap row) and acc[][] is indexed statically
+        for (int h = row0; h < rend; ++h) {
+            for (int w0 = 0; w0 < W; w0 += TW) {
+                dw_v2f g[TW];
 #pragma unroll
-            for (int t = 0; t < TW; ++t) {
-                const unsigned vo = (w0 + t < W && cok) ? (unsigned)((h * W + w0 + t) * C) * (unsigned)sizeof(T) + cb : kOutOfRange;
-                g[t] = dw_load2<T>(rg, vo);
-                accb = accb + g[t];
+                for (int t = 0; t < TW; ++t) {
+                    const unsigned vo = (w0 + t < W && cok) ? (unsigned)((h * W + w0 + t) * C) * (unsigned)sizeof(T) + cb : kOutOfRange;
+                    g[t] = dw_load2<T>(rg, vo);
+                    accb = accb + g[t];
+                }
+                dw_v2f xin[KS][NI];
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy) {
+                    const int hy = h + dy - R;
+                    const bool rowok = hy >= 0 && hy < H;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int wx = w0 - R + i;
+                        const unsigned vo = (rowok && wx >= 0 && wx < W && cok)
+                                                ? (unsigned)((hy * W + wx) * C) * (unsigned)sizeof(T) + cb : kOutOfRange;
+                        xin[dy][i] = dw_load2<T>(rx, vo);
+                    }
+                }
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) acc[dy][dx] = g[t] * xin[dy][t + dx] + acc[dy][dx];
             }
-#pragma unroll 1
-            for (int dy = 0; dy < KS; ++dy) {
+        }
+    } else {
+        // wide stencil: the tap row is the OUTER, unrolled loop -- acc[dy][] is indexed statically (the run-time-dy form
+        // updated all KS * KS accumulators under a select, KS times per column group, and paid one memory latency per tap
+        // row), only KS accumulators are hot per copy, and the column loop is unrolled so that several groups' loads are in
+        // flight.  gy is re-read once per tap row (from L2).
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy) {
+            for (int h = row0; h < rend; ++h) {
                 const int hy = h + dy - R;
-                const bool rowok = hy >= 0 && hy < H;
-                dw_v2f xin[NI];
+                if (hy < 0 || hy >= H) continue;   // (dy == R is never skipped: the bias sum below sees every row)
+#pragma unroll 2
+                for (int w0 = 0; w0 < W; w0 += TW) {
+                    dw_v2f g[TW], xin[NI];
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int wx = w0 - R + i;
-                    const unsigned vo = (rowok && wx >= 0 && wx < W && cok)
-                                            ? (unsigned)((hy * W + wx) * C) * (unsigned)sizeof(T) + cb : kOutOfRange;
-                    xin[i] = dw_load2<T>(rx, vo);
+                    for (int t = 0; t < TW; ++t) {
+                        const unsigned vo = (w0 + t < W && cok) ? (unsigned)((h * W + w0 + t) * C) * (unsigned)sizeof(T) + cb : kOutOfRange;
+                        g[t] = dw_load2<T>(rg, vo);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int wx = w0 - R + i;
+                        const unsigned vo = (wx >= 0 && wx < W && cok) ? (unsigned)((hy * W + wx) * C) * (unsigned)sizeof(T) + cb : kOutOfRange;
+                        xin[i] = dw_load2<T>(rx, vo);
+                    }
+                    if (dy == R) {   // (compile-time after unrolling)
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) accb = accb + g[t];
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) acc[dy][dx] = g[t] * xin[t + dx] + acc[dy][dx];
                 }
-                // acc[dy][dx] is indexed with a run-time dy: keep the row in registers through a switch-free copy
-                dw_v2f part[KS];
-#pragma unroll
-                for (int dx = 0; dx < KS; ++dx) {
-                    part[dx] = dw_v2f{0.f, 0.f};
-#pragma unroll
-                    for (int t = 0; t < TW; ++t) part[dx] = g[t] * xin[t + dx] + part[dx];
-                }
-#pragma unroll
-                for (int d2 = 0; d2 < KS; ++d2)
-                    if (d2 == dy)
-#pragma unroll
-                        for (int dx = 0; dx < KS; ++dx) acc[d2][dx] = acc[d2][dx] + part[dx];
             }
         }
     }
