@@ -424,6 +424,28 @@ def test_dwms_training_fold_matches_reference_sum():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 3, 64, 96, 2), (8, 64, 128, 48, 2), (2, 16, 24, 20, 1), (16, 8, 8, 64, 2)])
+def test_dense_conv_training_path_matches_autograd(dtype, cfg):
+    """_ConvNative (native forward / input gradient, im2col + token-split GEMM weight gradient) against F.conv2d autograd
+    in fp64; the last cases are large enough (B*Ho*Wo >= 8192) to take the split path."""
+    from tramba_amd import modules as M
+    b, cin, cout, hw, stride = cfg
+    g = torch.Generator().manual_seed(cin * cout + hw)
+    x = torch.randn(b, cin, hw, hw, generator=g).to(dtype)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).to(dtype)
+    bias = (0.1 * torch.randn(cout, generator=g)).to(dtype)
+    gy_shape = F.conv2d(x.float(), w.float(), stride=stride, padding=1).shape
+    gy = torch.randn(gy_shape, generator=g).to(dtype)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, bias))
+    F.conv2d(xr, wr, br, stride=stride, padding=1).backward(gy.double())
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, bias))
+    M._ConvNative.apply(xg, wg, bg, (stride, stride), (1, 1), 1).backward(gy.to(DEV))
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    for got, want in ((xg.grad, xr.grad), (wg.grad, wr.grad), (bg.grad, br.grad)):
+        np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rc", [(500, 128), (77, 512), (4100, 256), (33, 1024), (64, 2048), (50, 40), (100003, 128), (70001, 64),
                                 (9001, 320)])
 def test_layernorm_training_path_matches_autograd(dtype, rc):

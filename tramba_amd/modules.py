@@ -121,10 +121,18 @@ class _ConvNative(torch.autograd.Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         stride, padding, groups, has_bias = ctx.cfg
+        # dense convs: the weight gradient is a GEMM whose reduction runs over all B*Ho*Wo output pixels and whose output
+        # is Cout x 9 Cin -- the native kernel does it per sample with one tile (1 ms for the first stem conv); im2col once
+        # and the token-split batched GEMM of _wgrad_tall instead
+        own_gw = groups == 1 and ctx.needs_input_grad[1] and x.dim() == 4
         with torch.backends.cudnn.flags(enabled=False):
             gx, gw, gb = torch.ops.aten.convolution_backward(
                 gy.contiguous(), x, w, [w.shape[0]] if has_bias else None, list(stride), list(padding), [1, 1], False,
-                [0, 0], groups, [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias])
+                [0, 0], groups, [ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not own_gw, has_bias])
+        if own_gw:
+            cols = F.unfold(x, w.shape[-2:], padding=padding, stride=stride)           # (B, Cin*kh*kw, L)
+            gy2 = gy.flatten(2).transpose(1, 2).reshape(-1, gy.shape[1])                 # (B*L, Cout)
+            gw = _wgrad_tall(gy2, cols.transpose(1, 2).reshape(gy2.shape[0], -1)).view_as(w).to(w.dtype)
         return gx, gw, gb, None, None, None
 
 
