@@ -26,5 +26,6 @@ for e in prof.events():
         agg[key][0] += 1
         agg[key][1] += getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0)
 rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
-for (name, shp), (n, t) in rows[:70]:
+only = sys.argv[1:] or None
+for (name, shp), (n, t) in (rows[:70] if not only else [r for r in rows if r[0][0] in only][:90]):
     print(f"n={n:4d} {t/1e3:8.2f} ms {name:18s} {shp}")
