@@ -144,12 +144,24 @@ struct ConvGeom {
 // (n = 8g + 4(lane >> 5) + 0..3).  Dropping it into the fp32 staging tile is four 16-byte LDS writes per lane instead of
 // sixteen 4-byte ones, and with a row stride of BN + 4 floats the 16 lanes of a write pass hit 16 different bank groups
 // (the plain orientation wrote 2-way conflicting 4-byte columns: a quarter of the tall GEMMs' LDS time).
-template <int BM, int BN>
-__device__ __forceinline__ void acc_to_lds(acc16_t (&acc)[BM / 64][BN / 64], float *ep)
+// Wave layouts of a 256-thread block: NWM = 2 -> 2 x 2 waves (each BM/2 x BN/2); NWM = 3 -> 3 x 1 compute waves (each
+// BM/3 x BN), the fourth wave only stages operands and streams the epilogue (the 96x64 tile: M = 2304 is 24 x 96, so the
+// 15-block stage's 512-wide GEMMs make 192 workgroups = ONE round on 256 CUs, where 64x64 tiles make 288 = two).
+template <int BM, int BN, int NWM>
+struct WaveLayout {
+    static constexpr int NWN = NWM == 2 ? 2 : 1;
+    static constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tiles are whole 32x32 MFMA tiles");
+};
+
+template <int BM, int BN, int NWM = 2, typename ACC>
+__device__ __forceinline__ void acc_to_lds(ACC &acc, float *ep)   // ACC = acc16_t[TM][TN] of the layout
 {
-    constexpr int TM = BM / 64, TN = BN / 64, WM = BM / 2, WN = BN / 2, LDE = BN + 4;
+    using WL = WaveLayout<BM, BN, NWM>;
+    constexpr int TM = WL::TM, TN = WL::TN, WM = WL::WM, WN = WL::WN, LDE = BN + 4;
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
-    const int wm = wave >> 1, wn = wave & 1;
+    if (wave >= NWM * WL::NWN) return;       // the loader wave of the 3 x 1 layout holds no accumulators
+    const int wm = wave / WL::NWN, wn = wave % WL::NWN;
     const int r32 = lane & 31, hi = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -163,21 +175,18 @@ __device__ __forceinline__ void acc_to_lds(acc16_t (&acc)[BM / 64][BN / 64], flo
 }
 
 // Epilogue through LDS, block-wide (shared by the tile kernels): see the comment inside.
-template <typename T, typename TO, int BM, int BN>
-__device__ __forceinline__ void tile_epilogue(acc16_t (&acc)[BM / 64][BN / 64], unsigned char *lds,
+template <typename T, typename TO, int BM, int BN, int NWM = 2, typename ACC>
+__device__ __forceinline__ void tile_epilogue(ACC &acc, unsigned char *lds,
                                               const float *__restrict__ bias, const T *__restrict__ res,
                                               TO *__restrict__ y, long M, int N, int act, long m0, int n0)
 {
-    constexpr int TM = BM / 64, TN = BN / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r32 = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x;
     // ---- epilogue through LDS, block-wide: the four waves drop their accumulators into one BM x BN fp32
     // tile, then all 256 threads stream it out as 16-byte stores covering whole rows (a wave-private
     // 32-column epilogue wrote 64-byte half lines with 8-byte stores: ~1 TB/s on the output-bound layers)
     constexpr int LDE = BN + 4;
     float *ep = reinterpret_cast<float *>(lds);
-    acc_to_lds<BM, BN>(acc, ep);
+    acc_to_lds<BM, BN, NWM>(acc, ep);
     __syncthreads();
     constexpr int CPL = 8;                 // columns per lane: 16 bytes of a 16-bit output row
     constexpr int LPRW = BN / CPL;         // lanes per row
@@ -185,7 +194,7 @@ __device__ __forceinline__ void tile_epilogue(acc16_t (&acc)[BM / 64][BN / 64], 
     const int cl = (tid % LPRW) * CPL, rl = tid / LPRW;
     const int gcol = n0 + cl;
 #pragma unroll
-    for (int it = 0; it < BM / RPI; ++it) {
+    for (int it = 0; it < (BM + RPI - 1) / RPI; ++it) {
         const int row = it * RPI + rl;
         const long grow = m0 + row;
         if (grow >= M || gcol >= N) continue;
@@ -490,7 +499,7 @@ __device__ __forceinline__ void tile_epilogue_ln_head(acc16_t (&acc)[BM / 64][2]
 //   * exactly nk steps run (ring trips + a statically indexed tail), so no zero-padded dummy steps.
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 
-template <typename T, typename TO, int BM, int BN, int PF, bool LNHEAD = false>
+template <typename T, typename TO, int BM, int BN, int PF, bool LNHEAD = false, int NWM = 2>
 __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ x, const T *__restrict__ w,
                                                          const float *__restrict__ bias,
                                                          const T *__restrict__ res, TO *__restrict__ y, long M,
@@ -498,17 +507,21 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
                                                          LnHead hd = LnHead{})
 {
     // x2 != nullptr: A = [x (M, K1) | x2 (M, K - K1)], both halves whole K steps (no concatenation in memory)
-    constexpr int TM = BM / 64, TN = BN / 64;
+    using WL = WaveLayout<BM, BN, NWM>;
+    constexpr int TM = WL::TM, TN = WL::TN;
+    static_assert(!LNHEAD || NWM == 2, "the fused head epilogue is written for the 2 x 2 layout");
     constexpr int A_PER_T = BM * (kBK / 8) / 256, B_PER_T = BN * (kBK / 8) / 256;
     constexpr int TILE_BYTES = (BM + BN) * kBK * 2;
     constexpr int EPI_BYTES = BM * (BN + 4) * 4;
+    static_assert((BM * (kBK / 8)) % 256 == 0 && (BN * (kBK / 8)) % 256 == 0, "whole 16-byte chunks per thread");
     constexpr int LDS_BYTES = 2 * TILE_BYTES > EPI_BYTES ? 2 * TILE_BYTES : EPI_BYTES;
     constexpr int NS = PF + 1;
     static_assert(NS % 2 == 0, "the LDS buffer parity must be a compile-time constant");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const bool compute = wave < NWM * WL::NWN;                     // (3 x 1 layout: the fourth wave only moves data)
+    const int wm = compute ? wave / WL::NWN : 0, wn = wave % WL::NWN;
     const int r32 = lane & 31, hi = lane >> 5;
     long m0;
     int n0;
@@ -549,12 +562,12 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
     unsigned ard[TM], brd[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int row = wm * (BM / 2) + i * 32 + r32;
+        const int row = wm * WL::WM + i * 32 + r32;
         ard[i] = (unsigned)(row * 128 + swz_chunk(row, hi) * 16);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int row = wn * (BN / 2) + j * 32 + r32;
+        const int row = wn * WL::WN + j * 32 + r32;
         brd[j] = (unsigned)(BM * kBK * 2 + row * 128 + swz_chunk(row, hi) * 16);
     }
 
@@ -600,6 +613,7 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
         const unsigned char *base = lds + par * TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < kBK / 16; ++kk) {
+            if (NWM != 2 && !compute) break;   // wave-uniform
             frag8_t a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const frag8_t *>(base + (ard[i] ^ (unsigned)(kk * 32)));
@@ -632,13 +646,29 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
         static_assert(BN == 128, "one tile = whole 128-channel groups");
         tile_epilogue_ln_head<T, BM>(acc, lds, hd, M, m0, n0);
     } else {
-        tile_epilogue<T, TO, BM, BN>(acc, lds, bias, res, y, M, N, act, m0, n0);
+        tile_epilogue<T, TO, BM, BN, NWM>(acc, lds, bias, res, y, M, N, act, m0, n0);
     }
 }
 
 // Tile choice: 64x64 (3 K-tiles in flight) wins on every GEMM of this model (M = 576..36864, N <= 4096,
 // K <= 4096: short-M or short-K, measured in scripts/bench_gemm.py); 128x128 only pays once both the tile
 // count and K are large.  TRAMBA_GEMM_TILE=128x128 forces it (tuning aid).
+// 96x64 tiles where 64x64 tiles land just above a whole number of rounds of the 256 CUs and 96-row tiles land at or under
+// it (M = 2304, N = 512: 288 -> 192 workgroups).  TRAMBA_GEMM_TILE=96x64 forces it for every eligible shape, =64x64 forbids.
+static bool tile96(long m, int n, int k)
+{
+    static const int mode = [] {
+        const char *e = getenv("TRAMBA_GEMM_TILE");
+        return !e ? 0 : strcmp(e, "96x64") == 0 ? 1 : strcmp(e, "64x64") == 0 ? 2 : 0;
+    }();
+    if (mode == 2 || m < 96) return false;
+    if (mode == 1) return true;
+    const long t64 = ((m + 63) / 64) * ((n + 63) / 64), t96 = ((m + 95) / 96) * ((n + 63) / 64);
+    // rounds of the chip: time ~ rounds x tile height
+    const long r64 = (t64 + 255) / 256, r96 = (t96 + 255) / 256;
+    return k >= 512 && t64 <= 1024 && r96 * 96 < r64 * 64;
+}
+
 template <typename T, typename TO, bool CONV = false>
 static void launch_tiled(const void *x, const void *w, const float *bias, const void *res, void *y, long m, int n,
                          int k, int act, hipStream_t s, ConvGeom cg = ConvGeom{0, 0, 0, 0, 0},
@@ -657,6 +687,11 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
         dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
         hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2, CONV>), grid, block, 0, s, (const T *)x,
                            (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);
+    } else if (!CONV && lean_ok && tile96(m, n, k)) {
+        // 96x64 tiles, 3 compute waves + 1 loader wave: the tile count drops under one round of the chip
+        dim3 grid((n + 63) / 64, (unsigned)((m + 95) / 96)), block(256);
+        hipLaunchKernelGGL((linear_lean_kernel<T, TO, 96, 64, 1, false, 3>), grid, block, 0, s, (const T *)x, (const T *)w,
+                           bias, (const T *)res, (TO *)y, m, n, k, act, (const T *)x2, k1);
     } else if (!CONV && lean_ok && !(k >= 1024 && tiles64 <= 320)) {
         // 2-stage ring, 82 VGPRs: 5-6 resident blocks per CU hide the shallower prefetch (measured on the model's
         // 18 shapes, scripts/bench_gemm.py: 2.45 -> 2.20 ms per forward against the generic kernel)
