@@ -222,16 +222,54 @@ def _wgrad_tall(gy2, x2):
     return torch.bmm(gy2.reshape(s, m // s, -1).transpose(1, 2), x2.reshape(s, m // s, -1)).float().sum(0)
 
 
+# Low-precision shadows of the fp32 master weights for the training forward: 250 per-layer `weight.to(bf16)` kernels per
+# step become one multi-tensor copy after the optimizer step (train.train_step -> refresh_lowp_shadows).  A shadow is used
+# only while the parameter's version counter still equals the one it was cast at; otherwise the layer casts as before.
+_lowp_shadow = {}
+
+
+@torch.no_grad()
+def refresh_lowp_shadows(model, dtype):
+    if dtype is None or dtype == torch.float32:
+        return 0
+    params = [p for m in model.modules() if isinstance(m, Linear2d) for p in (m.weight, m.bias)
+              if p is not None and p.is_cuda and p.dtype == torch.float32]
+    if not params:
+        return 0
+    dst = []
+    for p in params:
+        ent = _lowp_shadow.get(id(p))
+        if ent is None or ent[0].dtype != dtype or ent[0].shape != p.shape or ent[0].device != p.device or ent[2]() is not p:
+            import weakref
+            ent = [torch.empty_like(p, dtype=dtype), -1, weakref.ref(p)]
+            _lowp_shadow[id(p)] = ent
+        dst.append(ent[0])
+    torch._foreach_copy_(dst, params)
+    for p in params:
+        _lowp_shadow[id(p)][1] = p._version
+    return len(params)
+
+
+def _lowp(p, dtype):
+    """p cast to dtype: the shadow when it is current, a fresh cast otherwise"""
+    if p.dtype == dtype:
+        return p
+    ent = _lowp_shadow.get(id(p))
+    if ent is not None and ent[1] == p._version and ent[0].dtype == dtype and ent[2]() is p:
+        return ent[0]
+    return p.to(dtype)
+
+
 class _LinearTrainCL(torch.autograd.Function):
     """y = x @ w^T + b on channels-last activations with autograd (training path): forward and input gradient are
     library GEMMs, the weight gradient is the split-token form above, produced in fp32 (no cast kernel afterwards)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
-        wa = w if w.dtype == x.dtype else w.to(x.dtype)
+        wa = _lowp(w, x.dtype)
         ctx.save_for_backward(x, wa)
         ctx.wdtype, ctx.has_bias = w.dtype, b is not None
-        return F.linear(x, wa, None if b is None else b.to(x.dtype))
+        return F.linear(x, wa, None if b is None else _lowp(b, x.dtype))
 
     @staticmethod
     def backward(ctx, gy):

@@ -11,6 +11,8 @@ import os
 import torch
 import torch.nn.functional as F
 
+from .modules import refresh_lowp_shadows
+
 
 def iou_loss(pred, mask):
     """utils/loss.py:6-11."""
@@ -65,6 +67,7 @@ def train_step(model, opt, images, label, reducer=None):
     if reducer is not None:
         reducer.finish()
     opt.step()
+    refresh_lowp_shadows(model, getattr(model, "compute_dtype", None))   # next forward's bf16 weights: one fused cast
     return loss.detach()
 
 
