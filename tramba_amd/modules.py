@@ -236,6 +236,8 @@ def refresh_lowp_shadows(model, dtype):
               if p is not None and p.is_cuda and p.dtype == torch.float32]
     if not params:
         return 0
+    for key in [k for k, ent in _lowp_shadow.items() if ent[2]() is None]:   # parameters of models that no longer exist
+        del _lowp_shadow[key]
     dst = []
     for p in params:
         ent = _lowp_shadow.get(id(p))
