@@ -295,3 +295,27 @@ def test_tramba_v_768_fp16_long_sequence_against_oracle():
     gt = (synth.synth_input("c5_gt", (768, 768)) > 0.5).numpy()
     mae = lambda o: oo.mae_metric(torch.sigmoid(o[-1])[0, 0].float().cpu().numpy(), gt)
     assert abs(mae(got16) - mae(want)) < 5e-4
+
+
+def test_training_weight_shadows_follow_the_optimizer():
+    """train_step refreshes the bf16 shadows of the fp32 Linear2d weights with one fused cast; a shadow is used only while
+    its parameter is unchanged (version counter), so an out-of-band update falls back to a fresh cast."""
+    import tramba_amd as ta
+    from tramba_amd import modules as M, train
+    torch.manual_seed(0)
+    m = ta.bulid_model(use_pretrain=False, img_size=384).to(DEV).train()
+    m.compute_dtype = torch.bfloat16
+    opt = train.get_opt(1e-4, m)
+    x = torch.randn(1, 3, 384, 384, generator=torch.Generator().manual_seed(0)).to(DEV)
+    y = (torch.rand(1, 1, 384, 384, generator=torch.Generator().manual_seed(1)) > 0.7).float().to(DEV)
+    train.train_step(m, opt, x, y)
+    lin = next(mod for mod in m.modules() if isinstance(mod, ta.Linear2d))
+    sh = M._lowp(lin.weight, torch.bfloat16)
+    assert sh.data_ptr() == M._lowp_shadow[id(lin.weight)][0].data_ptr()           # the shadow, not a new tensor
+    assert torch.equal(sh, lin.weight.detach().to(torch.bfloat16))
+    with torch.no_grad():
+        lin.weight.mul_(0.5)                                                        # out-of-band update: version moves on
+    fresh = M._lowp(lin.weight, torch.bfloat16)
+    assert fresh.data_ptr() != sh.data_ptr() and torch.equal(fresh, lin.weight.detach().to(torch.bfloat16))
+    l2 = float(train.train_step(m, opt, x, y))                                      # and training goes on
+    assert np.isfinite(l2)

@@ -1,6 +1,7 @@
 """Epoch loop + checkpoint formats of the reference's fit() (train.py:212-263) -- CPU, tiny module."""
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -62,3 +63,18 @@ def test_fit_only_main_rank_writes(tmp_path):
     train.fit(m, opt, _data, epochs=5, base_lr=1e-2, decay_epochs=[], decay_factors=[], save_model=str(tmp_path),
               method="T", evaluate=lambda mod, e: 0.1, see=0, is_main=False)
     assert not (tmp_path / "T").exists()
+
+
+def test_token_split_weight_gradient_matches_plain_gemm():
+    """_wgrad_tall: gy^T @ x with the token dimension split into chunks of >= 2048 (fp32 partial sums) == one GEMM."""
+    from tramba_amd.modules import _wgrad_tall
+    g = torch.Generator().manual_seed(3)
+    for m, n, k in ((2048 * 8, 24, 16), (2048 * 5, 8, 12), (4096 + 2048, 16, 8), (1000, 8, 8)):
+        gy, x = torch.randn(m, n, generator=g), torch.randn(m, k, generator=g)
+        want = gy.double().t() @ x.double()
+        got = _wgrad_tall(gy, x)
+        assert got.dtype == torch.float32 and got.shape == (n, k)
+        np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=1e-4, atol=1e-3)
+        # non-contiguous operands (a transposed view) take the same path
+        got2 = _wgrad_tall(gy.t().contiguous().t(), x)
+        np.testing.assert_allclose(got2.double().numpy(), want.numpy(), rtol=1e-4, atol=1e-3)
