@@ -106,3 +106,22 @@ def metric_cases():
     flip = rs.random_sample((72, 72)) < 0.08
     cases.append(("binary_pred", np.where(flip, 1.0 - gt, gt).astype(np.float32), gt))
     return cases
+
+
+def image_pair(tag: str, w: int, h: int):
+    """A seeded RGB image (smooth colour ramps + blobs + noise) and a binary blob mask of the same size, as PIL images:
+    the input of the data-loader cases (make_golden_data.py / tests/test_data.py)."""
+    from PIL import Image
+    rs = _rs("img_" + tag)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    cy, cx, r = rs.uniform(0.3, 0.7) * h, rs.uniform(0.3, 0.7) * w, rs.uniform(0.15, 0.3) * min(h, w)
+    blob = ((yy - cy) ** 2 + (xx - cx) ** 2) < r * r
+    blob |= (np.abs(yy - 0.2 * h) < 0.06 * h) & (np.abs(xx - 0.75 * w) < 0.1 * w)
+    rgb = np.stack([xx / w, yy / h, (xx + yy) / (w + h)], -1) * 160 + blob[..., None] * 70 + rs.uniform(0, 25, (h, w, 3))
+    return (Image.fromarray(np.clip(rgb, 0, 255).astype(np.uint8), "RGB"),
+            Image.fromarray((blob * 255).astype(np.uint8), "L"))
+
+
+DATA_SIZE = 32                                              # img_size of the loader cases
+DATA_SOURCES = [(70, 60), (41, 57), (32, 32), (96, 50)]     # (W, H) of the synthetic originals, cycled
+DATA_TRAIN_SAMPLES = 12                                     # consecutive samples through ONE transform instance
