@@ -140,3 +140,13 @@ def test_image_loader_iterates_a_folder_or_a_file(tmp_path):
     assert [s["name"] for s in got] == ["x2", "x10"] and got[0]["shape"] == (20, 50)
     assert tuple(got[0]["image"].shape) == (1, 3, 32, 32) and got[0]["original"].size == (50, 20)
     assert len(D.ImageLoader(os.path.join(folder, "x2.png"), 32)) == 1
+
+
+def test_device_batches_feed_the_epoch_loop(tmp_path):
+    root = str(tmp_path)
+    _write_split(root, "Train", [f"t{i}" for i in range(6)], [(36, 36)] * 6)
+    dl = D.train_loader(root, 32, batch_size=3, num_workers=0, rank=1, world_size=2)
+    batches = D.device_batches(dl, "cpu")
+    first = [(x.shape, y.shape) for x, y in batches(0)]
+    assert first == [(torch.Size([3, 3, 32, 32]), torch.Size([3, 1, 32, 32]))]
+    assert dl.sampler.epoch == 0 and list(batches(4)) and dl.sampler.epoch == 4

@@ -238,3 +238,15 @@ def train_loader(root, img_size=384, batch_size=4, num_workers=8, rank=0, world_
 def eval_loader(root, img_size=384, num_workers=8):
     """test_TSOD.py:48-52 / train.py:114-115: Test split, batch 1, in file order."""
     return DataLoader(RGB_Dataset(root, ["Test"], img_size, "Test"), batch_size=1, shuffle=False, num_workers=num_workers)
+
+
+def device_batches(loader, device="cuda"):
+    """Adapter from a loader of sample dictionaries to the `batches(epoch)` callable `tramba_amd.train.fit` consumes:
+    (images, label) on `device` (train.py:47-50 `data_batch['image']` / `['gt']` moved with `.cuda()`), copies asynchronous from
+    the pinned batches, and the epoch handed to a distributed sampler so that every epoch reshuffles."""
+    def batches(epoch):
+        if hasattr(loader.sampler, "set_epoch"):
+            loader.sampler.set_epoch(epoch)
+        for b in loader:
+            yield b["image"].to(device, non_blocking=True), b["gt"].to(device, non_blocking=True)
+    return batches
