@@ -150,3 +150,18 @@ def test_device_batches_feed_the_epoch_loop(tmp_path):
     first = [(x.shape, y.shape) for x, y in batches(0)]
     assert first == [(torch.Size([3, 3, 32, 32]), torch.Size([3, 1, 32, 32]))]
     assert dl.sampler.epoch == 0 and list(batches(4)) and dl.sampler.epoch == 4
+
+
+def test_worker_processes_draw_distinct_streams(tmp_path):
+    """Forked workers inherit the parent's numpy state; `_seed_worker` gives each its own, so two workers do not apply
+    the same augmentation to their samples (the same image read by two workers must come back different)."""
+    root = str(tmp_path)
+    _write_split(root, "Train", ["a", "b"], [(48, 48)] * 2)
+    for n in ("a", "b"):                                             # both files hold the same picture
+        img, gt = synth.image_pair("same", 48, 48)
+        img.save(os.path.join(root, "Train", "image", n + ".png"))
+        gt.save(os.path.join(root, "Train", "mask", n + ".png"))
+    torch.manual_seed(7)
+    dl = D.train_loader(root, 32, batch_size=1, num_workers=2)
+    got = {b["name"][0]: b["image"] for b in dl}
+    assert set(got) == {"a", "b"} and not torch.equal(got["a"], got["b"])

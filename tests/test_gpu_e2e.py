@@ -1,0 +1,61 @@
+"""End to end on the GPU, the way run.py drives the reference: a dataset on disk in the reference's folder layout ->
+RGB_Dataset loader -> fit() (train_step on the HIP path, files written) -> test_one_epoch metrics -> PNG dump."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_split(root, split, names, size):
+    for sub in ("image", "mask"):
+        os.makedirs(os.path.join(root, split, sub))
+    for n in names:
+        img, gt = synth.image_pair(n, *size)
+        img.save(os.path.join(root, split, "image", n + ".png"))
+        gt.save(os.path.join(root, split, "mask", n + ".png"))
+
+
+def test_disk_dataset_to_metrics(tmp_path):
+    import tramba_amd as ta
+    from tramba_amd import data, evaluate, train
+    from PIL import Image
+    root, out = str(tmp_path / "ds"), str(tmp_path / "out")
+    _write_split(root, "Train", [f"tr{i}" for i in range(4)], (150, 120))
+    _write_split(root, "Test", [f"te{i}" for i in range(3)], (150, 120))
+    torch.manual_seed(1026)
+    np.random.seed(1026)
+    m = ta.bulid_model(use_pretrain=False, img_size=384, dims=128, depths=[2, 2, 2, 2]).cuda().train()
+    m.compute_dtype = torch.bfloat16
+    opt = train.get_opt(1e-4, m)
+    dl = data.train_loader(root, 384, batch_size=2, num_workers=0)   # no forked workers next to a live HIP context
+    test_dl = data.eval_loader(root, 384, num_workers=0)
+    seen = []
+
+    def evaluate_epoch(model, epoch):
+        r = evaluate.test_one_epoch(model, test_dl, weighted=False)
+        seen.append(r)
+        return float(r["MAE_r"])
+
+    hist = train.fit(m, opt, data.device_batches(dl), epochs=5, base_lr=1e-4, decay_epochs=[3], decay_factors=[0.1],
+                     save_model=out, method="Tramba-V-TSOD", evaluate=evaluate_epoch, see=4)
+    assert len(hist) == 5 and all(np.isfinite(h["loss"]) for h in hist)
+    assert hist[-1]["loss"] < hist[0]["loss"]                         # 10 Adam steps on 4 images do fit them a little
+    assert [h["mae"] is not None for h in hist] == [False, False, False, True, True]
+    assert hist[3]["lr"] == pytest.approx(1e-5)
+    assert all(0.0 <= r["MAE_r"] <= 1.0 and 0.0 <= r["Smeasure_r"] <= 1.0 for r in seen)
+    files = [os.path.basename(p) for p in glob.glob(os.path.join(out, "**", "*.pth"), recursive=True)]
+    assert any(f.startswith("Tramba-V-TSOD_MAE_") for f in files), files       # best-MAE checkpoint (train.py:243-250)
+    assert "Tramba-V-TSOD_resume.pth" in files, files                          # every 5th epoch (train.py:254-262)
+    written = evaluate.save_predictions(m, test_dl, os.path.join(out, "pred"))
+    assert sorted(os.path.basename(p) for p in written) == ["te0.png", "te1.png", "te2.png"]
+    with Image.open(written[0]) as im:
+        assert im.size == (150, 120) and im.mode == "L"
