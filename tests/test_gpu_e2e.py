@@ -59,3 +59,42 @@ def test_disk_dataset_to_metrics(tmp_path):
     assert sorted(os.path.basename(p) for p in written) == ["te0.png", "te1.png", "te2.png"]
     with Image.open(written[0]) as im:
         assert im.size == (150, 120) and im.mode == "L"
+
+
+def test_graphed_forward_replays_the_eager_result():
+    import tramba_amd as ta
+    torch.manual_seed(3)
+    m = ta.bulid_model(use_pretrain=False, img_size=384, dims=128, depths=[2, 2, 2, 2]).cuda()
+    m.compute_dtype = torch.bfloat16
+    with pytest.raises(RuntimeError, match="eval"):
+        ta.GraphedForward(m)                                         # still in training mode
+    m.eval()
+    gf = ta.GraphedForward(m, strict=True)
+    for batch, seed in ((1, 0), (1, 1), (2, 2), (1, 3)):             # two shapes -> two graphs, replayed alternately
+        x = torch.randn(batch, 3, 384, 384, generator=torch.Generator().manual_seed(seed)).cuda()
+        with torch.no_grad():
+            want = [o.clone() for o in m(x)]
+        got = gf(x)
+        assert len(got) == len(want) and all(torch.equal(g, w) for g, w in zip(got, want)), (batch, seed)
+    assert len(gf._graphs) == 2 and all(v is not None for v in gf._graphs.values())
+    with pytest.raises(RuntimeError, match="device tensor"):
+        gf(torch.zeros(1, 3, 384, 384))
+
+
+def test_graphed_evaluation_gives_the_eager_metrics(tmp_path):
+    import tramba_amd as ta
+    from tramba_amd import data, evaluate
+    root = str(tmp_path / "ds")
+    _write_split(root, "Test", [f"te{i}" for i in range(3)], (150, 120))
+    torch.manual_seed(5)
+    m = ta.bulid_model(use_pretrain=False, img_size=384, dims=128, depths=[2, 2, 2, 2]).cuda().eval()
+    m.compute_dtype = torch.bfloat16
+    dl = data.eval_loader(root, 384, num_workers=0)
+    eager = evaluate.test_one_epoch(m, dl, weighted=False)
+    graphed = evaluate.test_one_epoch(m, dl, weighted=False, graph=True)
+    assert eager.keys() == graphed.keys()
+    for k in eager:
+        assert np.array_equal(np.asarray(eager[k]), np.asarray(graphed[k])), k
+    a = evaluate.save_predictions(m, dl, str(tmp_path / "a"))
+    b = evaluate.save_predictions(m, dl, str(tmp_path / "b"), graph=True)
+    assert [open(p, "rb").read() for p in a] == [open(p, "rb").read() for p in b]

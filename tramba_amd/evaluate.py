@@ -235,18 +235,29 @@ class WeightedFmeasure:
 
 
 # ----------------------------------------------------------------------------- loops
-def test_one_epoch(model, batches, methods="SOD", weighted=True):
+def _forward_fn(model, graph):
+    """`model` itself, or its hipGraph replay (tramba_amd/graph.py) when `graph` is set: the weights are fixed for the
+    duration of an evaluation pass, so a fresh capture per pass is safe."""
+    if not graph:
+        return model
+    from .graph import GraphedForward
+    return GraphedForward(model)
+
+
+def test_one_epoch(model, batches, methods="SOD", weighted=True, graph=False):
     """train.py:101-152.  `batches` yields dicts with 'image' (B,3,S,S) and 'gt' (B,1,S,S) (what RGB_Dataset's
-    loader yields; the reference uses B = 1, any B works here).  Returns the reference's results dictionary."""
+    loader yields; the reference uses B = 1, any B works here).  Returns the reference's results dictionary.
+    `graph=True` replays the forward as a hipGraph (one capture per input shape, same kernels, same results)."""
     fm, wfm, sm, em, mae = Fmeasure_and_FNR(), WeightedFmeasure(), Smeasure(), Emeasure(), MAE()
     dev = next(model.parameters()).device
     was_training = model.training
     model.eval()
+    forward = _forward_fn(model, graph)
     with torch.no_grad():
         for batch in batches:
             images = batch["image"].to(dev, non_blocking=True)
             gt = batch["gt"].to(dev).reshape(images.shape[0], *batch["gt"].shape[-2:]) != 0
-            pred = torch.sigmoid(model(images)[-1].float()).reshape(gt.shape)
+            pred = torch.sigmoid(forward(images)[-1].float()).reshape(gt.shape)
             for m in (fm, sm, em, mae):
                 m.step(pred=pred, gt=gt)
             if weighted:
@@ -281,16 +292,17 @@ def write_png_gray8(path, img: np.ndarray):
                 chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
-def save_predictions(model, batches, save_path):
+def save_predictions(model, batches, save_path, graph=False):
     """test_TSOD.py:46-68: forward, bilinear resize of the full-resolution logits to the image's original size
     (`shape` = (W, H) as the loader reports it), sigmoid, *255 -> uint8, <name>.png."""
     os.makedirs(save_path, exist_ok=True)
     dev = next(model.parameters()).device
     model.eval()
+    forward = _forward_fn(model, graph)
     written = []
     with torch.no_grad():
         for batch in batches:
-            res = model(batch["image"].to(dev))[-1].float()
+            res = forward(batch["image"].to(dev))[-1].float()
             for i in range(res.shape[0]):
                 shape, name = batch["shape"], batch["name"]
                 wd, ht = (int(shape[0][i]), int(shape[1][i])) if isinstance(shape[0], (list, tuple, torch.Tensor)) \
