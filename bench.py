@@ -201,10 +201,28 @@ def bench_train(args, world, rank, dtype):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    graphed = None
+    if world == 1:      # the same step replayed as ONE hipGraph (single process: no collective inside the capture)
+        try:
+            import tramba_amd as ta
+            gstep = ta.GraphedTrainStep(model, train.get_opt(1e-4, model, capturable=True))
+            for _ in range(2):
+                gstep(x, y)
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            for _ in range(steps):
+                gstep(x, y)
+            torch.cuda.synchronize()
+            gdt = time.perf_counter() - g0
+            graphed = {"value": round(b * steps / gdt, 2), "unit": "img/s", "ms_per_step": round(gdt / steps * 1e3, 2),
+                       "what": "tramba_amd.GraphedTrainStep: forward + loss + backward + Adam + weight-shadow refresh "
+                               "as one hipGraph replay"}
+        except Exception as e:  # an optimisation, never a requirement
+            graphed = {"error": f"{type(e).__name__}: {e}"[:300]}
     return {"metric": "images/sec fwd+bwd+Adam Tramba-V 384x384", "value": round(world * b * steps / dt, 2),
             "unit": "img/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2), "batch_per_gpu": b,
             "grad_bytes_per_step": red.bytes_per_step(), "stochastic_depth": "on (0.6 enc / 0.2 dec)",
-            "dtype": args.dtype + " activations, fp32 master weights"}
+            "dtype": args.dtype + " activations, fp32 master weights", "graphed": graphed}
 
 
 def main():

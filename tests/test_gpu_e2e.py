@@ -98,3 +98,41 @@ def test_graphed_evaluation_gives_the_eager_metrics(tmp_path):
     a = evaluate.save_predictions(m, dl, str(tmp_path / "a"))
     b = evaluate.save_predictions(m, dl, str(tmp_path / "b"), graph=True)
     assert [open(p, "rb").read() for p in a] == [open(p, "rb").read() for p in b]
+
+
+def test_graphed_train_step_follows_the_eager_step():
+    """The whole optimisation step replayed as one hipGraph walks the same trajectory as eager launches (stochastic
+    depth off so that both consume no random numbers; index_add atomics and the device-side Adam step counters leave
+    rounding-level differences, which six Adam steps amplify a little)."""
+    import tramba_amd as ta
+    from tramba_amd import train
+    x = torch.randn(2, 3, 384, 384, generator=torch.Generator().manual_seed(0)).cuda()
+    y = (torch.rand(2, 1, 384, 384, generator=torch.Generator().manual_seed(1)) > 0.7).float().cuda()
+
+    def fresh(capturable):
+        torch.manual_seed(11)
+        m = ta.bulid_model(use_pretrain=False, img_size=384).cuda().train()
+        for mod in m.modules():
+            if isinstance(mod, ta.DropPath):
+                mod.drop_prob = 0.0
+        m.compute_dtype = torch.bfloat16
+        return m, train.get_opt(1e-4, m, capturable=capturable)
+
+    m, opt = fresh(False)
+    with pytest.raises(RuntimeError, match="capturable"):
+        ta.GraphedTrainStep(m, opt)
+    eager = [float(train.train_step(m, opt, x, y)) for _ in range(8)]
+    del m, opt
+    m, opt = fresh(True)
+    step = ta.GraphedTrainStep(m, opt, warmup=3)
+    probe = next(p for n, p in m.named_parameters() if n.endswith("weight") and p.ndim == 2)
+    got = [float(step(x, y))]                                        # 3 eager warm-up steps, capture, replay = step 4
+    before = probe.detach().clone()
+    got += [float(step(x, y)) for _ in range(2)]                     # replays: steps 5 and 6
+    assert not torch.equal(before, probe)                            # the replay really updates the weights
+    assert np.allclose(got, eager[3:6], rtol=3e-2), (got, eager)
+    assert got[0] > got[1] > got[2]                                  # and it is still fitting the batch
+    train.adjust_learning_rate(opt, 1, [1], 1e-4, [0.1])             # new learning rates -> a new capture
+    key = step._key
+    later = float(step(x, y))
+    assert step._key != key and np.isfinite(later)

@@ -4,7 +4,7 @@ Drop-in for the reference's module surface (get_model.build / Trambav6.bulid_mod
 Trambav6_enc.bulid_model, SS2D scan/merge plugin API, selective_scan_cuda_oflex fwd/bwd) with
 every hot op a hand-written HIP kernel behind the C ABI of include/tramba_hip.h.
 """
-from .graph import GraphedForward  # noqa: F401
+from .graph import GraphedForward, GraphedTrainStep  # noqa: F401
 from . import data, evaluate, hip  # noqa: F401  (hip: ctypes binding, loads lazily)
 from .models import (BaseUMamba, BaseUMambaEnc, VSSMDecoder, build, bulid_model, bulid_model_enc,  # noqa: F401
                      prepare_inference)

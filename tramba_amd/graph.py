@@ -58,3 +58,55 @@ class GraphedForward:
         static_in.copy_(x, non_blocking=True)
         graph.replay()
         return out
+
+
+class GraphedTrainStep:
+    """One optimisation step (tramba_amd.train.train_step: forward, loss, backward, Adam, weight-shadow refresh) captured
+    as ONE hipGraph and replayed per batch -- the eager step issues ~6000 launches from Python.
+
+    Requirements: fixed batch shape; an optimizer built with `capturable=True` (`train.get_opt(lr, model, capturable=True)`:
+    Adam's step counters live on the device); single process (`reducer` must be None or a world-size-1 reducer: the RCCL
+    all-reduce of the data-parallel path stays on eager launches).  Learning rates are baked into the captured kernels: the
+    step re-captures by itself when `adjust_learning_rate` changes them (each capture first runs `warmup` eager steps on the
+    batch at hand, so a call that captures advances the optimisation by warmup + 1 steps).  Stochastic depth draws from torch's device
+    generator, which hipGraph capture advances per replay.  Returns the loss of the replayed step (static buffer)."""
+
+    def __init__(self, model, opt, reducer=None, warmup=3):
+        if reducer is not None and getattr(reducer, "world", 1) > 1:
+            raise RuntimeError("GraphedTrainStep is single-process; use train_step with the reducer for data parallel")
+        if not all(g.get("capturable", False) for g in opt.param_groups):
+            raise RuntimeError("GraphedTrainStep needs an optimizer with capturable=True")
+        self.model, self.opt, self.reducer, self.warmup = model, opt, reducer, warmup
+        self._entry = None
+        self._key = None
+
+    def _lrs(self):
+        return tuple(float(g["lr"]) for g in self.opt.param_groups)
+
+    def _capture(self, images, label):
+        from .train import train_step
+        sx, sy = images.clone(), label.clone()
+        side = torch.cuda.Stream(device=images.device)
+        side.wait_stream(torch.cuda.current_stream(images.device))
+        with torch.cuda.stream(side):                       # optimizer state and all lazy caches exist before capture
+            for _ in range(self.warmup):
+                train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
+        torch.cuda.current_stream(images.device).wait_stream(side)
+        torch.cuda.synchronize(images.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
+        return graph, sx, sy, loss
+
+    def __call__(self, images, label):
+        key = (tuple(images.shape), images.dtype, tuple(label.shape), label.dtype, self._lrs())
+        if self._entry is None or key != self._key:
+            self._entry, self._key = None, key
+            # the warm-up passes are real optimisation steps on this batch; the capture itself executes nothing, so the
+            # first call continues into a replay like every other call
+            self._entry = self._capture(images, label)
+        graph, sx, sy, loss = self._entry
+        sx.copy_(images, non_blocking=True)
+        sy.copy_(label, non_blocking=True)
+        graph.replay()
+        return loss

@@ -175,15 +175,28 @@ def _dwconv_train_cl(x_cl, conv: nn.Conv2d):
     return _DwConvCL.apply(x_cl.contiguous(), wt, bt)
 
 
+_centre_tap_cache = {}
+
+
+def _centre_tap7(device, dtype):
+    """The identity tap of the folded 7x7 stencil: a constant built once per device (writing one element from the host is
+    a synchronous copy -- two launches per call, and not allowed while a stream is being captured into a hipGraph)."""
+    key = (device, dtype)
+    t = _centre_tap_cache.get(key)
+    if t is None:
+        host = torch.zeros(1, 1, 7, 7, dtype=dtype)
+        host[0, 0, 3, 3] = 1.0
+        t = _centre_tap_cache[key] = host.to(device)
+    return t
+
+
 def _dwms_train_cl(h, c3: nn.Conv2d, c5: nn.Conv2d, c7: nn.Conv2d):
     """h + dw3(h) + dw5(h) + dw7(h) (vmamba.py:622) as ONE 7x7 stencil: the fold is written in differentiable
     torch ops on the small weight tensors, so autograd hands each parameter its share of the stencil gradient."""
     w7 = c7.weight.float()
     c = w7.shape[0]
     wf = w7 + F.pad(c5.weight.float(), (1, 1, 1, 1)) + F.pad(c3.weight.float(), (2, 2, 2, 2))
-    ident = torch.zeros(1, 1, 7, 7, dtype=wf.dtype, device=wf.device)
-    ident[0, 0, 3, 3] = 1.0
-    wf = wf + ident
+    wf = wf + _centre_tap7(wf.device, wf.dtype)
     bt = c7.bias.float() + c5.bias.float() + c3.bias.float()
     return _DwConvCL.apply(h.contiguous(), wf.reshape(c, 49).t(), bt)
 

@@ -37,11 +37,12 @@ def tramba_loss(outputs, label, loss_weights=None):
     return total
 
 
-def get_opt(lr, model):
-    """train.py:266-280: two Adam groups, encoder parameters at lr/10."""
+def get_opt(lr, model, capturable=False):
+    """train.py:266-280: two Adam groups, encoder parameters at lr/10.  `capturable`: step counters on the device, so
+    that the whole step can be replayed as a hipGraph (tramba_amd.graph.GraphedTrainStep)."""
     base = [p for n, p in model.named_parameters() if "encoder" in n]
     other = [p for n, p in model.named_parameters() if "encoder" not in n]
-    return torch.optim.Adam([{"params": base, "lr": lr * 0.1}, {"params": other, "lr": lr}], lr)
+    return torch.optim.Adam([{"params": base, "lr": lr * 0.1}, {"params": other, "lr": lr}], lr, capturable=capturable)
 
 
 def adjust_learning_rate(optimizer, epoch, decay_epochs, base_lr, decay_factors):
