@@ -55,6 +55,11 @@ def test_disk_dataset_to_metrics(tmp_path):
     files = [os.path.basename(p) for p in glob.glob(os.path.join(out, "**", "*.pth"), recursive=True)]
     assert any(f.startswith("Tramba-V-TSOD_MAE_") for f in files), files       # best-MAE checkpoint (train.py:243-250)
     assert "Tramba-V-TSOD_resume.pth" in files, files                          # every 5th epoch (train.py:254-262)
+    # the same loop with every step replayed as a hipGraph (fresh capturable optimizer, one more epoch)
+    m.train()
+    hist2 = train.fit(m, train.get_opt(1e-5, m, capturable=True), data.device_batches(dl), epochs=1, base_lr=1e-5,
+                      decay_epochs=[], decay_factors=[], save_model=out, method="Tramba-V-TSOD", graph=True)
+    assert len(hist2) == 1 and np.isfinite(hist2[0]["loss"]) and hist2[0]["loss"] < hist[0]["loss"]
     written = evaluate.save_predictions(m, test_dl, os.path.join(out, "pred"))
     assert sorted(os.path.basename(p) for p in written) == ["te0.png", "te1.png", "te2.png"]
     with Image.open(written[0]) as im:
@@ -124,15 +129,19 @@ def test_graphed_train_step_follows_the_eager_step():
     eager = [float(train.train_step(m, opt, x, y)) for _ in range(8)]
     del m, opt
     m, opt = fresh(True)
-    step = ta.GraphedTrainStep(m, opt, warmup=3)
+    step = ta.GraphedTrainStep(m, opt)
     probe = next(p for n, p in m.named_parameters() if n.endswith("weight") and p.ndim == 2)
-    got = [float(step(x, y))]                                        # 3 eager warm-up steps, capture, replay = step 4
-    before = probe.detach().clone()
-    got += [float(step(x, y)) for _ in range(2)]                     # replays: steps 5 and 6
-    assert not torch.equal(before, probe)                            # the replay really updates the weights
-    assert np.allclose(got, eager[3:6], rtol=3e-2), (got, eager)
-    assert got[0] > got[1] > got[2]                                  # and it is still fitting the batch
+    start = probe.detach().clone()
+    got = [float(step(x, y))]                # eager warm-up steps (undone), capture, replay: exactly step 1
+    after_one = probe.detach().clone()
+    assert not torch.equal(start, after_one)
+    got += [float(step(x, y)) for _ in range(5)]
+    assert not torch.equal(after_one, probe)                         # the replay really updates the weights
+    assert np.allclose(got, eager[:6], rtol=3e-2), (got, eager)
+    assert got[0] == pytest.approx(eager[0], rel=1e-5)               # same initial weights, same batch: same first loss
+    assert got[3] > got[4] > got[5]                                  # and it is still fitting the batch
+    x1, y1 = x[:1].contiguous(), y[:1].contiguous()                  # a short last batch: its own graph, no re-capture of
+    assert np.isfinite(float(step(x1, y1))) and len(step._graphs) == 2     # the full-batch one
     train.adjust_learning_rate(opt, 1, [1], 1e-4, [0.1])             # new learning rates -> a new capture
-    key = step._key
     later = float(step(x, y))
-    assert step._key != key and np.isfinite(later)
+    assert len(step._graphs) == 1 and step._lr_key == pytest.approx((1e-6, 1e-5)) and np.isfinite(later)

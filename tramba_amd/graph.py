@@ -64,48 +64,80 @@ class GraphedTrainStep:
     """One optimisation step (tramba_amd.train.train_step: forward, loss, backward, Adam, weight-shadow refresh) captured
     as ONE hipGraph and replayed per batch -- the eager step issues ~6000 launches from Python.
 
-    Requirements: fixed batch shape; an optimizer built with `capturable=True` (`train.get_opt(lr, model, capturable=True)`:
-    Adam's step counters live on the device); single process (`reducer` must be None or a world-size-1 reducer: the RCCL
-    all-reduce of the data-parallel path stays on eager launches).  Learning rates are baked into the captured kernels: the
-    step re-captures by itself when `adjust_learning_rate` changes them (each capture first runs `warmup` eager steps on the
-    batch at hand, so a call that captures advances the optimisation by warmup + 1 steps).  Stochastic depth draws from torch's device
-    generator, which hipGraph capture advances per replay.  Returns the loss of the replayed step (static buffer)."""
+    Requirements: an optimizer built with `capturable=True` (`train.get_opt(lr, model, capturable=True)`: Adam's step
+    counters live on the device); single process (`reducer` must be None or a world-size-1 reducer: the RCCL all-reduce of
+    the data-parallel path stays on eager launches).  One graph per batch shape (a short last batch of an epoch gets its
+    own).  Learning rates are baked into the captured kernels: the graphs are dropped and re-captured when
+    `adjust_learning_rate` changes them.  A capture needs eager warm-up steps (optimizer state and lazy caches must exist
+    before the stream is captured); parameters and optimizer state are saved before and restored after them, so every call
+    -- capturing or not -- advances the optimisation by exactly one step on the batch it was given.  Stochastic depth draws
+    from torch's device generator, which hipGraph capture advances per replay.  Returns the loss (a static buffer)."""
 
-    def __init__(self, model, opt, reducer=None, warmup=3):
+    def __init__(self, model, opt, reducer=None, warmup=2):
         if reducer is not None and getattr(reducer, "world", 1) > 1:
             raise RuntimeError("GraphedTrainStep is single-process; use train_step with the reducer for data parallel")
         if not all(g.get("capturable", False) for g in opt.param_groups):
             raise RuntimeError("GraphedTrainStep needs an optimizer with capturable=True")
         self.model, self.opt, self.reducer, self.warmup = model, opt, reducer, warmup
-        self._entry = None
-        self._key = None
+        self._graphs = {}
+        self._lr_key = None
 
     def _lrs(self):
         return tuple(float(g["lr"]) for g in self.opt.param_groups)
 
+    def _snapshot(self):
+        params = [p for g in self.opt.param_groups for p in g["params"]]
+        saved = []
+        for p in params:
+            st = self.opt.state.get(p)
+            saved.append((p, p.detach().clone(),
+                          None if not st else {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}))
+        return saved, [(b, b.detach().clone()) for b in self.model.buffers()]     # buffers: BatchNorm running statistics
+
+    def _restore(self, snapshot):
+        from .modules import refresh_lowp_shadows
+        saved, buffers = snapshot
+        with torch.no_grad():
+            for b, value in buffers:
+                b.copy_(value)
+            for p, value, st in saved:
+                p.copy_(value)
+                for k, v in self.opt.state.get(p, {}).items():
+                    if torch.is_tensor(v):               # in place: the graph holds pointers to these tensors
+                        if st is not None and k in st:
+                            v.copy_(st[k])
+                        else:
+                            v.zero_()                    # state created by the warm-up: back to "never stepped"
+        refresh_lowp_shadows(self.model, getattr(self.model, "compute_dtype", None))
+
     def _capture(self, images, label):
         from .train import train_step
         sx, sy = images.clone(), label.clone()
-        side = torch.cuda.Stream(device=images.device)
-        side.wait_stream(torch.cuda.current_stream(images.device))
+        saved = self._snapshot()
+        dev = images.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                       # optimizer state and all lazy caches exist before capture
             for _ in range(self.warmup):
                 train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
-        torch.cuda.current_stream(images.device).wait_stream(side)
-        torch.cuda.synchronize(images.device)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph):                       # records, executes nothing
             loss = train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
+        self._restore(saved)
         return graph, sx, sy, loss
 
     def __call__(self, images, label):
-        key = (tuple(images.shape), images.dtype, tuple(label.shape), label.dtype, self._lrs())
-        if self._entry is None or key != self._key:
-            self._entry, self._key = None, key
-            # the warm-up passes are real optimisation steps on this batch; the capture itself executes nothing, so the
-            # first call continues into a replay like every other call
-            self._entry = self._capture(images, label)
-        graph, sx, sy, loss = self._entry
+        lrs = self._lrs()
+        if lrs != self._lr_key:
+            self._graphs.clear()
+            self._lr_key = lrs
+        key = (tuple(images.shape), images.dtype, tuple(label.shape), label.dtype)
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._graphs[key] = self._capture(images, label)
+        graph, sx, sy, loss = entry
         sx.copy_(images, non_blocking=True)
         sy.copy_(label, non_blocking=True)
         graph.replay()

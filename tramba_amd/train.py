@@ -113,16 +113,23 @@ def load_resume(resume, save_model, method, model, opt, map_location=None):
 
 
 def fit(model, opt, batches, epochs, base_lr, decay_epochs, decay_factors, save_model, method, start_epoch=0,
-        evaluate=None, see=0, best_mae=None, reducer=None, is_main=True, log=None):
+        evaluate=None, see=0, best_mae=None, reducer=None, is_main=True, log=None, graph=False):
     """Epoch loop of train.py:212-263 around `train_step`.  `batches(epoch)` yields (images, label) device tensors;
-    `evaluate(model, epoch) -> MAE` runs from epoch `see` on (train.py:237); rank 0 (`is_main`) writes the files."""
+    `evaluate(model, epoch) -> MAE` runs from epoch `see` on (train.py:237); rank 0 (`is_main`) writes the files.
+    `graph=True` (single process, optimizer from `get_opt(..., capturable=True)`): every step is a hipGraph replay
+    (tramba_amd.graph.GraphedTrainStep), re-captured by itself when the learning rate steps."""
+    step_fn = train_step
+    if graph:
+        from .graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt, reducer=reducer)
+        step_fn = lambda m_, o_, images, label, reducer=None: graphed(images, label)  # noqa: E731
     history = []
     for epoch in range(start_epoch, epochs):
         lr = adjust_learning_rate(opt, epoch, decay_epochs, base_lr, decay_factors)
         total, n = None, 0
         for images, label in batches(epoch):
-            loss = train_step(model, opt, images, label, reducer=reducer)
-            total = loss if total is None else total + loss
+            loss = step_fn(model, opt, images, label, reducer=reducer)
+            total = loss.clone() if total is None else total + loss     # clone: a graphed step reuses its loss buffer
             n += 1
         mean_loss = float(total / max(n, 1)) if total is not None else float("nan")   # one host sync per epoch
         mae = None
