@@ -101,3 +101,24 @@ def test_get_model_build_surface():
     with pytest.raises(NotImplementedError):
         ta.build("BaseUMamba-SOD", args)
     assert ta.build("no-such-model", args) is None
+
+
+def test_graph_wrappers_validate_before_touching_the_device():
+    """tramba_amd/graph.py: wrong mode / optimizer / tensor placement are host-side errors, not capture failures."""
+    import tramba_amd as ta
+    net = torch.nn.Linear(4, 2)
+    with pytest.raises(RuntimeError, match="eval"):
+        ta.GraphedForward(net)                                          # training mode
+    fwd = ta.GraphedForward(net.eval())
+    with pytest.raises(RuntimeError, match="device tensor"):
+        fwd(torch.zeros(1, 4))                                          # no CPU path
+    net.train()
+    with pytest.raises(RuntimeError, match="training mode"):
+        fwd(torch.zeros(1, 4))
+    with pytest.raises(RuntimeError, match="capturable"):
+        ta.GraphedTrainStep(net, torch.optim.Adam(net.parameters(), 1e-3))
+
+    class TwoRanks:
+        world = 2
+    with pytest.raises(RuntimeError, match="single-process"):
+        ta.GraphedTrainStep(net, torch.optim.Adam(net.parameters(), 1e-3, capturable=True), reducer=TwoRanks())
