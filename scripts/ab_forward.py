@@ -2,7 +2,7 @@
 Box-to-box and run-to-run spread is ~2 %, larger than most single optimisations, so both variants are captured as
 hipGraphs in ONE process and replayed alternately.
 
-    python scripts/ab_forward.py tramba_amd.models.FUSED_FINAL_STAGE
+    python scripts/ab_forward.py tramba_amd.models.OVERLAP_BRANCHES
 """
 import importlib
 import os

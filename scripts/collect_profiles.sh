@@ -8,9 +8,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py --steps 30 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --train > $OUT/bench_train.json 2>> $OUT/bench.err
-export TRAMBA_OVERLAP=0   # single stream: per-kernel durations of kernels running alone
+# (bench.py --no-overlap: one stream, per-kernel durations of kernels running alone)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline > $OUT/trace.log 2>&1
-unset TRAMBA_OVERLAP
+
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 scripts/pmc_scan.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 scripts/pmc_scan.py > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python3 scripts/profile_train.py > $OUT/trace_train.log 2>&1

@@ -145,3 +145,40 @@ def test_graphed_train_step_follows_the_eager_step():
     train.adjust_learning_rate(opt, 1, [1], 1e-4, [0.1])             # new learning rates -> a new capture
     later = float(step(x, y))
     assert len(step._graphs) == 1 and step._lr_key == pytest.approx((1e-6, 1e-5)) and np.isfinite(later)
+
+
+def test_inference_after_graphed_steps_sees_the_current_weights():
+    """A hipGraph replay rewrites the weights in place; the inference path keeps derived copies of them (packed stencils,
+    -exp(A_logs), fp32 views, head biases, bf16 shadows) keyed on the parameters' version counters.  Two rounds of
+    [graphed steps -> evaluation] must evaluate the CURRENT weights: compare with a fresh model loaded from the
+    state_dict (the first evaluation used to freeze those caches)."""
+    import tramba_amd as ta
+    from tramba_amd import train
+    x = torch.randn(2, 3, 384, 384, generator=torch.Generator().manual_seed(0)).cuda()
+    y = (torch.rand(2, 1, 384, 384, generator=torch.Generator().manual_seed(1)) > 0.7).float().cuda()
+    xe = torch.randn(1, 3, 384, 384, generator=torch.Generator().manual_seed(2)).cuda()
+    torch.manual_seed(7)
+    m = ta.bulid_model(use_pretrain=False, img_size=384).cuda().train()
+    m.compute_dtype = torch.bfloat16
+    step = ta.GraphedTrainStep(m, train.get_opt(1e-3, m, capturable=True))
+    with pytest.raises(RuntimeError, match="eval mode"):
+        m.eval()
+        step(x, y)
+    m.train()
+    outs = []
+    for _ in range(2):
+        for _ in range(2):
+            step(x, y)
+        m.eval()
+        with torch.no_grad():
+            outs.append([o.clone() for o in m(xe)])
+        m.train()
+    assert not torch.equal(outs[0][-1], outs[1][-1])                 # two more steps at lr 1e-3 do move the prediction
+    fresh = ta.bulid_model(use_pretrain=False, img_size=384).cuda()
+    fresh.load_state_dict(m.state_dict())
+    fresh.compute_dtype = torch.bfloat16
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh(xe)
+    for g, w in zip(outs[1], want):
+        assert torch.equal(g, w)

@@ -46,27 +46,47 @@ def _data(n):
     return x, m
 
 
-def _worker(rank, world, port, out_dir, steps, bucket_mb):
+class _WrapSpare(_Wrap):
+    """the same net plus a head that only rank 0 uses (`use_spare`), and one nobody uses"""
+
+    def __init__(self):
+        super().__init__()
+        self.spare = nn.Conv2d(1, 1, 1)
+        self.never = nn.Conv2d(1, 1, 1)
+        self.use_spare = False
+
+    def forward(self, x):
+        outs = super().forward(x)
+        if self.use_spare:
+            outs[1] = outs[1] + 0.5 * self.spare(outs[1])
+        return outs
+
+
+def _worker(rank, world, port, out_dir, steps, bucket_mb, bucket_dtype=None, spare=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tramba_amd import parallel, train
-    model = _Wrap()
+    model = _WrapSpare() if spare else _Wrap()
+    if spare:
+        model.use_spare = rank == 0
     if rank != 0:  # replicas must not depend on identical local seeds
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(1.0)
     parallel.broadcast_parameters(model, src=0)
-    red = parallel.GradBucketReducer(model, bucket_mb=bucket_mb)
+    red = parallel.GradBucketReducer(model, bucket_mb=bucket_mb, bucket_dtype=bucket_dtype, find_unused=spare)
     opt = train.get_opt(1e-2, model)
     x, m = _data(4 * world)
     xs, ms = x[rank::world], m[rank::world]
     losses = []
     for _ in range(steps):
         losses.append(float(train.train_step(model, opt, xs, ms, reducer=red)))
-    if rank == 0:
-        torch.save({"sd": model.state_dict(), "losses": losses, "nbuckets": len(red.buckets),
-                    "bytes": red.bytes_per_step()}, os.path.join(out_dir, "r0.pt"))
+    extra = {}
+    if spare:   # `spare` got a gradient on rank 0 only: every rank holds the mean; `never` stayed None everywhere
+        extra = {"spare_grad": model.spare.weight.grad.clone(), "never_is_none": model.never.weight.grad is None}
+    torch.save({"sd": model.state_dict(), "losses": losses, "nbuckets": len(red.buckets),
+                "bytes": red.bytes_per_step(), **extra}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,6 +112,63 @@ def test_dp2_matches_single_process(tmp_path, bucket_mb):
     for k, v in model.state_dict().items():
         np.testing.assert_allclose(got["sd"][k].numpy(), v.numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
     assert got["bytes"] == sum(p.numel() * 4 for p in model.parameters())
+
+
+def test_dp2_bf16_buckets_follow_the_fp32_run(tmp_path):
+    """bucket_dtype=bf16: half the bytes on the links, gradients rounded once -- the trajectory stays close"""
+    steps, world = 3, 2
+    os.makedirs(tmp_path / "a")
+    os.makedirs(tmp_path / "b")
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path / "a"), steps, 32.0), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path / "b"), steps, 32.0, torch.bfloat16), nprocs=world, join=True)
+    a, b = torch.load(tmp_path / "a" / "r0.pt"), torch.load(tmp_path / "b" / "r0.pt")
+    assert b["bytes"] * 2 == a["bytes"]
+    np.testing.assert_allclose(b["losses"], a["losses"], rtol=2e-2)
+    for k, v in a["sd"].items():
+        np.testing.assert_allclose(b["sd"][k].numpy(), v.numpy(), rtol=0.1, atol=2e-2, err_msg=k)
+
+
+def test_dp2_parameter_unused_on_one_rank_or_on_all(tmp_path):
+    """find_unused=True: a head used by rank 0 only receives the mean (half of rank 0's gradient) on both ranks and the
+    replicas stay identical; a head no rank used keeps .grad = None, so Adam never touches it."""
+    steps, world = 2, 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), steps, 32.0, None, True), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert r0["never_is_none"] and r1["never_is_none"]
+    assert torch.equal(r0["spare_grad"], r1["spare_grad"]) and float(r0["spare_grad"].abs().sum()) > 0
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    fresh = _WrapSpare()
+    assert torch.equal(r0["sd"]["never.weight"], fresh.state_dict()["never.weight"])
+    assert not torch.equal(r0["sd"]["spare.weight"], fresh.state_dict()["spare.weight"])
+
+
+def test_reducer_single_process_semantics():
+    """world size 1: an unused parameter keeps .grad = None (Adam skips it, like the reference's plain loop); freezing
+    the encoder rebuilds the buckets at the next step; remove_hooks() detaches the reducer from the model."""
+    from tramba_amd import parallel, train
+    model = _WrapSpare()
+    red = parallel.GradBucketReducer(model, bucket_mb=0.0005)
+    opt = train.get_opt(1e-2, model)
+    x, m = _data(4)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    train.train_step(model, opt, x, m, reducer=red)
+    assert model.spare.weight.grad is None and model.never.bias.grad is None
+    assert torch.equal(model.spare.weight, before["spare.weight"])
+    assert not torch.equal(model.decoder.weight, before["decoder.weight"])
+    nb = len(red.buckets)
+    for p in model.encoder.parameters():
+        p.requires_grad = False
+    frozen = {k: v.clone() for k, v in model.encoder.state_dict().items()}
+    train.train_step(model, opt, x, m, reducer=red)
+    train.train_step(model, opt, x, m, reducer=red)
+    assert len(red.buckets) < nb and all(p.grad is None for p in model.encoder.parameters())
+    for k, v in model.encoder.state_dict().items():
+        assert torch.equal(v, frozen[k]), k                         # no stale momentum keeps moving frozen weights
+    red.remove_hooks()
+    opt.zero_grad(set_to_none=True)
+    train.tramba_loss(model(x), m).backward()                       # a plain step: the reducer no longer sees it
+    assert model.decoder.weight.grad is not None and not red._armed
 
 
 def test_loss_matches_oracle_and_reference_known_answer(golden_meta):

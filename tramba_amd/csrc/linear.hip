@@ -657,12 +657,7 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
 // it (M = 2304, N = 512: 288 -> 192 workgroups).  TRAMBA_GEMM_TILE=96x64 forces it for every eligible shape, =64x64 forbids.
 static bool tile96(long m, int n, int k)
 {
-    static const int mode = [] {
-        const char *e = getenv("TRAMBA_GEMM_TILE");
-        return !e ? 0 : strcmp(e, "96x64") == 0 ? 1 : strcmp(e, "64x64") == 0 ? 2 : 0;
-    }();
-    if (mode == 2 || m < 96) return false;
-    if (mode == 1) return true;
+    if (m < 96) return false;
     const long t64 = ((m + 63) / 64) * ((n + 63) / 64), t96 = ((m + 95) / 96) * ((n + 63) / 64);
     // rounds of the chip: time ~ rounds x tile height
     const long r64 = (t64 + 255) / 256, r96 = (t96 + 255) / 256;
@@ -674,16 +669,11 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
                          int k, int act, hipStream_t s, ConvGeom cg = ConvGeom{0, 0, 0, 0, 0},
                          const void *x2 = nullptr, int k1 = 0)
 {
-    static const bool force_big = [] {
-        const char *e = getenv("TRAMBA_GEMM_TILE");
-        return e && strcmp(e, "128x128") == 0;
-    }();
     const long big = ((m + 127) / 128) * ((n + 127) / 128);
     // lean kernel: whole 64-deep K steps, and a 64-row operand panel within 32-bit byte offsets
-    static const bool no_lean = getenv("TRAMBA_GEMM_LEAN") && strcmp(getenv("TRAMBA_GEMM_LEAN"), "0") == 0;
-    const bool lean_ok = !no_lean && k % 64 == 0 && (double)k * 2.0 * 128.0 < 2147483648.0;
+    const bool lean_ok = k % 64 == 0 && (double)k * 2.0 * 128.0 < 2147483648.0;
     const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
-    if (!x2 && (force_big || (big >= 2048 && k >= 1024))) {
+    if (!x2 && big >= 2048 && k >= 1024) {
         dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
         hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2, CONV>), grid, block, 0, s, (const T *)x,
                            (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);

@@ -795,8 +795,7 @@ static int launch_dw(const void *x, const float *wt, const float *bt, void *y, i
     hipLaunchKernelGGL((dwconv_cl_kernel<T, KS, V_, TW>), grid, block, 0, s, (const T *)x, wt, bt, (T *)y, B, H, W, \
                        C, act, nthreads)
     // buffer-addressed kernel: 4 channels per lane, every wave inside one image, 32-bit byte offsets
-    static const bool legacy = getenv("TRAMBA_DWCONV") && strcmp(getenv("TRAMBA_DWCONV"), "legacy") == 0;
-    if (!legacy && v == 4 && H <= 65535 && B <= 65535 && (double)H * W * C * sizeof(T) < 2147483648.0) {
+    if (v == 4 && H <= 65535 && B <= 65535 && (double)H * W * C * sizeof(T) < 2147483648.0) {
         dim3 g3((unsigned)(((long)(C / 4) * wtiles + 255) / 256), (unsigned)H, (unsigned)B);
         hipLaunchKernelGGL((dwconv4_cl_kernel<T, KS, TW>), g3, block, 0, s, (const T *)x, wt, bt, (T *)y, B, H, W, C, act);
         TRAMBA_LAUNCH_CHECK();
@@ -853,8 +852,8 @@ extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const floa
     const long rpw = ln_bwd_rows_per_wave(rows);
     const long waves = (rows + rpw - 1) / rpw;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    // short rows: several rows per wave, 16-byte accesses (TRAMBA_LN_BWD=wave keeps the one-row-per-wave kernel)
-    static const bool rows_form = !(getenv("TRAMBA_LN_BWD") && strcmp(getenv("TRAMBA_LN_BWD"), "wave") == 0);
+    // short rows: several rows per wave, 16-byte accesses; longer rows: one row per wave
+    const bool rows_form = true;
     const int vm = dtype == TRAMBA_F32 ? 4 : 8;
     if (rows_form && c % vm == 0 && c <= kWave * vm) {
         int lpr = 1;

@@ -1068,56 +1068,125 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_stream_kernel(
     }
 }
 
-// ss2d_merge_norm_cl, one-wave-per-pixel form (small maps, wide rows, many-to-one Helix tables).
-// NIT = wave iterations per row (D <= 64*V*NIT); BATCH rows of ys are requested back to back
-// before any is consumed, so a pixel pays ~1 memory latency instead of one per direction.
-template <typename TY, typename T, int V, int NIT>
-__global__ __launch_bounds__(256) void ss2d_merge_norm_cl_kernel(
-    const TY *__restrict__ ys, const int32_t *__restrict__ inv_ptr, const int32_t *__restrict__ inv_idx,
-    const float *__restrict__ ln_w, const float *__restrict__ ln_b, T *__restrict__ y, long npix, int L,
-    int D, int K, float eps, int act)
+// ss2d_merge_norm_cl, one-wave-per-pixel form (many-to-one Helix tables, small maps, merge-only calls).
+// A Helix pixel lists 6 .. 4 + 2H entries (196 at 96x96: the Bresenham lines all cross the image centre), so the
+// kernel is built around the long pixels instead of suffering them:
+//  * the entry list of a pixel is fetched 64 entries per load (one per lane), not 4;
+//  * a short pixel (<= RB rows) requests all its rows at once -- one memory latency; a long one walks its rows RB at a
+//    time on two static register buffers, branch-free (rows past the end are clamped re-reads weighted 0), so 2*RB row
+//    requests stay in flight per wave;
+//  * on a square map the waves take the image rows centre-out (all images' centre rows first): the few hundred long
+//    pixels start at t = 0 and finish under the cover of the short ones instead of forming the kernel's tail
+//    (r01: 97 us for 302 MB, of which ~70 us was one wave summing 196 rows four at a time).
+// Rows are kept as raw bits until they are summed (a conversion at the load site makes hipcc wait for the load there);
+// the summation order is the CSR order, fixed.
+template <typename TY, int V>
+__device__ __forceinline__ Pack<TY, V> buf_load_pack(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-    constexpr int BATCH = NIT == 1 ? 4 : (NIT == 2 ? 4 : (NIT == 4 ? 2 : 1));
+    constexpr int kB = (int)sizeof(TY) * V;
+    static_assert(kB == 16 || kB == 8 || kB == 4 || kB == 2, "row piece of 2..16 bytes");
+    if constexpr (kB == 16) return __builtin_bit_cast(Pack<TY, V>, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    else if constexpr (kB == 8) return __builtin_bit_cast(Pack<TY, V>, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    else if constexpr (kB == 4) return __builtin_bit_cast(Pack<TY, V>, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    else return __builtin_bit_cast(Pack<TY, V>, __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0));
+}
+
+template <typename TY, typename T, int V, int NIT>
+__global__ __launch_bounds__(256) void ss2d_merge_norm_deep_kernel(
+    const TY *__restrict__ ys, const int32_t *__restrict__ inv_ptr, const int32_t *__restrict__ inv_idx,
+    const float *__restrict__ ln_w, const float *__restrict__ ln_b, T *__restrict__ y, long npix, int B, int L,
+    int D, int K, int H, float eps, int act)
+{
+    // rows per batch: 64 bytes per lane and buffer (2 buffers in flight = 8 KB per wave)
+    constexpr int RB = 64 / (NIT * V * (int)sizeof(TY)) > 0 ? 64 / (NIT * V * (int)sizeof(TY)) : 1;
     const int lane = threadIdx.x & (kWave - 1);
-    const long pix = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (pix >= npix) return;
-    const int b = (int)((unsigned)pix / (unsigned)L), p = (int)((unsigned)pix % (unsigned)L);   // npix < 2^31
+    const long wid = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wid >= npix) return;   // wave-uniform, no barriers below
+    int b, p;
+    if (H > 0) {   // square map: image rows centre-out, every image's row of one rank side by side (npix < 2^31)
+        const unsigned Wd = (unsigned)L / (unsigned)H, per = (unsigned)B * Wd;
+        const unsigned rank = (unsigned)wid / per, rem = (unsigned)wid % per;
+        b = (int)(rem / Wd);
+        const int row = H / 2 + ((rank & 1u) ? -(int)((rank + 1) >> 1) : (int)(rank >> 1));
+        p = row * (int)Wd + (int)(rem % Wd);
+    } else {
+        b = (int)((unsigned)wid / (unsigned)L);
+        p = (int)((unsigned)wid % (unsigned)L);
+    }
+    const int e0 = __builtin_amdgcn_readfirstlane(inv_ptr[p]), e1 = __builtin_amdgcn_readfirstlane(inv_ptr[p + 1]);
+    const int n = e1 - e0;
+
+    const unsigned srow = (unsigned)D * (unsigned)sizeof(TY);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(ys + (long)b * K * L * D, (unsigned)K * (unsigned)L * srow);
+    unsigned coff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c0 = (it * kWave + lane) * V;
+        coff[it] = c0 + V <= D ? (unsigned)c0 * (unsigned)sizeof(TY) : kOutOfRange;   // past D: reads as zero
+    }
     float acc[kNormMaxIt][V];
 #pragma unroll
     for (int it = 0; it < kNormMaxIt; ++it)
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[it][v] = 0.f;
 
-    const TY *yb = ys + (long)b * K * L * D;
-    const int e0 = inv_ptr[p], e1 = inv_ptr[p + 1];
-    for (int e = e0; e < e1; e += BATCH) {
-        const int mine = (lane < BATCH && e + lane < e1) ? inv_idx[e + lane] : 0;
-        float t[BATCH][NIT][V];
+    typedef Pack<TY, V> Raw;
+    for (int base = 0; base < n; base += kWave) {   // one trip except for the few pixels with > 64 entries
+        const int cn = n - base < kWave ? n - base : kWave;
+        const int ent = inv_idx[e0 + base + (lane < cn ? lane : cn - 1)];   // entry = k*L + l: row of ys
+        auto row_off = [&](int j) -> unsigned {   // j wave-uniform, < cn
+            return (unsigned)__builtin_amdgcn_readlane(ent, j) * srow;
+        };
+        if (cn <= RB) {
+            // short pixel: every row requested before any is summed (wave-uniform guards, no wasted requests)
+            Raw t[RB][NIT];
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            if (e + j < e1) {  // wave-uniform
-                const TY *row = yb + (long)__builtin_amdgcn_readlane(mine, j) * D;  // entry = k*L + l
+            for (int j = 0; j < RB; ++j)
+                if (j < cn) {
+                    const unsigned so = row_off(j);
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int c0 = (it * kWave + lane) * V;
-                    if (c0 + V <= D) {
-                        load_pack<TY, V>(row + c0, t[j][it]);
-                    } else {
-#pragma unroll
-                        for (int v = 0; v < V; ++v) t[j][it][v] = 0.f;
-                    }
+                    for (int it = 0; it < NIT; ++it) t[j][it] = buf_load_pack<TY, V>(rs, coff[it], so);
                 }
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                if (j < cn)
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                        for (int v = 0; v < V; ++v) acc[it][v] += Cvt<TY>::to_f(t[j][it].v[v]);
+        } else {
+            // long pixel: batches of RB rows on two static buffers, branch-free
+            const int nb = (cn + RB - 1) / RB;
+            auto issue = [&](int q, Raw (&t)[RB][NIT]) {
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const int r = q * RB + j;
+                    const unsigned so = row_off(r < cn ? r : cn - 1);
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) t[j][it] = buf_load_pack<TY, V>(rs, coff[it], so);
+                }
+            };
+            auto consume = [&](int q, const Raw (&t)[RB][NIT]) {
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const float wr = q * RB + j < cn ? 1.f : 0.f;   // scalar
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                        for (int v = 0; v < V; ++v) acc[it][v] = fmaf(Cvt<TY>::to_f(t[j][it].v[v]), wr, acc[it][v]);
+                }
+            };
+            Raw t0[RB][NIT], t1[RB][NIT];
+            issue(0, t0);
+            for (int q = 0; q < nb; q += 2) {
+                issue(q + 1, t1);
+                consume(q, t0);
+                issue(q + 2, t0);
+                consume(q + 1, t1);
             }
         }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j)
-            if (e + j < e1)
-#pragma unroll
-                for (int it = 0; it < NIT; ++it)
-#pragma unroll
-                    for (int v = 0; v < V; ++v) acc[it][v] += t[j][it][v];
     }
-    T *orow = y + pix * D;
+    T *orow = y + ((long)b * L + p) * D;
     if (eps < 0.f) {   // merge only (CrossMerge without out_norm: the training path and gradient merges)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -1302,14 +1371,9 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     // Form selection (measured, scripts/bench_scan.py): the kernels are VALU-throughput bound once the chip
     // is full, so the segment form (1.6x the arithmetic) only wins where the chained form leaves CUs idle:
     // a single-segment sequence (no recompute at all, no barriers), or <= 128 sequences of >= 64 tiles.
-    // TRAMBA_SCAN_FORM=segment|chain overrides (tuning / tests).
-    static const int forced = [] {
-        const char *e = getenv("TRAMBA_SCAN_FORM");
-        return !e ? 0 : (strcmp(e, "segment") == 0 ? 1 : (strcmp(e, "chain") == 0 ? 2 : 0));
-    }();
+    // (A caller that passes no workspace gets the chained form.)
     const bool seg_wins = p.nseg == 1 || ((long)batch * k * ct <= 128 && p.ntiles >= 64);
-    const bool use_seg = workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) &&
-                         (forced == 1 || (forced == 0 && seg_wins));
+    const bool use_seg = workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) && seg_wins;
     if (use_seg) {
         // ---- wave-segment form: pass 0 -> pass 1 (single pass when one segment suffices)
         TRAMBA_CHECK(aligned16(workspace), "ss2d_scan_cl: workspace must be 16-byte aligned");
@@ -1340,8 +1404,6 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     int W = kMaxW;
     while (W > 1 && (long)batch * k * ct * W > 2048) W >>= 1;
     if (W > (l + kTP - 1) / kTP) W = (l + kTP - 1) / kTP;
-    static const int forced_w = [] { const char *e = getenv("TRAMBA_SCAN_W"); return e ? atoi(e) : 0; }();
-    if (forced_w > 0 && forced_w < W) W = forced_w;
     dim3 grid(ct, k, batch), block(W * kWave);
 #define GO_(T, TY, NK_, SP_)                                                                               \
     hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK_, SP_>), grid, block, 0, s, (const T *)x, xdbl, table, \
@@ -1432,19 +1494,50 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
     const long nwaves = (long)batch * nchunk;
     // split-row form: a wide row (>= 4 wave iterations) on a map too small to fill the chip one wave per pixel
     const bool split_form = !sum_only && !stream_form && nit >= 4 && npix <= 16384;
-    dim3 grid(stream_form ? (unsigned)((nwaves + 3) / 4) : (split_form ? (unsigned)npix : (unsigned)((npix + 3) / 4))),
-        block(256);
+    if (!stream_form && !split_form) {
+        // one wave per pixel, deep row pipeline (Helix tables, small maps, merge-only): widest access that keeps 64 lanes
+        // busy, 16 bytes at most
+        const int vd = norm_vec(d, ys_dtype == TRAMBA_F32 ? 4 : 8);
+        const int nd_need = (d + kWave * vd - 1) / (kWave * vd);
+        TRAMBA_CHECK(nd_need <= kNormMaxIt, "ss2d_merge_norm_cl: D=%d too large", d);
+        TRAMBA_CHECK((double)k * l * d * 4.0 < 4294967296.0, "ss2d_merge_norm_cl: K*L*D too large for 32-bit offsets");
+        const int nd = nd_need <= 1 ? 1 : (nd_need <= 2 ? 2 : (nd_need <= 4 ? 4 : 8));
+        int hh = 1;
+        while ((long)hh * hh < l) ++hh;
+        if ((long)hh * hh != l) hh = 0;   // not a square map: plain pixel order
+        dim3 gridd((unsigned)((npix + 3) / 4)), blockd(256);
+#define DEEP_(TY, T, V_, N_)                                                                                      \
+    hipLaunchKernelGGL((ss2d_merge_norm_deep_kernel<TY, T, V_, N_>), gridd, blockd, 0, s, (const TY *)ys, inv_ptr, \
+                       inv_idx, ln_w, ln_b, (T *)y, npix, batch, l, d, k, hh, eps, act)
+#define DEEP_N_(TY, T, V_)                    \
+    if (nd == 1) { DEEP_(TY, T, V_, 1); }     \
+    else if (nd == 2) { DEEP_(TY, T, V_, 2); } \
+    else if (nd == 4) { DEEP_(TY, T, V_, 4); } \
+    else { DEEP_(TY, T, V_, 8); }
+#define DEEP_V_(TY, T)                                                  \
+    if (vd == 8) {                                                      \
+        if constexpr (sizeof(TY) == 2) { DEEP_N_(TY, T, 8) }            \
+    } else if (vd == 4) { DEEP_N_(TY, T, 4) }                           \
+    else if (vd == 2) { DEEP_N_(TY, T, 2) }                             \
+    else { DEEP_N_(TY, T, 1) }
+        TRAMBA_DISPATCH_DTYPE(dtype, T, {
+            if (ys_dtype == TRAMBA_F32) { DEEP_V_(float, T) } else { DEEP_V_(T, T) }
+        });
+#undef DEEP_V_
+#undef DEEP_N_
+#undef DEEP_
+        TRAMBA_LAUNCH_CHECK();
+        return TRAMBA_OK;
+    }
+    dim3 grid(stream_form ? (unsigned)((nwaves + 3) / 4) : (unsigned)npix), block(256);
 #define GO_(TY, T, V_, N_)                                                                                    \
     if (split_form)                                                                                           \
         hipLaunchKernelGGL((ss2d_merge_norm_split_kernel<TY, T, V_, (N_ >= 4 ? N_ : 4), 4>), grid, block, 0, s, \
                            (const TY *)ys, inv_ptr, inv_idx, ln_w, ln_b, (T *)y, npix, l, d, k, eps, act);    \
-    else if (stream_form)                                                                                          \
+    else                                                                                                      \
         hipLaunchKernelGGL((ss2d_merge_norm_stream_kernel<TY, T, V_, (N_ <= 2 ? N_ : 2), 4>), grid, block, 0, s, \
                            (const TY *)ys, inv_ptr, inv_idx, ln_w, ln_b, (T *)y, nwaves, nchunk, pw, l, d, k, eps, \
-                           act);                                                                              \
-    else                                                                                                      \
-        hipLaunchKernelGGL((ss2d_merge_norm_cl_kernel<TY, T, V_, N_>), grid, block, 0, s, (const TY *)ys, inv_ptr, \
-                           inv_idx, ln_w, ln_b, (T *)y, npix, l, d, k, eps, act)
+                           act)
 #define BY_N_(TY, T, V_)               \
     if (nit == 1) { GO_(TY, T, V_, 1); }   \
     else if (nit == 2) { GO_(TY, T, V_, 2); } \

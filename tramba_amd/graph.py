@@ -110,11 +110,27 @@ class GraphedTrainStep:
                             v.zero_()                    # state created by the warm-up: back to "never stepped"
         refresh_lowp_shadows(self.model, getattr(self.model, "compute_dtype", None))
 
+    def _touched(self):
+        """Every tensor a replay rewrites in place behind autograd's back: parameters, optimizer state, buffers."""
+        ts = [p for g in self.opt.param_groups for p in g["params"]]
+        ts += [v for p in list(ts) for v in self.opt.state.get(p, {}).values() if torch.is_tensor(v)]
+        ts += list(self.model.buffers())
+        return ts
+
+    def _mark_modified(self):
+        """A graph replay updates the weights without bumping their version counters, and every derived-weight cache of
+        the inference path (packed stencils, -exp(A_logs), fp32 views, head biases, the low-precision shadows) is keyed
+        on those counters: bump them, then re-stamp the shadows the replay has just refreshed as current."""
+        from .modules import restamp_lowp_shadows
+        torch.autograd.graph.increment_version(self._touched())
+        restamp_lowp_shadows(self.model)
+
     def _capture(self, images, label):
         from .train import train_step
         sx, sy = images.clone(), label.clone()
         saved = self._snapshot()
         dev = images.device
+        rng = torch.cuda.get_rng_state(dev)                 # the warm-up steps draw stochastic-depth masks: undone below
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                       # optimizer state and all lazy caches exist before capture
@@ -126,9 +142,13 @@ class GraphedTrainStep:
         with torch.cuda.graph(graph):                       # records, executes nothing
             loss = train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
         self._restore(saved)
+        torch.cuda.set_rng_state(rng, dev)
         return graph, sx, sy, loss
 
     def __call__(self, images, label):
+        if not self.model.training:
+            raise RuntimeError("GraphedTrainStep: the model is in eval mode (an evaluation callback must switch it back "
+                               "with model.train() before the next step)")
         lrs = self._lrs()
         if lrs != self._lr_key:
             self._graphs.clear()
@@ -141,4 +161,5 @@ class GraphedTrainStep:
         sx.copy_(images, non_blocking=True)
         sy.copy_(label, non_blocking=True)
         graph.replay()
+        self._mark_modified()
         return loss

@@ -5,7 +5,6 @@
 "encoder"), 679 state_dict entries for Tramba-V so ``load_state_dict(strict=True)`` of a reference
 checkpoint works (test_TSOD.py:36-38).
 """
-import os
 from collections import OrderedDict
 
 import torch
@@ -18,10 +17,9 @@ from .modules import (FinalPatchExpand_X4, FreqBlockv6, LayerNorm2d, Linear2d, M
 from .ops import CrossMerge_Line, CrossScan_Line
 
 
-# Independent branches of the inference graph on separate HIP streams (TRAMBA_OVERLAP=0 disables).
-OVERLAP_BRANCHES = os.environ.get("TRAMBA_OVERLAP", "1") != "0"
-# Last decoder stage (expand GEMM + pixel shuffle + LayerNorm + head) as ONE kernel (TRAMBA_FUSED_FINAL=0 disables).
-FUSED_FINAL_STAGE = os.environ.get("TRAMBA_FUSED_FINAL", "1") != "0"
+# Independent branches of the inference graph run on separate HIP streams; profiling passes that want every kernel timed
+# alone set this False (a scheduling choice: the kernels are the same either way).
+OVERLAP_BRANCHES = True
 _side_streams = {}
 
 
@@ -101,7 +99,7 @@ class VSSMDecoder(nn.Module):
         fin, conv = self.expand_layers[-1], self.seg_layers[-1]
         if _infer(x_low, conv.weight) and isinstance(self.stage_layers[-1], nn.Identity) and fin.output_dim % 8 == 0:
             if (x_low.dtype != torch.float32 and fin.output_dim == 128 and x_low.shape[-1] % 64 == 0
-                    and fin.expand.bias is None and FUSED_FINAL_STAGE):
+                    and fin.expand.bias is None):
                 y = hip.expand_norm_head_cl(x_low, fin.expand.weight.to(x_low.dtype), hip._f32(fin.norm.weight),
                                             hip._f32(fin.norm.bias), hip._f32(conv.weight).view(-1), _bias_scalar(conv),
                                             fin.scale, fin.norm.eps)

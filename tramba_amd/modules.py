@@ -21,7 +21,6 @@ Reference files mirrored: Models/modules.py:10-27,134-153,183-274,678-696; Model
 MultiScaleDecoderBlock); Models/DCT_2D.py; Models/freq_mamba.py; Models/mamba_init.py.
 """
 import math
-import os
 from collections import OrderedDict
 
 import torch
@@ -32,17 +31,9 @@ from . import hip
 from .ops import (CrossMerge, CrossMerge_Dilation, CrossMerge_Line, CrossMerge_Window, CrossScan,
                   CrossScan_Dilation, CrossScan_Line, CrossScan_Window, SelectiveScanOflex)
 
-# GEMMs: "hip" = libtramba_hip MFMA kernel with fused epilogue, "blas" = torch.matmul (hipBLASLt)
-GEMM_BACKEND = os.environ.get("TRAMBA_GEMM", "hip")
-# dtype of the (B,K,L,D) scan output between the fused scan and the merge kernel in inference:
-# "f32" mirrors the reference's oflex fp32 output, "act" stores it in the activation dtype
-TWO_SOURCE_GEMM = os.environ.get("TRAMBA_CAT_GEMM", "1") != "0"   # 0: materialise torch.cat before concat_back_dim
-YS_DTYPE = os.environ.get("TRAMBA_YS", "f32")
-# training-path LayerNorm: "hip" = tramba_layernorm_cl / tramba_layernorm_bwd_cl, "torch" = F.layer_norm in fp32
-TRAIN_NORM_BACKEND = os.environ.get("TRAMBA_TRAIN_NORM", "hip")
-# training-path SS2D core: "hip" = fused channels-last scan forward + backward, "plugin" = the reference's graph
-# through the scan / merge plugin classes and selective_scan_cuda_oflex
-TRAIN_SCAN_BACKEND = os.environ.get("TRAMBA_TRAIN_SCAN", "hip")
+# One implementation per op: every kernel below is libtramba_hip; there are no environment switches and no alternative
+# backends.  The reference's scan / merge PLUGIN API (SS2D(scan=, merge=)) is the only other route through SS2D, taken when
+# a caller supplies scan classes of its own (scripts/ab_forward.py monkey-patches module attributes for A/B timing).
 
 
 def to_cl(x: torch.Tensor) -> torch.Tensor:
@@ -265,6 +256,17 @@ def refresh_lowp_shadows(model, dtype):
     return len(params)
 
 
+def restamp_lowp_shadows(model):
+    """Declare the shadows of `model`'s parameters current (after a hipGraph replay that refreshed them itself and a
+    version bump of the parameters: tramba_amd.graph.GraphedTrainStep)."""
+    for m in model.modules():
+        if isinstance(m, Linear2d):
+            for p in (m.weight, m.bias):
+                ent = None if p is None else _lowp_shadow.get(id(p))
+                if ent is not None and ent[2]() is p:
+                    ent[1] = p._version
+
+
 def _lowp(p, dtype):
     """p cast to dtype: the shadow when it is current, a fresh cast otherwise"""
     if p.dtype == dtype:
@@ -304,7 +306,7 @@ class Linear2d(nn.Linear):
     """1x1 convolution stored as an (out,in) matrix (modules.py:10-19)."""
 
     def _forward_cl(self, x, act=hip.ACT_NONE, residual=None, out_dtype=None):
-        if _infer(x, self.weight) and GEMM_BACKEND == "hip":
+        if _infer(x, self.weight):
             w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
             return hip.linear_cl(x, w.detach(), _f32(self.bias), residual, act, out_dtype)
         y = _act_torch(_LinearTrainCL.apply(x, self.weight, self.bias), act)
@@ -315,7 +317,7 @@ class Linear2d(nn.Linear):
     def _forward_cat_cl(self, x1, x2, act=hip.ACT_NONE, residual=None, out_dtype=None):
         """Linear2d(torch.cat((x1, x2), dim=-1)) -- in 16-bit inference the K loop reads the two tensors in turn
         (tramba_linear2_cl), so the concatenation never exists.  act = ACT_SIGMOID_GATE multiplies by `residual`."""
-        if (TWO_SOURCE_GEMM and _infer(x1, x2, self.weight) and GEMM_BACKEND == "hip" and x1.dtype != torch.float32
+        if (_infer(x1, x2, self.weight) and x1.dtype != torch.float32
                 and x1.dtype == x2.dtype
                 and x1.shape[-1] % 64 == 0 and x2.shape[-1] % 64 == 0):
             w = self.weight if self.weight.dtype == x1.dtype else self.weight.to(x1.dtype)
@@ -363,10 +365,8 @@ class LayerNorm2d(nn.LayerNorm):
     def _forward_cl(self, x, act=hip.ACT_NONE):
         if _infer(x, self.weight):
             return hip.layernorm_cl(x, _f32(self.weight), _f32(self.bias), self.eps, act)
-        if x.is_cuda and TRAIN_NORM_BACKEND == "hip":
-            return _act_torch(_LayerNormCL.apply(x, self.weight, self.bias, self.eps), act)
-        y = F.layer_norm(x.float(), self.normalized_shape, self.weight.float(), self.bias.float(), self.eps)
-        return _act_torch(y, act).to(x.dtype)
+        _need_device(x)
+        return _act_torch(_LayerNormCL.apply(x, self.weight, self.bias, self.eps), act)
 
     def forward(self, x):
         _need_device(x)
@@ -702,14 +702,16 @@ class SS2D(nn.Module):
         xf = x.view(b, h * w, d)
         xdbl = hip.linear_cl(xf, self._padded_x_proj(x.dtype), out_dtype=torch.float32)  # x_proj once, spatial order
         dt_w, dt_b, a_neg, ds = self._scan_params()
-        ys_dtype = torch.float32 if YS_DTYPE == "f32" else x.dtype
+        # the per-direction outputs travel between the scan and the merge kernel in the activation dtype (fp32 sums and
+        # LayerNorm statistics inside the merge): half the bytes of the K-fold intermediate at 16-bit activations
+        ys_dtype = x.dtype
         ys = hip.ss2d_scan_cl(xf, xdbl, order, dt_w, dt_b, a_neg, ds, ys_dtype)
         y = hip.ss2d_merge_norm_cl(ys, order, _f32(self.out_norm.weight), _f32(self.out_norm.bias),
                                    self.out_norm.eps, hip.ACT_GELU, x.dtype)
         return y.view(b, h, w, d)
 
     def _train_fused_ok(self, x):
-        return (TRAIN_SCAN_BACKEND == "hip" and x.is_cuda and self.d_state == 1 and self.dt_rank <= 64
+        return (x.is_cuda and self.d_state == 1 and self.dt_rank <= 64
                 and getattr(self.scan, "_tramba_family", None) is not None
                 and getattr(self.merge, "_tramba_family", None) == self.scan._tramba_family
                 and self.scan._tramba_k == self.k_group)
