@@ -4,30 +4,40 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one forward of Tramba-V (VMamba-B encoder + Dual-Frequency/Helix decoder) over one
-synthetic batch already resident in HBM (BASELINE.json configs[1]: 384x384, bf16, batch 4 per GPU).
-Inference shards by image: every rank runs an independent replica on its own batch, no data-path
-collective ("weak" scaling); the barrier only brackets the timed region.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the parent
+process (which never touches the GPU) runs `python -m torch.distributed.run ... bench.py <same flags>` as a child and
+exits with its code.
 
-Rank 0 prints ONE JSON line.  Extra objects on that line:
-  roofline      the dominant kernel launch of the step -- the fused channels-last selective scan on the Helix order at
-                96x96 (K = 8, D = 256, B = 4; 2 launches per forward, the largest single item): algorithmic bytes per
-                launch / average launch duration (one HIP-event pair around 20 back-to-back launches on the launch
-                stream), against 8 TB/s HBM peak; `traffic` = PMC bytes of the same launch (profiles/*_traffic.json)
-  roofline_fused_scan_all   every fused-scan launch of a forward (33, all shapes) timed inside an eager pass of the model
-  roofline_boundary   the reference-layout selective scan (the L0 drop-in op, 8 B/element at bf16-in/fp32-out, SURVEY
-                8d) on the largest call shape of this model
+One "step" = one forward of Tramba-V (VMamba-B encoder + Dual-Frequency/Helix decoder) over one synthetic batch already
+resident in HBM (BASELINE.json configs[1]: 384x384, bf16, batch 4 per GPU).  Inference shards by image: every rank runs
+an independent replica on its own batch, no data-path collective ("weak" scaling); the barrier only brackets the timed
+region.  `value` = images/s of that forward, whole job.
+
+Rank 0 prints ONE JSON line.  Objects on that line besides the contract's fields:
+  std_ms        standard deviation of the per-step device time (HIP events between the steps of the timed region)
+  latency_b1    the reference's own latency protocol (Trambav6.py:219-255): batch 1, 50 warm-up + 500 timed forwards,
+                one HIP-event pair per forward, mean / std / FPS
+  roofline      the Helix-SS2D core at the decoder's 96x96 stage (K = 8, D = 256, B = 4; 2 per forward) as a PAIR of
+                launches, fused scan + merge/out_norm: SURVEY 8(d)'s fused-Helix bytes (x once + low-rank x_proj
+                rows + merged y) / the summed average duration of the two launches, timed by HIP events on the launch
+                stream inside eager single-stream forwards of the model; `traffic` = PMC bytes of the pair
+  roofline_kernel_boundary   the same two launches at their own kernel boundaries (the K-fold `ys` intermediate counted
+                where it is written and where it is read)
+  roofline_fused_scan_all    every fused-scan launch of a forward (33, all shapes)
+  roofline_boundary   the reference-layout selective scan (the L0 drop-in op, 8 B/element) on the largest call
+                shape of this model
   roofline_gemm       the 1x1-conv projections (MFMA): 2*M*N*K of every GEMM launch of a forward / their time
-  cpu_baseline  the CPU oracle (a port of the reference forward, oracle/) timed on this host
+  cpu_baseline  the CPU oracle (a port of the reference forward, oracle/) timed on this host (N = 1 only)
+  train         BASELINE configs[2]/[3]: fwd + bwd + two-group Adam at batch 8 per GPU, gradients averaged over RCCL
+                when N > 1 (bucketed, overlapped with backward), eager launches and -- when the capture succeeds on every
+                rank -- the same step replayed as one hipGraph
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,6 +45,43 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (no 2:1 sparsity)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (config: 4)")
+    ap.add_argument("--img", type=int, default=384)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="SURVEY 8d protocol for the CPU port: 3 warm-up + 10 timed passes on all cores, plus one "
+                         "single-thread pass (minutes)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-overlap", action="store_true", help="one stream (no side stream for the guide branches)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training leg")
+    ap.add_argument("--train", action="store_true", help="(default) kept for older command lines")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency protocol")
+    ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step (config: 8)")
+    ap.add_argument("--bucket-dtype", default="fp32", choices=["fp32", "bf16"], help="gradient all-reduce buckets")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend (gloo only to rehearse the N > 1 plumbing on a one-GPU box)")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as a child job before this process touches the GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def pmc_traffic(key):
@@ -54,54 +101,83 @@ def pmc_traffic(key):
     return best
 
 
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (config: 4)")
-    ap.add_argument("--img", type=int, default=384)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--train", action="store_true",
-                    help="also time the training step (fwd+bwd+Adam, DP all-reduce when N>1) and report it as 'train'")
-    ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step (config: 8)")
-    return ap.parse_args()
-
-
 def build_model(img, dtype):
+    import torch
     import tramba_amd as ta
     torch.manual_seed(1026)  # train.py:284
     m = ta.bulid_model(deep_supervision=True, use_pretrain=False, img_size=img, dims=128, depths=[2, 2, 2, 2])
     return ta.prepare_inference(m.cuda(), dtype)
 
 
-def cpu_baseline(img):
-    """Reference forward as restated by the oracle (kind "port"), bounded sample on the host."""
-    import synth
+def host_cpu():
+    """(model name, physical cores, logical cpus) of this host from /proc/cpuinfo"""
+    model, phys, logical = None, set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                logical += 1
+            elif line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or None), logical
+
+
+def cpu_baseline(img, full):
+    """Reference forward as restated by the oracle (kind "port") on the host cores.  Default: a bounded sample (1 warm-up
+    + the passes that fit ~20 s, at least 3).  `full`: SURVEY 8d -- 3 warm-up + 10 timed, and one single-thread pass."""
+    import torch
     from oracle import model as om
-    from oracle import ops as oo
     import tramba_amd as ta
     torch.manual_seed(1026)
     m = ta.bulid_model(use_pretrain=False, img_size=img)
     sd = {k: v.detach() for k, v in m.state_dict().items()}
     x = torch.randn(1, 3, img, img, generator=torch.Generator().manual_seed(0))
-    cores = torch.get_num_threads()
+    name, phys, logical = host_cpu()
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    threads = min(phys or usable, usable)
+    torch.set_num_threads(max(1, threads))
+    os.environ["OMP_NUM_THREADS"] = str(max(1, threads))
+    single = None
     with torch.no_grad():
-        om.tramba_v(sd, x)  # warm-up (builds tables, loads the C scan)
+        for _ in range(3 if full else 1):       # warm-up (builds tables, loads the C scan)
+            om.tramba_v(sd, x)
         n, t0 = 0, time.perf_counter()
-        while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 8):
+        while (n < 10) if full else (n < 3 or (time.perf_counter() - t0 < 20.0 and n < 10)):
             om.tramba_v(sd, x)
             n += 1
         dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"{n} forward passes of Tramba-V {img}x{img}, batch 1, fp32, oracle/model.py "
-                      f"(torch-CPU ops + OpenMP C scan)"}
+        if full:
+            torch.set_num_threads(1)
+            os.environ["OMP_NUM_THREADS"] = "1"
+            s0 = time.perf_counter()
+            om.tramba_v(sd, x)
+            single = {"value": round(1.0 / (time.perf_counter() - s0), 5), "unit": "img/s", "cores": 1, "passes": 1}
+            torch.set_num_threads(max(1, threads))
+            os.environ["OMP_NUM_THREADS"] = str(max(1, threads))
+    return {"value": round(n / dt, 4), "unit": "img/s", "cores": threads, "kind": "port",
+            "cpu_model": name, "physical_cores": phys, "logical_cpus": logical, "usable_cpus": usable,
+            "single_thread": single,
+            "sample": f"{n} timed forward passes after {3 if full else 1} warm-up, Tramba-V {img}x{img}, batch 1, fp32, "
+                      f"oracle/model.py (torch-CPU ops + OpenMP C scan), {threads} threads"
+                      + ("" if full else "; bounded sample -- the SURVEY 8d protocol (3 + 10 passes, single-thread figure) "
+                                         "is `--cpu-baseline-full`, recorded in profiles/")}
 
 
 def boundary_scan_roofline(dtype):
-    """Op-level run of the L0 selective scan on this model's largest call shape (4,1024,9216)."""
+    """Op-level run of the L0 selective scan on this model's largest call shape (4,1024,9216): algorithmic bytes from the
+    library's own accounting / the average launch duration from ONE pair of HIP events around 20 back-to-back launches
+    on the launch stream (a pair per launch adds the markers' own ~8 us of serialisation to a 60 us kernel)."""
+    import torch
     from tramba_amd import hip
     dev = torch.device("cuda")
     nb, kd, k, l = 4, 1024, 4, 9216
@@ -116,14 +192,10 @@ def boundary_scan_roofline(dtype):
     for _ in range(5):
         hip.selective_scan_fwd(u, delta, A, B, C, D, bias, True, True, want_ckpt=False)
     torch.cuda.synchronize()
-    # algorithmic bytes of one launch from the library's own accounting ...
     hip.profile_enable(hip.PROF_SCAN_BOUNDARY, True)
     hip.selective_scan_fwd(u, delta, A, B, C, D, bias, True, True, want_ckpt=False)
     _, _, bytes_per_launch = hip.profile_read(hip.PROF_SCAN_BOUNDARY)
     hip.profile_enable(hip.PROF_SCAN_BOUNDARY, False)
-    # ... and the average launch duration from ONE pair of HIP events around n back-to-back launches on the launch
-    # stream (a pair per launch adds the event markers' own ~8 us of serialisation to a 60 us kernel and no longer
-    # agrees with the rocprofv3 kernel trace)
     n = 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -133,45 +205,92 @@ def boundary_scan_roofline(dtype):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    nbytes = bytes_per_launch * n
-    gbs = nbytes / (ms * 1e-3) / 1e9
+    gbs = bytes_per_launch * n / (ms * 1e-3) / 1e9
+    pmc = pmc_traffic("selective_scan_fwd_kernel@grid262144")
     return {"bound": "hbm", "kernel": "selective_scan_fwd_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": (pmc_traffic("selective_scan_fwd_kernel@grid262144") or {}).get("bytes"),
-            "traffic_detail": pmc_traffic("selective_scan_fwd_kernel@grid262144"),
-            "shape": [nb, kd, l], "launches": n, "avg_us": round(ms / n * 1e3, 2)}
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": (pmc or {}).get("bytes"),
+            "traffic_detail": pmc, "shape": [nb, kd, l], "launches": n, "avg_us": round(ms / n * 1e3, 2)}
 
 
-def helix_scan_roofline(step, nrep):
-    """The Helix-SS2D launch of the fused scan kernel at the decoder's 96x96 stage (K = 8, D = 256, B = 4): the largest
-    single (kernel, shape) item of the forward (2 launches, ~0.24 ms of 5.3), timed INSIDE eager forwards of the model:
-    the library's launch profiler (one HIP-event pair per launch, on the launch stream) is restricted to launches
-    accounting for >= 300 MB, which only this shape does (335 MB; the next largest fused scan is 177 MB)."""
+def helix_pair_roofline(step, nrep, batch, act_bytes):
+    """The Helix-SS2D core at 96x96 (K = 8, D = 256): fused scan launch + merge/out_norm launch, both timed INSIDE eager
+    single-stream forwards of the model by the library's launch profiler (one HIP-event pair per launch on the launch
+    stream), restricted by `tramba_profile_min_units` to launches of >= 150 MB, which only this shape reaches (scan: 184
+    MB with 2-byte ys, next largest 101 MB; merge: 170 MB, next largest 94 MB)."""
     from tramba_amd import hip
-    hip.profile_min_units(hip.PROF_SCAN_FUSED, 300e6)
-    hip.profile_enable(hip.PROF_SCAN_FUSED, True)
+    for which in (hip.PROF_SCAN_FUSED, hip.PROF_MERGE):
+        hip.profile_min_units(which, 150e6)
+        hip.profile_enable(which, True)
     for _ in range(nrep):
         step()
-    n, ms, nbytes = hip.profile_read(hip.PROF_SCAN_FUSED)
-    hip.profile_enable(hip.PROF_SCAN_FUSED, False)
-    hip.profile_min_units(hip.PROF_SCAN_FUSED, 0.0)
-    if n == 0:
-        return None
-    gbs = nbytes / (ms * 1e-3) / 1e9
-    pmc = pmc_traffic("ss2d_scan_cl_kernel@grid131072")
-    return {"bound": "hbm", "kernel": "ss2d_scan_cl_kernel (Helix-SS2D launch: 96x96, K=8, D=256, B=4, ys f32)",
+    ns, ms_s, by_s = hip.profile_read(hip.PROF_SCAN_FUSED)
+    nm, ms_m, by_m = hip.profile_read(hip.PROF_MERGE)
+    for which in (hip.PROF_SCAN_FUSED, hip.PROF_MERGE):
+        hip.profile_enable(which, False)
+        hip.profile_min_units(which, 0.0)
+    if ns == 0 or nm == 0:
+        return None, None
+    us_s, us_m = ms_s / ns * 1e3, ms_m / nm * 1e3
+    b, l, d, k, r = batch, 96 * 96, 256, 8, 8
+    # SURVEY 8(d), fused Helix-SS2D: read x once + low-rank (R + 2N) x_proj rows per direction (fp32 as stored) + write
+    # the merged y
+    alg = b * l * d * act_bytes + (r + 2) * k * b * l * 4 + b * l * d * act_bytes
+    gbs = alg / ((us_s + us_m) * 1e-6) / 1e9
+    pmc_s, pmc_m = pmc_traffic("ss2d_scan_cl_kernel@helix96"), pmc_traffic("ss2d_merge_norm_deep_kernel@helix96")
+    traffic = pmc_s["bytes"] + pmc_m["bytes"] if pmc_s and pmc_m else None
+    pair = {"bound": "hbm",
+            "kernel": "Helix-SS2D core at 96x96 (K=8, D=256, B=%d): ss2d_scan_cl_kernel + ss2d_merge_norm_deep_kernel" % b,
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": pmc["bytes"] if pmc else None, "traffic_detail": pmc, "algorithmic_bytes": int(nbytes / n),
-            "launches": n, "avg_us": round(ms / n * 1e3, 2),
-            "note": "per launch: algorithmic bytes (x once + x_proj rows + ys) / average HIP-event duration of this "
-                    "shape's launches inside eager single-stream forwards of the model; traffic = PMC bytes of the same "
-                    "launch (separate FETCH_SIZE / WRITE_SIZE passes); all 33 fused-scan launches of a forward together: "
-                    "roofline_fused_scan_all"}
+            "traffic": traffic, "algorithmic_bytes": alg, "launches": ns,
+            "avg_us": round(us_s + us_m, 2), "scan_us": round(us_s, 2), "merge_us": round(us_m, 2),
+            "formula": "SURVEY 8(d) fused Helix-SS2D: B*L*D*s (x once) + (R+2N)*K*B*L*4 (x_proj rows) + B*L*D*s (merged y), "
+                       "s = activation bytes; the K-fold per-direction `ys` between the two launches is NOT counted "
+                       "(it is this implementation's intermediate: roofline_kernel_boundary counts it)",
+            "note": "both launches are VALU/transcendental-issue and latency bound, not HBM bound (DESIGN.md section 4: "
+                    "SQ counters); average HIP-event durations inside eager single-stream forwards"}
+    kb = {"scan": {"bound": "hbm", "kernel": "ss2d_scan_cl_kernel (Helix 96x96)", "achieved": round(by_s / (ms_s * 1e-3) / 1e9, 1),
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by_s / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "algorithmic_bytes": int(by_s / ns), "avg_us": round(us_s, 2), "traffic": (pmc_s or {}).get("bytes"),
+                   "formula": "x once + x_proj rows (padded groups) + ys (B,K,L,D) written"},
+          "merge": {"bound": "hbm", "kernel": "ss2d_merge_norm_deep_kernel (Helix 96x96)",
+                    "achieved": round(by_m / (ms_m * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(by_m / (ms_m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(by_m / nm),
+                    "avg_us": round(us_m, 2), "traffic": (pmc_m or {}).get("bytes"),
+                    "formula": "ys (B,K,L,D) read + y (B,L,D) written"}}
+    return pair, kb
 
 
-def bench_train(args, world, rank, dtype):
-    """BASELINE configs[2]/[3]: fwd + bwd (BCE+IoU on 4 outputs) + two-group Adam, batch 8 per GPU,
-    gradients all-reduced over RCCL in 32 MB buckets overlapped with backward when world > 1."""
+def latency_b1(model, img, graph_ok):
+    """Trambav6.py:219-255: batch 1, 50 warm-up + 500 timed forwards, one event pair per forward, mean / std / FPS."""
+    import torch
+    import tramba_amd as ta
+    x = torch.randn(1, 3, img, img, generator=torch.Generator().manual_seed(0)).cuda()
+    gf = ta.GraphedForward(model) if graph_ok else None
+    run = (lambda: gf(x)) if gf is not None else (lambda: model(x))
+    with torch.no_grad():
+        for _ in range(50):
+            run()
+        torch.cuda.synchronize()
+        reps = 500
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            run()
+            b.record()
+        torch.cuda.synchronize()
+    ts = torch.tensor([a.elapsed_time(b) for a, b in evs], dtype=torch.float64)
+    mean, std = float(ts.mean()), float(ts.std(unbiased=False))
+    return {"mean_ms": round(mean, 4), "std_ms": round(std, 4), "fps": round(1000.0 / mean, 2), "batch": 1,
+            "warmup": 50, "reps": reps, "launch": "hipGraph replay" if gf is not None else "eager",
+            "protocol": "Trambav6.py:219-255 (one event pair per forward)"}
+
+
+def bench_train(args, world, rank, dtype, sync_all):
+    """BASELINE configs[2]/[3]: fwd + bwd (BCE+IoU on 4 outputs) + two-group Adam, batch 8 per GPU, stochastic depth
+    on; gradients averaged over RCCL in 32 MB buckets launched from autograd hooks (overlapped with backward) when
+    world > 1.  Timed like the forward leg: barrier + synchronize on both sides, max over ranks."""
+    import torch
+    import torch.distributed as dist
     import tramba_amd as ta
     from tramba_amd import parallel, train
     torch.manual_seed(1026)
@@ -179,65 +298,108 @@ def bench_train(args, world, rank, dtype):
     model.compute_dtype = None if dtype == torch.float32 else dtype
     if world > 1:
         parallel.broadcast_parameters(model, src=0)
-    red = parallel.GradBucketReducer(model)
+    bdt = torch.bfloat16 if args.bucket_dtype == "bf16" else None
+    red = parallel.GradBucketReducer(model, bucket_dtype=bdt)
     opt = train.get_opt(1e-4, model)
     b = args.train_batch
     x = torch.randn(b, 3, args.img, args.img, generator=torch.Generator().manual_seed(100 + rank)).cuda()
     y = (torch.rand(b, 1, args.img, args.img, generator=torch.Generator().manual_seed(200 + rank)) > 0.7).float().cuda()
     steps, warm = max(5, args.steps // 2), 3
+
+    def timed(fn):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync_all()
+        t = torch.tensor([time.perf_counter() - t0], device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(warm):
         train.train_step(model, opt, x, y, reducer=red)
-    torch.cuda.synchronize()
+    dt = timed(lambda: train.train_step(model, opt, x, y, reducer=red))
+    # share of the step the collective is not hidden behind backward: the same step with the reducer left out of the
+    # exchange (world 1 semantics) cannot be run without desynchronising the replicas, so time the all-reduce of the
+    # buckets alone instead and report it beside the step
+    comm = None
     if world > 1:
+        torch.cuda.synchronize()
         dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        train.train_step(model, opt, x, y, reducer=red)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        c0 = time.perf_counter()
+        for _ in range(3):
+            hs = [dist.all_reduce(f, op=dist.ReduceOp.SUM, async_op=True) for f in red.flat]
+            for h in hs:
+                h.wait()
+        torch.cuda.synchronize()
+        cdt = (time.perf_counter() - c0) / 3
+        nbytes = red.bytes_per_step()
+        comm = {"allreduce_alone_ms": round(cdt * 1e3, 3), "share_of_step_if_exposed": round(cdt / (dt / steps), 4),
+                "bus_GBps_per_rank": round(2.0 * (world - 1) / world * nbytes / cdt / 1e9, 1),
+                "note": "all buckets reduced back to back with nothing else running; inside the step the buckets are "
+                        "launched from autograd hooks and overlap the rest of backward"}
+        # (the buckets now hold scribble; the next step's prepare() / fill overwrites them)
+    # the same step replayed as ONE hipGraph (collectives captured with it when world > 1)
     graphed = None
-    if world == 1:      # the same step replayed as ONE hipGraph (single process: no collective inside the capture)
+    try:
+        gopt = train.get_opt(1e-4, model, capturable=True)
+        gstep = ta.GraphedTrainStep(model, gopt, reducer=red)
+        ok, err = torch.ones(1, device="cuda"), "capture failed on another rank"
         try:
-            import tramba_amd as ta
-            gstep = ta.GraphedTrainStep(model, train.get_opt(1e-4, model, capturable=True))
             for _ in range(2):
                 gstep(x, y)
             torch.cuda.synchronize()
-            g0 = time.perf_counter()
-            for _ in range(steps):
-                gstep(x, y)
-            torch.cuda.synchronize()
-            gdt = time.perf_counter() - g0
-            graphed = {"value": round(b * steps / gdt, 2), "unit": "img/s", "ms_per_step": round(gdt / steps * 1e3, 2),
-                       "what": "tramba_amd.GraphedTrainStep: forward + loss + backward + Adam + weight-shadow refresh "
-                               "as one hipGraph replay"}
-        except Exception as e:  # an optimisation, never a requirement
-            graphed = {"error": f"{type(e).__name__}: {e}"[:300]}
+        except Exception as e:
+            ok.zero_()
+            err = f"{type(e).__name__}: {e}"[:300]
+        if world > 1:       # replay only if EVERY rank holds a graph (a rank replaying alone would wait for ever)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            gdt = timed(lambda: gstep(x, y))
+            graphed = {"value": round(world * b * steps / gdt, 2), "unit": "img/s", "ms_per_step": round(gdt / steps * 1e3, 2),
+                       "what": "tramba_amd.GraphedTrainStep: forward + loss + backward (+ bucketed all-reduce) + Adam + "
+                               "weight-shadow refresh as one hipGraph replay per step"}
+        else:
+            graphed = {"error": err}
+    except Exception as e:  # an optimisation, never a requirement
+        graphed = {"error": f"{type(e).__name__}: {e}"[:300]}
     return {"metric": "images/sec fwd+bwd+Adam Tramba-V 384x384", "value": round(world * b * steps / dt, 2),
             "unit": "img/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2), "batch_per_gpu": b,
-            "grad_bytes_per_step": red.bytes_per_step(), "stochastic_depth": "on (0.6 enc / 0.2 dec)",
-            "dtype": args.dtype + " activations, fp32 master weights", "graphed": graphed}
+            "global_batch": b * world, "launch": "eager",
+            "grad_bytes_per_step": red.bytes_per_step() if world > 1 else 0,
+            "grad_bucket_bytes": red.bytes_per_step(), "grad_buckets": len(red.buckets),
+            "grad_bucket_dtype": args.bucket_dtype, "allreduce": comm,
+            "parallelism": f"dp{world}" + ((", RCCL all-reduce (ncclAvg)" if args.backend == "nccl" else ", gloo all-reduce")
+                                            + " of gradient buckets from autograd hooks" if world > 1 else ", no collective"),
+            "stochastic_depth": "on (0.6 enc / 0.2 dec)", "dtype": args.dtype + " activations, fp32 master weights",
+            "graphed": graphed}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running with {world} ranks", file=sys.stderr)
+    ndev = torch.cuda.device_count()
+    assert ndev > 0, "bench.py needs an MI355X"
+    dev_index = local % ndev
     if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if args.gpus != world and rank == 0 and world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-        sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     from tramba_amd import hip
+    from tramba_amd import models as _models
+    if args.no_overlap:
+        _models.OVERLAP_BRANCHES = False
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     model = build_model(args.img, dtype)
     x = torch.randn(args.batch, 3, args.img, args.img, generator=torch.Generator().manual_seed(rank)).cuda()
@@ -261,20 +423,24 @@ def main():
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out_static = step()
+                out_static = step()  # noqa: F841
         except Exception as e:  # graph capture is an optimisation, never a requirement
             if rank == 0:
                 print(f"bench.py: hipGraph capture unavailable ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
     run = (lambda: graph.replay()) if graph is not None else step
+    graph_used = graph is not None
 
     for _ in range(args.warmup):
         run()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         run()
+        marks[i + 1].record()
     sync_all()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device="cuda")
@@ -282,12 +448,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     value = world * args.batch * args.steps / dt
+    per = torch.tensor([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)], dtype=torch.float64)
+    std_ms = float(per.std(unbiased=False)) if args.steps > 1 else 0.0
 
-    # ---- roofline of the dominant kernel: eager pass of the same steps with HIP events around
-    #      every launch of the fused scan kernel (events cannot live inside a captured graph)
-    roof = roof_all = roof_b = roof_g = cpu = None
+    # ---- rank 0: latency protocol, rooflines (eager single-stream passes with HIP events around the library's
+    #      launches; events cannot live inside a captured graph), CPU baseline
+    lat = roof = roof_kb = roof_all = roof_b = roof_g = cpu = None
     if rank == 0:
-        from tramba_amd import models as _models
+        if not args.no_latency:
+            lat = latency_b1(model, args.img, graph is not None)
         overlap_was = _models.OVERLAP_BRANCHES
         _models.OVERLAP_BRANCHES = False      # one stream: a launch is timed alone, like the rocprofv3 trace
         hip.profile_enable(hip.PROF_SCAN_FUSED, True)
@@ -299,15 +468,13 @@ def main():
         ng, msg, flops = hip.profile_read(hip.PROF_GEMM)
         hip.profile_enable(hip.PROF_SCAN_FUSED, False)
         hip.profile_enable(hip.PROF_GEMM, False)
-        _models.OVERLAP_BRANCHES = overlap_was
         gbs = nbytes / (ms * 1e-3) / 1e9
         roof_all = {"bound": "hbm", "kernel": "ss2d_scan_cl_kernel + ss2d_seg_kernel, all shapes", "achieved": round(gbs, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                     "launches": n, "avg_us": round(ms / n * 1e3, 2), "ms_per_step": round(ms / nrep, 3),
-                    "note": "sum of algorithmic bytes / sum of HIP-event time over every fused-scan launch of a step "
-                            "(single-stream eager pass, one event pair per launch)"}
-        _models.OVERLAP_BRANCHES = False
-        roof = helix_scan_roofline(step, nrep)
+                    "note": "kernel-boundary bytes (x once + x_proj rows + ys) / HIP-event time, summed over every "
+                            "fused-scan launch of a step (single-stream eager pass, one event pair per launch)"}
+        roof, roof_kb = helix_pair_roofline(step, nrep, args.batch, 4 if dtype == torch.float32 else 2)
         _models.OVERLAP_BRANCHES = overlap_was
         tfs = flops / (msg * 1e-3) / 1e12
         roof_g = {"bound": "mfma", "kernel": "linear_lean_kernel / linear_tiled_kernel (1x1-conv projections)",
@@ -317,10 +484,10 @@ def main():
                           "small (M = 576..36864, K <= 4096): LDS- and latency-bound, far from the dense MFMA peak"}
         roof_b = boundary_scan_roofline(dtype)
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.img)
+            cpu = cpu_baseline(args.img, args.cpu_baseline_full)
     train_obj = None
-    if args.train:
-        train_obj = bench_train(args, world, rank, dtype)
+    if not args.no_train:
+        train_obj = bench_train(args, world, rank, dtype, sync_all)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -328,19 +495,17 @@ def main():
         line = {
             "metric": "images/sec fwd Tramba-V 384x384", "value": round(value, 2), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "std_ms": round(std_ms, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"Tramba-V (VMamba-B encoder) {args.img}x{args.img} {args.dtype} inference, "
                                    f"batch {args.batch} per GPU, random-init weights (seed 1026), randn images",
                        "global_batch": args.batch * world, "parallelism": f"dp{world} replicas, no collective",
-                       "launch": ("hipGraph replay" if graph is not None else "eager") +
-                                 (", decoder guide branches on a side stream"
-                                  if os.environ.get("TRAMBA_OVERLAP", "1") != "0" else "")},
-            "roofline": roof, "roofline_fused_scan_all": roof_all, "roofline_boundary": roof_b, "roofline_gemm": roof_g,
-            "cpu_baseline": cpu,
+                       "launch": ("hipGraph replay" if graph_used else "eager") +
+                                 ("" if args.no_overlap else ", decoder guide branches on a side stream")},
+            "latency_b1": lat,
+            "roofline": roof, "roofline_kernel_boundary": roof_kb, "roofline_fused_scan_all": roof_all,
+            "roofline_boundary": roof_b, "roofline_gemm": roof_g, "cpu_baseline": cpu, "train": train_obj,
         }
-        if train_obj is not None:
-            line["train"] = train_obj
         print(json.dumps(line), flush=True)
 
 

@@ -74,10 +74,18 @@ int tramba_profile_read(int which, double *total_ms, double *total_bytes);
 /* Time only the launches of class `which` that account for at least `min_units` bytes (flops): singles out one shape
  * (e.g. the Helix 96x96 fused scan inside a model forward).  0 = every launch (default). */
 int tramba_profile_min_units(int which, double min_units);
+/* Kernel-variant selection for A/B timing from scripts/ (never needed for correctness: 0 = the library's own choice).
+ * knob TRAMBA_TUNE_MERGE_FORM: 1 = one wave per pixel (deep row pipeline), 2 = streaming (several pixels per wave). */
+int tramba_tune_set(int knob, int value);
+int tramba_tune_get(int knob);
+#define TRAMBA_TUNE_MERGE_FORM 0
+#define TRAMBA_TUNE_SCAN_FORM 1      /* 1 = chained, 2 = wave-segment */
+#define TRAMBA_TUNE_COUNT 2
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1
 #define TRAMBA_PROF_GEMM 2          /* tramba_linear_cl (1x1-conv projections) */
-#define TRAMBA_PROF_COUNT 3
+#define TRAMBA_PROF_MERGE 3         /* tramba_ss2d_merge_norm_cl: K*L*D ys bytes read + L*D written, per image */
+#define TRAMBA_PROF_COUNT 4
 
 /* ------------------------------------------------------------------ scan-order tables (host) */
 /* Number of directions K of a family. */
@@ -207,6 +215,24 @@ int tramba_linear_cl(const void *x, const void *w, const float *bias, const void
  * FreqSS2Dv6, freq_mamba.py:52).  16-bit dtypes, k1 % 64 == 0 and (k - k1) % 64 == 0. */
 int tramba_linear2_cl(const void *x1, const void *x2, int k1, const void *w, const float *bias, const void *residual,
                       void *y, int64_t m, int n, int k, int act, int dtype, int out_dtype, void *stream);
+
+/* Weight (and bias) gradient of a 1x1 convolution under autograd -- what `loss.backward()` computes for every
+ * Linear2d (Models/modules.py:10-19; the reference gets it from cuDNN/cuBLAS through F.conv2d's autograd):
+ *   out[g][n*K + k]  = sum over batches b and tokens t of gy[g][b][t][n] * x[g][b][t][k]       (N x K, fp32)
+ *   out[g][N*K + n]  = sum over b, t of gy[g][b][t][n]                                          (bias gradient, if want_bias)
+ * Element (g, b, t, c) of an operand sits at base + b*bs + g*gs + t*ld + c (element strides): groups / nbatch serve the
+ * per-direction contractions of the SS2D backward on (B, K, L, C) tensors; a plain Linear2d has groups = nbatch = 1.
+ * out: (groups, N*K + N) f32.  workspace: tramba_wgrad_workspace() bytes of fp32 partial slabs (the token range is split
+ * over workgroups, slabs are summed in a fixed order).  16-bit dtypes; N, K and every stride multiples of 8. */
+size_t tramba_wgrad_workspace(int64_t m, int n, int k, int groups, int nbatch);
+int tramba_wgrad_cl(const void *gy, const void *x, float *out, void *workspace, size_t workspace_bytes, int64_t m, int n,
+                    int k, int groups, int nbatch, int64_t gy_bs, int64_t gy_gs, int gy_ld, int64_t x_bs, int64_t x_gs,
+                    int x_ld, int want_bias, int dtype, void *stream);
+/* y[z][t][0..N) = x[z][t][:] . w[z % groups][n][:]  for z < nz, t < m: x (nz, m, K) dtype, w (groups, N, K) dtype,
+ * y fp32 rows of stride ldy (>= N; the columns past N are left untouched).  N <= 64, K % 8 == 0.  The dt_rank projection
+ * of the SS2D backward (vmamba.py:236 under autograd): d(x_dbl ranks) = d(dt_raw) @ dt_projs_weight[k]. */
+int tramba_rows_gemm_cl(const void *x, const void *w, float *y, int nz, int64_t m, int n, int k, int groups, int ldy,
+                        int dtype, void *stream);
 
 /* The whole last decoder stage in one kernel (FinalPatchExpand_X4 + seg_layers[-1], Trambav6.py:132-137):
  * y (B, H*P, W*P) f32 = head(LayerNorm_128(pixel_shuffle_P(x @ w^T))).  x (B, H, W, Cin) dtype, w (P*P*128, Cin) dtype

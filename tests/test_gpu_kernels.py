@@ -426,8 +426,9 @@ def test_dwms_training_fold_matches_reference_sum():
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(2, 3, 64, 96, 2), (8, 64, 128, 48, 2), (2, 16, 24, 20, 1), (16, 8, 8, 64, 2)])
 def test_dense_conv_training_path_matches_autograd(dtype, cfg):
-    """_ConvNative (native forward / input gradient, im2col + token-split GEMM weight gradient) against F.conv2d autograd
-    in fp64; the last cases are large enough (B*Ho*Wo >= 8192) to take the split path."""
+    """_ConvIm2colCL (channels-last; im2col around tramba_linear_cl for the forward / input gradient and tramba_wgrad_cl
+    for the weight / bias gradient; fp32 through bf16 hi + lo splits) against F.conv2d autograd in fp64.  Cin = 3 takes
+    the padded-K route (27 -> 32 columns), the last cases split the token range over several workgroups."""
     from tramba_amd import modules as M
     b, cin, cout, hw, stride = cfg
     g = torch.Generator().manual_seed(cin * cout + hw)
@@ -437,12 +438,16 @@ def test_dense_conv_training_path_matches_autograd(dtype, cfg):
     gy_shape = F.conv2d(x.float(), w.float(), stride=stride, padding=1).shape
     gy = torch.randn(gy_shape, generator=g).to(dtype)
     xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, bias))
-    F.conv2d(xr, wr, br, stride=stride, padding=1).backward(gy.double())
-    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, bias))
-    M._ConvNative.apply(xg, wg, bg, (stride, stride), (1, 1), 1).backward(gy.to(DEV))
-    tol = 1e-4 if dtype == torch.float32 else 3e-2
-    for got, want in ((xg.grad, xr.grad), (wg.grad, wr.grad), (bg.grad, br.grad)):
-        np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol * float(want.abs().max()))
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=1)
+    yr.backward(gy.double())
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)                 # channels-last (B,H,W,C)
+    wg, bg = (t.float().to(DEV).requires_grad_(True) for t in (w, bias))                  # fp32 master parameters
+    y = M._ConvIm2colCL.apply(xg, wg, bg, (stride, stride), (1, 1))
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    pairs = ((y.permute(0, 3, 1, 2), yr.detach()), (xg.grad.permute(0, 3, 1, 2), xr.grad), (wg.grad, wr.grad), (bg.grad, br.grad))
+    for got, want in pairs:
+        np.testing.assert_allclose(got.detach().cpu().double().numpy(), want.numpy(), rtol=tol, atol=tol * float(want.abs().max()))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -567,3 +572,50 @@ def test_linear2_cl_matches_concatenated_gemm(dtype, cfg):
     gate = H.linear2_cl(x1, x2, w, None, res, H.ACT_SIGMOID_GATE)
     want = torch.sigmoid(xc.double() @ w.double().T) * res.double()
     np.testing.assert_allclose(gate.cpu().double().numpy(), want.cpu().numpy(), rtol=2e-2, atol=2e-2)
+
+
+# ----------------------------------------------------------------------------- training-path GEMMs (train_gemm.hip)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k", [(576, 128, 512), (2304, 256, 128), (1000, 8, 136), (33, 264, 72), (9216, 48, 256),
+                                   (4608, 1024, 256)])
+def test_wgrad_tn_against_fp64(m, n, k, dtype):
+    """gw = gy^T x and gb = column sums of gy (the weight / bias gradient of Linear2d, modules.py:10-19 under autograd)
+    against an fp64 contraction of the same rounded operands: ragged token counts (tail steps, several splits), channel
+    counts that are not multiples of the 128 tile, strided rows."""
+    H = hip()
+    g = torch.Generator().manual_seed(m + n + k)
+    wide = torch.randn(m, n + 16, generator=g).to(DEV, dtype)
+    gy = wide[:, 8:8 + n]                                         # strided rows, 16-byte aligned start
+    x = torch.randn(m, k, generator=g).to(DEV, dtype)
+    gw, gb = H.wgrad_cl(gy, x, want_bias=True)
+    want = gy.double().t() @ x.double()
+    scale = float((gy.double().abs().t() @ x.double().abs()).max())
+    assert gw.shape == (n, k) and gw.dtype == torch.float32
+    assert float((gw.double() - want).abs().max()) <= 2e-6 * scale + 1e-6
+    wb = gy.double().sum(0)
+    assert float((gb.double() - wb).abs().max()) <= 2e-6 * float(gy.double().abs().sum(0).max()) + 1e-6
+    gw2, none = H.wgrad_cl(gy.contiguous(), x)
+    assert none is None and torch.equal(gw2, gw)                  # strides do not change the summation order
+
+
+@pytest.mark.parametrize("b,kk,l,d,r", [(2, 4, 144, 64, 8), (1, 8, 576, 128, 16), (2, 8, 2304, 256, 8), (1, 4, 100, 2048, 64),
+                                        (1, 4, 576, 40, 8)])
+def test_ss2d_backward_small_contractions(b, kk, l, d, r):
+    """the per-direction projections of the SS2D backward (vmamba.py:233-236 under autograd): d(dt_projs_weight)[k] =
+    sum_{b,l} graw^T ranks (grouped TN GEMM) and d(ranks) = graw @ dt_projs_weight[k] (rows_gemm into strided fp32 rows)"""
+    H = hip()
+    g = torch.Generator().manual_seed(b * l + d)
+    graw = torch.randn(b, kk, l, d, generator=g).to(DEV, torch.bfloat16)
+    ranks = torch.randn(b, kk, l, r, generator=g).to(DEV, torch.bfloat16)
+    dt_w = (torch.randn(kk, d, r, generator=g) * d ** -0.5).to(DEV)
+    got = H.wgrad_grouped_cl(graw, ranks)
+    want = torch.einsum("bkld,bklr->kdr", graw.double(), ranks.double())
+    scale = float(torch.einsum("bkld,bklr->kdr", graw.double().abs(), ranks.double().abs()).max())
+    assert got.shape == (kk, d, r) and float((got.double() - want).abs().max()) <= 2e-6 * scale + 1e-6
+    rg = r + 4
+    y = torch.full((b * kk, l, rg), 7.0, device=DEV)
+    wt = dt_w.transpose(1, 2).contiguous().to(torch.bfloat16)     # (K, R, D)
+    H.rows_gemm_cl(graw.view(b * kk, l, d), wt, y, r)
+    want2 = torch.einsum("bkld,krd->bklr", graw.double(), wt.double()).reshape(b * kk, l, r)
+    assert float((y[..., :r].double() - want2).abs().max()) <= 1e-5 * float(want2.abs().max()) + 1e-5
+    assert torch.all(y[..., r:] == 7.0)                           # columns past N untouched

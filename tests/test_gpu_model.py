@@ -151,6 +151,144 @@ def test_tramba_v_low_precision_keeps_mae(golden_meta, dtype):
     assert abs(mae - golden_meta["G5_tramba_v_mae"]) < 5e-4, (mae, golden_meta["G5_tramba_v_mae"])
 
 
+def _err_stats(got, want):
+    """max-abs and RMS error relative to the RMS of the reference map, and the fraction of sigmoid > 0.5 decisions that flip"""
+    d = got.double() - want.double()
+    ref = float(want.double().square().mean().sqrt())
+    return float(d.abs().max()) / ref, float(d.square().mean().sqrt()) / ref, float(((got > 0) != (want > 0)).double().mean())
+
+
+@pytest.fixture(scope="module")
+def batch4_oracle():
+    """Tramba-V 384x384 at the BENCHMARKED batch (4): closed-form weights, image 0 = the G5 golden input, fp32 CPU oracle
+    outputs of all four maps (the oracle itself is pinned to the reference's forward by tests/test_oracle.py)."""
+    import tramba_amd as ta
+    m = _load_synth(ta.bulid_model(deep_supervision=True, use_pretrain=False, img_size=384))
+    x = torch.cat([synth.synth_input("g5_v", (1, 3, 384, 384))] +
+                  [synth.synth_input(f"g5_v_b{i}", (1, 3, 384, 384)) for i in range(1, 4)], 0)
+    with torch.no_grad():
+        want = om.tramba_v({k: v.detach().cpu() for k, v in m.state_dict().items()}, x)
+    del m
+    return x, want
+
+
+# measured on MI355X (scripts/measure_lowp_parity.py, profiles/r02_lowp_parity.json), relative to the RMS of each
+# reference map: (max-abs, RMS, decision flips) -- asserted with ~1.6x headroom
+LOWP_TOL = {torch.bfloat16: (0.16, 0.04, 0.02), torch.float16: (0.025, 0.006, 0.008), torch.float32: (2e-4, 2e-5, 1e-4)}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_tramba_v_batch4_elementwise_against_fp32_oracle(golden, batch4_oracle, dtype):
+    """BASELINE configs[1] is bf16 at batch 4: every logit of all four output maps against the fp32 reference forward on
+    the same inputs -- max-abs and RMS error and the fraction of pixels whose saliency decision flips (the
+    MAE of a chance-level map cannot see wrong logits)."""
+    import tramba_amd as ta
+    x, want = batch4_oracle
+    m = ta.prepare_inference(_load_synth(ta.bulid_model(deep_supervision=True, use_pretrain=False, img_size=384)), dtype)
+    with torch.no_grad():
+        got = [o.float().cpu() for o in m(x.to(DEV))]
+    tmax, trms, tflip = LOWP_TOL[dtype]
+    for i, (g, w) in enumerate(zip(got, want)):
+        emax, erms, flips = _err_stats(g, w)
+        assert emax <= tmax and erms <= trms and flips <= tflip, (str(dtype), i, emax, erms, flips)
+    # image 0 is the golden input of the reference run itself
+    for i in range(3):
+        emax, erms, _ = _err_stats(got[i][:1], torch.from_numpy(golden[f"g5_v_out{i}"]))
+        assert emax <= tmax and erms <= trms, (str(dtype), i, emax, erms)
+    emax, erms, _ = _err_stats(got[3][:1, :, 160:224, 160:224], torch.from_numpy(golden["g5_v_out3_crop"]))
+    assert emax <= 1.5 * tmax and erms <= 1.5 * trms, (str(dtype), emax, erms)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tag", TAGS)
+def test_block_inference_low_precision_against_reference_golden(golden, tag, dtype):
+    """the nine G4 blocks with 16-bit activations / GEMM weights against the reference's fp32 outputs"""
+    import tramba_amd as ta
+    ctor, shape = _blocks()[tag]
+    m = _load_synth(ctor())
+    for mod in m.modules():            # the prepare_inference policy on a bare block
+        if isinstance(mod, ta.Linear2d):
+            mod.weight.data = mod.weight.data.to(dtype)
+        elif isinstance(mod, ta.SS2D):
+            mod.x_proj_weight.data = mod.x_proj_weight.data.to(dtype)
+    x = synth.synth_input("g4_" + tag, shape).to(DEV, dtype)
+    with torch.no_grad():
+        y = m(x).float().cpu()
+    emax, erms, _ = _err_stats(y, torch.from_numpy(golden[f"g4_{tag}_y"]))
+    tmax, trms = (0.08, 0.012) if dtype == torch.bfloat16 else (0.01, 0.0015)
+    assert emax <= tmax and erms <= trms, (tag, str(dtype), emax, erms)
+
+
+def test_tramba_r_384_matches_reference_golden(golden):
+    """Tramba-Res at the reference's own resolution against the reference forward (G5: Trambav6_enc.py:131-159)"""
+    import tramba_amd as ta
+    m = _load_synth(ta.bulid_model_enc("Tramba-R-TSOD", img_size=384))
+    x = synth.synth_input("g5_r", (1, 3, 384, 384)).to(DEV)
+    with torch.no_grad():
+        outs = m(x)
+    assert [tuple(o.shape) for o in outs] == [(1, 1, 48, 48), (1, 1, 96, 96), (1, 1, 384, 384)]
+    for i in range(2):
+        np.testing.assert_allclose(outs[i].cpu().numpy(), golden[f"g5_r_out{i}"], rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(outs[2][:, :, 160:224, 160:224].cpu().numpy(), golden["g5_r_out2_crop"], rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(torch.nn.functional.avg_pool2d(outs[2], 8).cpu().numpy(), golden["g5_r_out2_pool8"],
+                               rtol=2e-3, atol=1e-3)
+
+
+def test_loss_on_device_matches_oracle_and_reference_constants(golden_meta):
+    """train.py:76-85 / utils/loss.py:6-11 evaluated on the device: the G7 known answers of the reference's own
+    functions and the oracle's restatement on the same deep-supervision pyramid"""
+    from tramba_amd import train
+    pred = synth.synth_input("g7_pred", (2, 1, 24, 24), scale=2.0)
+    mask = (synth.synth_input("g7_mask", (2, 1, 24, 24)) > 0.3).float()
+    pd, md = pred.to(DEV), mask.to(DEV)
+    assert abs(float(train.iou_loss(pd, md)) - golden_meta["G7"]["iou_loss"]) < 1e-6
+    assert abs(float(torch.nn.functional.binary_cross_entropy_with_logits(pd, md)) - golden_meta["G7"]["bce"]) < 1e-6
+    outs = [torch.nn.functional.avg_pool2d(pred, 4), torch.nn.functional.avg_pool2d(pred, 2), pred * 0.5, pred]
+    want = float(oo.tramba_loss(outs, mask))
+    got = float(train.tramba_loss([o.to(DEV) for o in outs], md))
+    assert abs(got - want) < 1e-5 * max(1.0, abs(want)), (got, want)
+    got16 = float(train.tramba_loss([o.to(DEV, torch.bfloat16) for o in outs], md))     # model outputs arrive as bf16
+    assert abs(got16 - want) < 2e-2 * abs(want)
+
+
+def test_reducer_on_a_one_rank_rccl_group():
+    """GradBucketReducer through torch.distributed's nccl backend (= RCCL) with a single rank: the collective code path
+    (ncclAvg all-reduce of the flat buckets launched from autograd hooks, wait, .grad views) runs on the device and leaves
+    exactly the gradients of a plain backward; the same with bf16 buckets up to their rounding."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from tramba_amd import parallel, train
+    import tramba_amd as ta
+    assert not dist.is_initialized()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(0)
+        m = ta.MultiScaleDecoderBlock(hidden_dim=32, drop_path=0.0, channel_first=True).to(DEV).train()
+        x = torch.randn(2, 32, 24, 24, device=DEV)
+        m(x).square().mean().backward()
+        want = {n: p.grad.clone() for n, p in m.named_parameters()}
+        # (two backward passes differ in the last bits: index_add_ / atomic sums of the scan backward)
+        for bdt, tol in ((None, 1e-4), (torch.bfloat16, 1e-2)):
+            red = parallel.GradBucketReducer(m, bucket_mb=0.01, bucket_dtype=bdt)
+            assert red.world == 1 and red._native_avg and len(red.buckets) > 1
+            red.world = 2                      # force the collective path (a one-rank group averages over one rank)
+            red.prepare()
+            m(x).square().mean().backward()
+            red.finish()
+            torch.cuda.synchronize()
+            for n, p in m.named_parameters():
+                assert p.grad is not None and p.grad.dtype == p.dtype, n
+                assert float((p.grad - want[n]).abs().max()) <= tol * float(want[n].abs().max()) + 1e-12, n
+            red.remove_hooks()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_tramba_v_batch4_consistent(tramba_v):
     """images are independent units: a batch of 4 equals four batches of 1."""
     x = torch.randn(4, 3, 384, 384, generator=torch.Generator().manual_seed(0)).to(DEV)

@@ -185,5 +185,9 @@ def test_full_forward_is_batch_independent_and_deterministic():
     for u, v in zip(a, b2):
         assert torch.equal(u, v)
     for u, v in zip(a, one):
-        # kernel schedules depend on the batch (waves per sequence, segment plan), so the rounding differs slightly
-        np.testing.assert_allclose(u[2:3].float().cpu().numpy(), v.float().cpu().numpy(), rtol=0.1, atol=0.15)
+        # Kernel schedules depend on the batch (GEMM tile shapes, waves per sequence, segment plan), so fp32 sums are taken
+        # in another order and some bf16 roundings of the ~100 layers fall the other way: the two runs differ by as much as
+        # either differs from the fp32 reference (measured: RMS 0.025, max 0.09 of the map's RMS; profiles/r02_lowp_parity.json).
+        d = (u[2:3].double() - v.double()).cpu()
+        ref = float(v.double().square().mean().sqrt())
+        assert float(d.square().mean().sqrt()) <= 0.04 * ref and float(d.abs().max()) <= 0.16 * ref

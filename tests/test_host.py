@@ -118,7 +118,53 @@ def test_graph_wrappers_validate_before_touching_the_device():
     with pytest.raises(RuntimeError, match="capturable"):
         ta.GraphedTrainStep(net, torch.optim.Adam(net.parameters(), 1e-3))
 
-    class TwoRanks:
-        world = 2
-    with pytest.raises(RuntimeError, match="single-process"):
-        ta.GraphedTrainStep(net, torch.optim.Adam(net.parameters(), 1e-3, capturable=True), reducer=TwoRanks())
+    class TwoRanksHostRead:                                             # a reducer whose step reads flags on the host
+        world, find_unused = 2, True
+    with pytest.raises(RuntimeError, match="find_unused"):
+        ta.GraphedTrainStep(net, torch.optim.Adam(net.parameters(), 1e-3, capturable=True), reducer=TwoRanksHostRead())
+
+
+def test_load_pretrained_base_follows_the_reference_rules(tmp_path, capsys):
+    """Models/vmamba.py:707-732 on a synthetic VMamba-style checkpoint: `layers.i.downsample.*` -> `downsample.i.*`,
+    classifier keys skipped, unknown keys reported and ignored, (out,in,1,1) conv weights accepted for Linear2d, any
+    other shape mismatch an AssertionError, uncovered parameters left alone and reported."""
+    from tramba_amd.modules import Linear2d, VSSMEncoder, load_pretrained_Base
+    torch.manual_seed(0)
+    src = VSSMEncoder(depths=[1, 1, 1, 1], dims=16, imgsize=64)
+    torch.manual_seed(1)
+    dst = VSSMEncoder(depths=[1, 1, 1, 1], dims=16, imgsize=64)
+    lin = {n + ".weight" for n, m in src.named_modules() if isinstance(m, Linear2d)}
+    left_out = "layers.3.blocks.0.norm.weight"
+    ck = {}
+    for k, v in src.state_dict().items():
+        if k == left_out:
+            continue
+        if k.startswith("downsample."):                                 # VMamba keeps the downsample inside the stage
+            i, rest = k.split(".", 2)[1:]
+            k = f"layers.{i}.downsample.{rest}"
+        ck[k] = v.clone().view(*v.shape, 1, 1) if k in lin else v.clone()
+    assert any(".downsample." in k for k in ck) and any(v.dim() == 4 and v.shape[2:] == (1, 1) for k, v in ck.items() if k in lin)
+    ck["classifier.head.weight"] = torch.randn(1000, 128)
+    ck["classifier.norm.bias"] = torch.randn(128)
+    ck["not_a_module.weight"] = torch.randn(3)
+    path = str(tmp_path / "vssm.pth")
+    torch.save({"model": ck}, path)
+    keep = dst.state_dict()[left_out].clone()
+    assert load_pretrained_Base(dst, ckpt_path=path) is dst
+    out = capsys.readouterr().out
+    assert "Passing weights: classifier.head.weight" in out and "Module can not find: not_a_module.weight" in out
+    assert f"Module {left_out} has not been inited!" in out and out.count("has not been inited") == 1
+    got, want = dst.state_dict(), src.state_dict()
+    assert list(got) == list(want)
+    for k in want:
+        assert torch.equal(got[k], keep if k == left_out else want[k]), k
+    bad = dict(ck)
+    bad["patch_embed.0.bias"] = torch.randn(ck["patch_embed.0.bias"].numel() + 1)
+    torch.save({"model": bad}, path)
+    with pytest.raises(AssertionError, match="Shape mismatch"):
+        load_pretrained_Base(dst, ckpt_path=path)
+    bad = dict(ck)
+    bad["layers.3.downsample.1.weight"] = torch.randn(2)               # the last stage has no downsample to rename to
+    torch.save({"model": bad}, path)
+    with pytest.raises(AssertionError):
+        load_pretrained_Base(dst, ckpt_path=path)

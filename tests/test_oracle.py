@@ -25,7 +25,7 @@ def test_line_tables_other_sizes(golden_meta, h):
     assert [st.table_hash(r) for r in st.line_table(h, h)] == golden_meta["G1"][f"line_{h}"]
 
 
-@pytest.mark.parametrize("h,ws", [(16, 4), (32, 8), (64, 16), (192, 16)])
+@pytest.mark.parametrize("h,ws", [(16, 4), (16, 8), (32, 8), (64, 16), (192, 16)])
 def test_offtable_generators(golden_meta, h, ws):
     g1 = golden_meta["G1"]
     assert [st.table_hash(r) for r in st.dilation_table(h, h)] == g1[f"dilation_{h}"]

@@ -65,16 +65,12 @@ def test_fit_only_main_rank_writes(tmp_path):
     assert not (tmp_path / "T").exists()
 
 
-def test_token_split_weight_gradient_matches_plain_gemm():
-    """_wgrad_tall: gy^T @ x with the token dimension split into chunks of >= 2048 (fp32 partial sums) == one GEMM."""
-    from tramba_amd.modules import _wgrad_tall
-    g = torch.Generator().manual_seed(3)
-    for m, n, k in ((2048 * 8, 24, 16), (2048 * 5, 8, 12), (4096 + 2048, 16, 8), (1000, 8, 8)):
-        gy, x = torch.randn(m, n, generator=g), torch.randn(m, k, generator=g)
-        want = gy.double().t() @ x.double()
-        got = _wgrad_tall(gy, x)
-        assert got.dtype == torch.float32 and got.shape == (n, k)
-        np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=1e-4, atol=1e-3)
-        # non-contiguous operands (a transposed view) take the same path
-        got2 = _wgrad_tall(gy.t().contiguous().t(), x)
-        np.testing.assert_allclose(got2.double().numpy(), want.numpy(), rtol=1e-4, atol=1e-3)
+def test_bf16_split_is_exact_to_fp32_resolution():
+    """_split16: the fp32 validation mode feeds the 16-bit matrix-core kernels hi + lo bf16 pieces (three passes); the
+    two pieces must carry the fp32 value to 2^-16 relative, so that hi.hi + hi.lo + lo.hi is an fp32-grade product."""
+    from tramba_amd.modules import _split16
+    t = torch.randn(4096, generator=torch.Generator().manual_seed(3)) * torch.logspace(-3, 3, 4096)
+    hi, lo = _split16(t)
+    assert hi.dtype == lo.dtype == torch.bfloat16
+    rel = ((hi.double() + lo.double()) - t.double()).abs() / t.double().abs()
+    assert float(rel.max()) < 2.0 ** -15

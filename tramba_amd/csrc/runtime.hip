@@ -59,6 +59,15 @@ using namespace tramba;
 extern "C" const char *tramba_last_error(void) { return g_err; }
 extern "C" int tramba_abi_version(void) { return 1; }
 
+static int g_tune[TRAMBA_TUNE_COUNT] = {0};
+extern "C" int tramba_tune_set(int knob, int value)
+{
+    TRAMBA_CHECK(knob >= 0 && knob < TRAMBA_TUNE_COUNT, "tune knob %d out of range", knob);
+    g_tune[knob] = value;
+    return TRAMBA_OK;
+}
+extern "C" int tramba_tune_get(int knob) { return knob >= 0 && knob < TRAMBA_TUNE_COUNT ? g_tune[knob] : 0; }
+
 extern "C" int tramba_profile_enable(int which, int enable)
 {
     TRAMBA_CHECK(which >= 0 && which < TRAMBA_PROF_COUNT, "profile class %d out of range", which);

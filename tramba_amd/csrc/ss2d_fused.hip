@@ -942,13 +942,22 @@ template <typename TY, typename T, int V, int NIT, int BATCH>
 __global__ __launch_bounds__(256) void ss2d_merge_norm_stream_kernel(
     const TY *__restrict__ ys, const int32_t *__restrict__ inv_ptr, const int32_t *__restrict__ inv_idx,
     const float *__restrict__ ln_w, const float *__restrict__ ln_b, T *__restrict__ y, long nwaves, int nchunk,
-    int P, int L, int D, int K, float eps, int act)
+    int P, int L, int D, int K, float eps, int act, int B, int H)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const long wid = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wid >= nwaves) return;   // wave-uniform, no barriers below
-    const int b = (int)((unsigned)wid / (unsigned)nchunk);   // 32-bit: nwaves < 2^31 (host-checked)
-    const int pl0 = (int)((unsigned)wid % (unsigned)nchunk) * P;
+    int b, pl0;   // 32-bit: nwaves < 2^31 (host-checked)
+    if (H > 0) {  // many-to-one table on a square map whose rows are whole chunks: image rows centre-out (long pixels first)
+        const unsigned cpr = (unsigned)(L / H) / (unsigned)P, per = (unsigned)B * cpr;
+        const unsigned rank = (unsigned)wid / per, rem = (unsigned)wid % per;
+        b = (int)(rem / cpr);
+        const int row = H / 2 + ((rank & 1u) ? -(int)((rank + 1) >> 1) : (int)(rank >> 1));
+        pl0 = row * (L / H) + (int)(rem % cpr) * P;
+    } else {
+        b = (int)((unsigned)wid / (unsigned)nchunk);
+        pl0 = (int)((unsigned)wid % (unsigned)nchunk) * P;
+    }
     const int np = L - pl0 < P ? L - pl0 : P;   // pixels of this wave
 
     // CSR window: pointers of pixels pl0 .. pl0+np in lanes 0..np, then 64 entries from the first one
@@ -1137,15 +1146,15 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_deep_kernel(
         auto row_off = [&](int j) -> unsigned {   // j wave-uniform, < cn
             return (unsigned)__builtin_amdgcn_readlane(ent, j) * srow;
         };
+        Raw t0[RB][NIT], t1[RB][NIT];
         if (cn <= RB) {
             // short pixel: every row requested before any is summed (wave-uniform guards, no wasted requests)
-            Raw t[RB][NIT];
 #pragma unroll
             for (int j = 0; j < RB; ++j)
                 if (j < cn) {
                     const unsigned so = row_off(j);
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) t[j][it] = buf_load_pack<TY, V>(rs, coff[it], so);
+                    for (int it = 0; it < NIT; ++it) t0[j][it] = buf_load_pack<TY, V>(rs, coff[it], so);
                 }
 #pragma unroll
             for (int j = 0; j < RB; ++j)
@@ -1153,7 +1162,7 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_deep_kernel(
 #pragma unroll
                     for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                        for (int v = 0; v < V; ++v) acc[it][v] += Cvt<TY>::to_f(t[j][it].v[v]);
+                        for (int v = 0; v < V; ++v) acc[it][v] += Cvt<TY>::to_f(t0[j][it].v[v]);
         } else {
             // long pixel: batches of RB rows on two static buffers, branch-free
             const int nb = (cn + RB - 1) / RB;
@@ -1176,7 +1185,6 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_deep_kernel(
                         for (int v = 0; v < V; ++v) acc[it][v] = fmaf(Cvt<TY>::to_f(t[j][it].v[v]), wr, acc[it][v]);
                 }
             };
-            Raw t0[RB][NIT], t1[RB][NIT];
             issue(0, t0);
             for (int q = 0; q < nb; q += 2) {
                 issue(q + 1, t1);
@@ -1487,13 +1495,25 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
     // Streaming form (measured, scripts/bench_scan.py): wins where one batch covers a pixel (K <= 4), the row
     // is at most two wave iterations and the map is large enough to fill the chip with 16-pixel waves
     // (6 TB/s on 96x96 D=256); elsewhere one wave per pixel is faster.
+    ProfScope prof(TRAMBA_PROF_MERGE, s, (double)batch * k * l * (double)d * dtype_size(ys_dtype) +
+                                              (double)batch * l * (double)d * dtype_size(dtype));
     const bool sum_only = eps < 0.f;   // no LayerNorm: only the per-pixel form implements it
-    const bool stream_form = !sum_only && k <= 4 && nit <= 2 && npix >= 8192 && (double)k * l * d * 4.0 < 4294967296.0;
-    const int pw = 16;
+    const int tune = tramba_tune_get(TRAMBA_TUNE_MERGE_FORM);
+    const bool stream_ok = !sum_only && nit <= 2 && k <= 8 && (double)k * l * d * 4.0 < 4294967296.0;
+    const bool stream_form = stream_ok && (tune == 2 || (tune == 0 && k <= 4 && npix >= 8192));
+    const bool wide = k > 4;               // 8 rows per batch, 4 pixels per wave (a Helix pixel lists >= 6 entries)
+    const int pw = wide ? 4 : 16;
     const int nchunk = (l + pw - 1) / pw;
     const long nwaves = (long)batch * nchunk;
+    int hs = 0;                            // many-to-one tables on square maps: image rows centre-out
+    if (wide) {
+        hs = 1;
+        while ((long)hs * hs < l) ++hs;
+        if ((long)hs * hs != l || hs % pw != 0) hs = 0;
+    }
     // split-row form: a wide row (>= 4 wave iterations) on a map too small to fill the chip one wave per pixel
-    const bool split_form = !sum_only && !stream_form && nit >= 4 && npix <= 16384;
+    // (fp32 ys only: with 2-byte rows the one-wave-per-pixel form with 16-byte accesses is faster, 19.6 vs 26.5 us at 24x24 D=1024)
+    const bool split_form = !sum_only && !stream_form && tune != 1 && ys_dtype == TRAMBA_F32 && nit >= 4 && npix <= 16384;
     if (!stream_form && !split_form) {
         // one wave per pixel, deep row pipeline (Helix tables, small maps, merge-only): widest access that keeps 64 lanes
         // busy, 16 bytes at most
@@ -1534,10 +1554,14 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
     if (split_form)                                                                                           \
         hipLaunchKernelGGL((ss2d_merge_norm_split_kernel<TY, T, V_, (N_ >= 4 ? N_ : 4), 4>), grid, block, 0, s, \
                            (const TY *)ys, inv_ptr, inv_idx, ln_w, ln_b, (T *)y, npix, l, d, k, eps, act);    \
+    else if (wide)                                                                                            \
+        hipLaunchKernelGGL((ss2d_merge_norm_stream_kernel<TY, T, V_, (N_ <= 2 ? N_ : 2), 8>), grid, block, 0, s, \
+                           (const TY *)ys, inv_ptr, inv_idx, ln_w, ln_b, (T *)y, nwaves, nchunk, pw, l, d, k, eps, \
+                           act, batch, hs);                                                                   \
     else                                                                                                      \
         hipLaunchKernelGGL((ss2d_merge_norm_stream_kernel<TY, T, V_, (N_ <= 2 ? N_ : 2), 4>), grid, block, 0, s, \
                            (const TY *)ys, inv_ptr, inv_idx, ln_w, ln_b, (T *)y, nwaves, nchunk, pw, l, d, k, eps, \
-                           act)
+                           act, batch, 0)
 #define BY_N_(TY, T, V_)               \
     if (nit == 1) { GO_(TY, T, V_, 1); }   \
     else if (nit == 2) { GO_(TY, T, V_, 2); } \

@@ -65,8 +65,10 @@ class GraphedTrainStep:
     as ONE hipGraph and replayed per batch -- the eager step issues ~6000 launches from Python.
 
     Requirements: an optimizer built with `capturable=True` (`train.get_opt(lr, model, capturable=True)`: Adam's step
-    counters live on the device); single process (`reducer` must be None or a world-size-1 reducer: the RCCL all-reduce of
-    the data-parallel path stays on eager launches).  One graph per batch shape (a short last batch of an epoch gets its
+    counters live on the device).  With a data-parallel `reducer` (world size > 1) the bucketed RCCL all-reduces launched
+    from the autograd hooks are captured with the step (RCCL's stream joins the capture through the usual event edges) and
+    replayed as graph nodes: every rank must capture and replay the same sequence (same batch shapes per step), and the
+    reducer must not use `find_unused` (its host read of the flag vector cannot be captured).  One graph per batch shape (a short last batch of an epoch gets its
     own).  Learning rates are baked into the captured kernels: the graphs are dropped and re-captured when
     `adjust_learning_rate` changes them.  A capture needs eager warm-up steps (optimizer state and lazy caches must exist
     before the stream is captured); parameters and optimizer state are saved before and restored after them, so every call
@@ -74,8 +76,9 @@ class GraphedTrainStep:
     from torch's device generator, which hipGraph capture advances per replay.  Returns the loss (a static buffer)."""
 
     def __init__(self, model, opt, reducer=None, warmup=2):
-        if reducer is not None and getattr(reducer, "world", 1) > 1:
-            raise RuntimeError("GraphedTrainStep is single-process; use train_step with the reducer for data parallel")
+        if reducer is not None and getattr(reducer, "world", 1) > 1 and getattr(reducer, "find_unused", False):
+            raise RuntimeError("GraphedTrainStep: a reducer with find_unused=True reads flags on the host every step and "
+                               "cannot be captured")
         if not all(g.get("capturable", False) for g in opt.param_groups):
             raise RuntimeError("GraphedTrainStep needs an optimizer with capturable=True")
         self.model, self.opt, self.reducer, self.warmup = model, opt, reducer, warmup

@@ -20,7 +20,7 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_SIGMOID_GATE = 0, 1, 2, 3
 SCAN_RASTER, SCAN_LINE, SCAN_HELIX, SCAN_WINDOW, SCAN_DILATION = range(5)
 FAMILY = {"raster": SCAN_RASTER, "line": SCAN_LINE, "helix": SCAN_HELIX, "window": SCAN_WINDOW,
           "dilation": SCAN_DILATION}
-PROF_SCAN_BOUNDARY, PROF_SCAN_FUSED, PROF_GEMM = 0, 1, 2
+PROF_SCAN_BOUNDARY, PROF_SCAN_FUSED, PROF_GEMM, PROF_MERGE = 0, 1, 2, 3
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -30,6 +30,8 @@ c_int, c_i64, c_f, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c
 SIGNATURES = {
     "tramba_last_error": (ctypes.c_char_p, []),
     "tramba_abi_version": (c_int, []),
+    "tramba_tune_set": (c_int, [c_int, c_int]),
+    "tramba_tune_get": (c_int, [c_int]),
     "tramba_profile_enable": (c_int, [c_int, c_int]),
     "tramba_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "tramba_profile_min_units": (c_int, [c_int, ctypes.c_double]),
@@ -62,6 +64,10 @@ SIGNATURES = {
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_linear2_cl": (c_int, [c_vp, c_vp, c_int] + [c_vp] * 4 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_wgrad_workspace": (ctypes.c_size_t, [c_i64, c_int, c_int, c_int, c_int]),
+    "tramba_wgrad_cl": (c_int, [c_vp] * 4 + [ctypes.c_size_t, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_int, c_i64,
+                                             c_i64, c_int, c_int, c_int, c_vp]),
+    "tramba_rows_gemm_cl": (c_int, [c_vp] * 3 + [c_int, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_expand_norm_head_cl": (c_int, [c_vp] * 5 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_conv3x3s2_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
     "tramba_stem_conv_ln_gelu": (c_int, [c_vp] * 6 + [c_int] * 3 + [c_f, c_int, c_int, c_vp]),
@@ -198,7 +204,15 @@ def scan_order(family: str, h: int, w: int, device, param: int = 0) -> ScanOrder
     return so
 
 
-# ----------------------------------------------------------------------------- profiling
+# ----------------------------------------------------------------------------- profiling / tuning
+TUNE_MERGE_FORM, TUNE_SCAN_FORM = 0, 1
+
+
+def tune_set(knob: int, value: int):
+    """kernel-variant selection for A/B timing scripts (0 = the library's own choice)"""
+    _check(lib().tramba_tune_set(knob, value), "tune_set")
+
+
 def profile_enable(which: int, on: bool):
     _check(lib().tramba_profile_enable(which, int(on)), "profile_enable")
 
@@ -536,6 +550,68 @@ def linear2_cl(x1, x2, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None
     y = torch.empty(x1.shape[:-1] + (n,), dtype=out_dtype, device=x1.device)
     _check(lib().tramba_linear2_cl(_ptr(x1), _ptr(x2), k1, _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), m, n, k1 + k2,
                                    act, dt(x1), dt(y), _stream()), "linear2_cl")
+    return y
+
+
+def wgrad_cl(gy, x, want_bias=False):
+    """Weight gradient of y = x @ W^T: gy (..., N), x (..., K) 16-bit, same leading shape -> (gw (N, K) f32, gb (N) f32 or
+    None).  Rows may be strided (a column slice of a wider tensor) as long as the last dim is contiguous."""
+    n, k = gy.shape[-1], x.shape[-1]
+    gy2, x2 = gy.reshape(-1, n), x.reshape(-1, k)
+    if gy2.stride(-1) != 1 or x2.stride(-1) != 1:
+        gy2, x2 = gy2.contiguous(), x2.contiguous()
+    m = gy2.shape[0]
+    if x2.shape[0] != m or gy2.dtype != x2.dtype:
+        raise TrambaHipError("wgrad_cl: gy / x mismatch")
+    return _wgrad(gy2, x2, m, n, k, 1, 1, 0, 0, gy2.stride(0), 0, 0, x2.stride(0), want_bias)
+
+
+def wgrad_grouped_cl(gy, x):
+    """gy (B, G, L, N), x (B, G, L, K) 16-bit contiguous -> (G, N, K) f32: per group g, sum over b and l of gy^T x."""
+    _dev(gy, x)
+    b, g, l, n = gy.shape
+    k = x.shape[-1]
+    if x.shape[:3] != gy.shape[:3] or gy.dtype != x.dtype:
+        raise TrambaHipError("wgrad_grouped_cl: gy / x mismatch")
+    out, _ = _wgrad(gy, x, l, n, k, g, b, g * l * n, l * n, n, g * l * k, l * k, k, False)
+    return out
+
+
+def tn_shared_cl(a, x):
+    """out[g] = a^T @ x[g]: a (T, N) 16-bit shared by every group, x (G, T, K) same dtype -> (G, N, K) f32 -- a separable
+    transform along a leading axis of a channels-last tensor (the DCT backward: T = coefficients, N = pixels)."""
+    _dev(a, x)
+    t, n = a.shape
+    g, t2, k = x.shape
+    if t2 != t or a.dtype != x.dtype:
+        raise TrambaHipError("tn_shared_cl: operand shapes / dtypes do not match")
+    out, _ = _wgrad(a, x, t, n, k, g, 1, 0, 0, n, 0, t * k, k, False)
+    return out if g > 1 else out.view(1, n, k)
+
+
+def _wgrad(gy, x, m, n, k, groups, nbatch, gy_bs, gy_gs, gy_ld, x_bs, x_gs, x_ld, want_bias):
+    for t in (gy, x):
+        if not t.is_cuda:
+            raise TrambaHipError("tramba_amd kernels need tensors on a HIP device (no CPU fallback)")
+    ws_bytes = lib().tramba_wgrad_workspace(m, n, k, groups, nbatch)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=gy.device)
+    out = torch.empty((groups, n * k + n), dtype=torch.float32, device=gy.device)
+    _check(lib().tramba_wgrad_cl(_ptr(gy), _ptr(x), _ptr(out), _ptr(ws), ws_bytes, m, n, k, groups, nbatch, gy_bs, gy_gs,
+                                 gy_ld, x_bs, x_gs, x_ld, int(want_bias), dt(gy), _stream()), "wgrad_cl")
+    gw = out[:, :n * k].view(groups, n, k)
+    if groups == 1:
+        return gw[0], (out[0, n * k:] if want_bias else None)
+    return gw, None
+
+
+def rows_gemm_cl(x, w, y, n):
+    """y[z, t, :n] = x[z, t, :] @ w[z % G]^T: x (Z, M, K) 16-bit, w (G, n, K) same dtype, y (Z, M, ldy) f32 (in place)."""
+    _dev(x, w, y)
+    z, m, k = x.shape
+    if w.shape[1:] != (n, k) or w.dtype != x.dtype or y.dtype != torch.float32 or y.shape[:2] != (z, m):
+        raise TrambaHipError("rows_gemm_cl: operand shapes / dtypes do not match")
+    _check(lib().tramba_rows_gemm_cl(_ptr(x), _ptr(w), _ptr(y), z, m, n, k, w.shape[0], y.shape[-1], dt(x), _stream()),
+           "rows_gemm_cl")
     return y
 
 

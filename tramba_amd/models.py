@@ -89,9 +89,8 @@ class VSSMDecoder(nn.Module):
         if _infer(x, conv.weight) and x.shape[-1] % 8 == 0:
             y = hip.rowdot_cl(x, hip._f32(conv.weight).view(-1), _bias_scalar(conv))
             return y.unsqueeze(1)
-        w = conv.weight.view(1, -1).to(x.dtype)
-        y = F.linear(x, w, conv.bias.to(x.dtype))
-        return y.permute(0, 3, 1, 2)
+        from .modules import _RowDotCL
+        return _RowDotCL.apply(x, conv.weight, conv.bias).unsqueeze(1)
 
     def _final_cl(self, x_low):
         """Last decoder stage: FinalPatchExpand_X4 -> (Identity) -> seg head.  Inference fuses pixel-shuffle +

@@ -95,36 +95,68 @@ def _act_torch(x, act):
     return x
 
 
-class _ConvNative(torch.autograd.Function):
-    """Convolutions of the TRAINING path with autograd: PyTorch's native kernels (depth-wise kernels /
-    im2col + GEMM), forward and backward, with MIOpen bypassed -- its channels-last grouped-conv and
-    bwd-weight kernels are 10-100x slower on these shapes (scripts/probe_dw.py, profiles/).  The inference
-    path uses tramba_dwconv_cl / tramba_conv3x3s2_cl instead."""
+def _split16(t):
+    """fp32 -> (hi, lo) bf16 with hi + lo == t to 2^-17 relative: the 16-bit matrix-core kernels serve the fp32 validation
+    mode by three passes (hi.hi + hi.lo + lo.hi)."""
+    hi = t.to(torch.bfloat16)
+    return hi, (t - hi.float()).to(torch.bfloat16)
+
+
+def _wgrad(gy2, x2, want_bias=False):
+    """Weight (and bias) gradient of y = x @ W^T: gy2 (M, N), x2 (M, K) -> gw (N, K) f32 [, gb (N) f32], on
+    tramba_wgrad_cl (token-split TN GEMM, transposed LDS reads)."""
+    if gy2.dtype != torch.float32:
+        return hip.wgrad_cl(gy2, x2, want_bias)
+    gh, gl = _split16(gy2)
+    xh, xl = _split16(x2)
+    gw = hip.wgrad_cl(gh, xh)[0] + hip.wgrad_cl(gh, xl)[0] + hip.wgrad_cl(gl, xh)[0]
+    return gw, (gy2.sum(0) if want_bias else None)
+
+
+def _dgrad(gy2, wa):
+    """Input gradient of y = x @ W^T: gy2 (M, N) @ wa (N, K) on the forward GEMM kernel, with the weight transposed once."""
+    return hip.linear_cl(gy2, wa.t().contiguous())
+
+
+class _ConvIm2colCL(torch.autograd.Function):
+    """A dense convolution of the TRAINING path on a channels-last map with autograd (the four 3x3 / stride-2 convs of
+    the VMamba stem and downsample layers, vmamba.py:454,481,486): im2col (torch's native unfold / fold kernels, pure
+    data movement) around the library's own GEMMs -- forward and input gradient on tramba_linear_cl, weight / bias
+    gradient on tramba_wgrad_cl.  x (B,H,W,Cin), w (Cout,Cin,kh,kw), b (Cout) or None -> (B,Ho,Wo,Cout)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, groups):
-        ctx.save_for_backward(x, w)
-        ctx.cfg = (tuple(stride), tuple(padding), groups, b is not None)
-        with torch.backends.cudnn.flags(enabled=False):
-            return F.conv2d(x, w, b, stride=stride, padding=padding, groups=groups)
+    def forward(ctx, x, w, b, stride, padding):
+        bsz, h, wd, cin = x.shape
+        cout, _, kh, kw = w.shape
+        cols = F.unfold(x.permute(0, 3, 1, 2), (kh, kw), padding=padding, stride=stride)      # (B, Cin*kh*kw, L)
+        ck = cin * kh * kw
+        ckp = (ck + 7) // 8 * 8                                                                # 16-byte rows for the kernels
+        ct = cols.transpose(1, 2)
+        ct = F.pad(ct, (0, ckp - ck)) if ckp != ck else ct.contiguous()                        # (B, L, CKp)
+        w2 = w.detach().reshape(cout, ck).to(x.dtype)
+        if ckp != ck:
+            w2 = F.pad(w2, (0, ckp - ck))
+        ho = (h + 2 * padding[0] - kh) // stride[0] + 1
+        wo = (wd + 2 * padding[1] - kw) // stride[1] + 1
+        y = hip.linear_cl(ct.view(-1, ckp), w2.contiguous(), None if b is None else b.detach().float().contiguous())
+        ctx.save_for_backward(ct, w2)
+        ctx.cfg = (tuple(stride), tuple(padding), (kh, kw), (h, wd), cin, ck, b is not None, w.dtype, w.shape)
+        return y.view(bsz, ho, wo, cout)
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        stride, padding, groups, has_bias = ctx.cfg
-        # dense convs: the weight gradient is a GEMM whose reduction runs over all B*Ho*Wo output pixels and whose output
-        # is Cout x 9 Cin -- the native kernel does it per sample with one tile (1 ms for the first stem conv); im2col once
-        # and the token-split batched GEMM of _wgrad_tall instead
-        own_gw = groups == 1 and ctx.needs_input_grad[1] and x.dim() == 4
-        with torch.backends.cudnn.flags(enabled=False):
-            gx, gw, gb = torch.ops.aten.convolution_backward(
-                gy.contiguous(), x, w, [w.shape[0]] if has_bias else None, list(stride), list(padding), [1, 1], False,
-                [0, 0], groups, [ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not own_gw, has_bias])
-        if own_gw:
-            cols = F.unfold(x, w.shape[-2:], padding=padding, stride=stride)           # (B, Cin*kh*kw, L)
-            gy2 = gy.flatten(2).transpose(1, 2).reshape(-1, gy.shape[1])                 # (B*L, Cout)
-            gw = _wgrad_tall(gy2, cols.transpose(1, 2).reshape(gy2.shape[0], -1)).view_as(w).to(w.dtype)
-        return gx, gw, gb, None, None, None
+        ct, w2 = ctx.saved_tensors
+        stride, padding, ks, hw, cin, ck, has_bias, wdtype, wshape = ctx.cfg
+        bsz = gy.shape[0]
+        gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gct = _dgrad(gy2, w2)[:, :ck].reshape(bsz, -1, ck).transpose(1, 2)                 # (B, Cin*kh*kw, L)
+            gx = F.fold(gct, hw, ks, padding=padding, stride=stride).permute(0, 2, 3, 1).contiguous()
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gw, gb = _wgrad(gy2, ct.view(gy2.shape[0], -1), has_bias)
+            gw = gw[:, :ck].reshape(wshape).to(wdtype)
+        return gx, gw, gb, None, None
 
 
 class _DwConvCL(torch.autograd.Function):
@@ -211,21 +243,6 @@ class DropPath(nn.Module):
 
 
 # ----------------------------------------------------------------------------- basic layers
-def _wgrad_tall(gy2, x2):
-    """gy2 (M, N)^T @ x2 (M, K) -> (N, K) fp32 for the weight gradient of a 1x1 convolution: M = B*H*W tokens is the
-    reduction dimension (73728 at 96x96, batch 8) and N x K is at most 1024 x 1024, so a plain GEMM has 8..64 output
-    tiles for 256 CUs (hipBLASLt: 216-252 us at M = 73728).  Split the tokens into S chunks, one batched GEMM with fp32
-    partial sums added afterwards: 41 us, and closer to the fp64 result than the single bf16-output GEMM (2.0e-3 against
-    3.6e-3 relative; scripts/micro/wgrad_splitk.py)."""
-    m = gy2.shape[0]
-    s = 1
-    while s < 32 and m // (2 * s) >= 2048 and m % (2 * s) == 0:
-        s *= 2
-    if s < 4:
-        return torch.mm(gy2.t(), x2).float()
-    return torch.bmm(gy2.reshape(s, m // s, -1).transpose(1, 2), x2.reshape(s, m // s, -1)).float().sum(0)
-
-
 # Low-precision shadows of the fp32 master weights for the training forward: 250 per-layer `weight.to(bf16)` kernels per
 # step become one multi-tensor copy after the optimizer step (train.train_step -> refresh_lowp_shadows).  A shadow is used
 # only while the parameter's version counter still equals the one it was cast at; otherwise the layer casts as before.
@@ -278,27 +295,59 @@ def _lowp(p, dtype):
 
 
 class _LinearTrainCL(torch.autograd.Function):
-    """y = x @ w^T + b on channels-last activations with autograd (training path): forward and input gradient are
-    library GEMMs, the weight gradient is the split-token form above, produced in fp32 (no cast kernel afterwards)."""
+    """y = x @ w^T + b on channels-last activations with autograd (training path), all on the library's matrix-core
+    kernels: forward and input gradient tramba_linear_cl (bias in the epilogue), weight / bias gradient tramba_wgrad_cl
+    (fp32 out, no cast kernel afterwards)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
-        wa = _lowp(w, x.dtype)
-        ctx.save_for_backward(x, wa)
-        ctx.wdtype, ctx.has_bias = w.dtype, b is not None
-        return F.linear(x, wa, None if b is None else _lowp(b, x.dtype))
+        wa = _lowp(w, x.dtype).detach().contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        ctx.save_for_backward(x2, wa)
+        ctx.wdtype, ctx.has_bias, ctx.xshape = w.dtype, b is not None, x.shape
+        y = hip.linear_cl(x2, wa, None if b is None else b.detach().float().contiguous())
+        return y.view(x.shape[:-1] + (wa.shape[0],))
 
     @staticmethod
     def backward(ctx, gy):
-        x, wa = ctx.saved_tensors
+        x2, wa = ctx.saved_tensors
         gx = gw = gb = None
         gy2 = gy.reshape(-1, gy.shape[-1])
+        gy2 = gy2 if gy2.is_contiguous() and gy2.dtype == x2.dtype else gy2.to(x2.dtype).contiguous()
         if ctx.needs_input_grad[0]:
-            gx = torch.matmul(gy, wa)
+            gx = _dgrad(gy2, wa).view(ctx.xshape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = _wgrad(gy2, x2, ctx.has_bias)
+            gw = gw.to(ctx.wdtype)
+        return gx, gw, gb
+
+
+class _RowDotCL(torch.autograd.Function):
+    """A C -> 1 segmentation head (nn.Conv2d(C, 1, 1), Trambav6.py:82,130) on a channels-last map with autograd:
+    forward tramba_rowdot_cl (fp32 logits), weight gradient on tramba_wgrad_cl (the one output channel padded to the
+    kernel's 8-channel granule)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        wf = w.detach().float().reshape(-1).contiguous()
+        ctx.save_for_backward(x, wf)
+        ctx.wshape, ctx.wdtype = w.shape, w.dtype
+        return hip.rowdot_cl(x, wf, 0.0) + b.detach().float()
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wf = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (gy.unsqueeze(-1) * wf).to(x.dtype)
         if ctx.needs_input_grad[1]:
-            gw = _wgrad_tall(gy2, x.reshape(-1, x.shape[-1])).to(ctx.wdtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy2.sum(0, dtype=torch.float32)
+            g8 = torch.zeros((gy.numel(), 8), dtype=x.dtype, device=x.device)
+            g8[:, 0] = gy.reshape(-1)
+            gw = _wgrad(g8, x.view(-1, x.shape[-1]))[0][0].reshape(ctx.wshape).to(ctx.wdtype)
+        if ctx.needs_input_grad[2]:
+            gb = gy.sum().reshape(1)
         return gx, gw, gb
 
 
@@ -493,6 +542,50 @@ class DCT2DSpatialTransformLayer_y(nn.Module):
         self.register_buffer("weight", _dct_filter(height))
 
 
+def _tn_f32(a32, x):
+    """a32 (T, N) fp32 coefficients, x (G, T, K) activations -> a^T @ x[g] in fp32 accuracy on the 16-bit TN kernel:
+    the coefficient matrix enters as bf16 hi + lo (two passes); fp32 data is split the same way (a third pass)."""
+    n = a32.shape[1]
+    if n % 8:                                   # the kernel moves 16-byte rows: pad the (tiny) coefficient matrix
+        a32 = F.pad(a32, (0, 8 - n % 8))
+    ah, al = _split16(a32)
+    if x.dtype == torch.bfloat16:
+        out = hip.tn_shared_cl(ah, x) + hip.tn_shared_cl(al, x)
+    else:
+        xh, xl = _split16(x.float())
+        out = hip.tn_shared_cl(ah, xh) + hip.tn_shared_cl(al, xh) + hip.tn_shared_cl(ah, xl)
+    return out[:, :n] if out.shape[1] != n else out
+
+
+class _DCTSplitCL(torch.autograd.Function):
+    """DCT split with autograd (training path).  Forward = the inference kernel (tramba_dct_split_cl: LL and HH quadrants
+    of Wy X Wx^T).  Backward: gX = Wy_lo^T gLow Wx_lo + Wy_hi^T gHigh Wx_hi -- each term two TN contractions on the
+    library's grouped matrix-core kernel (over the coefficient index of W, then of H), coefficients in fp32 accuracy."""
+
+    @staticmethod
+    def forward(ctx, x, wx, wy):
+        ctx.save_for_backward(wx, wy)
+        ctx.xdtype = x.dtype
+        return hip.dct_split_cl(x.contiguous(), wx, wy)
+
+    @staticmethod
+    def backward(ctx, g_high, g_low):
+        wx, wy = ctx.saved_tensors
+        n = wx.shape[0]
+        h2 = n // 2
+        gx = None
+        for g, lo in ((g_low, True), (g_high, False)):
+            if g is None:
+                continue
+            bsz, _, _, c = g.shape
+            wxq = (wx[:h2] if lo else wx[h2:]).float().contiguous()       # (U, W): coefficient-major = the TN "a" operand
+            wyq = (wy[:h2] if lo else wy[h2:]).float().contiguous()       # (V, H)
+            z1 = _tn_f32(wxq, g.contiguous().view(bsz * h2, h2, c))       # (B*V, W, C): contracted over u
+            z2 = _tn_f32(wyq, z1.reshape(bsz, h2, n * c))                 # (B, H, W*C): contracted over v
+            gx = z2 if gx is None else gx + z2
+        return gx.view(-1, n, n, g_high.shape[-1] if g_high is not None else g_low.shape[-1]).to(ctx.xdtype), None, None
+
+
 class DCT2D(nn.Module):
     """DCT_2D.py:6-29: Y = Wy X Wx^T; returns (high = HH quadrant, low = LL quadrant)."""
 
@@ -507,10 +600,7 @@ class DCT2D(nn.Module):
             raise RuntimeError(f"DCT2D built for {wy.shape[0]}x{wx.shape[0]}, got {x.shape[1]}x{x.shape[2]}")
         if _infer(x):
             return hip.dct_split_cl(x, _f32(wx), _f32(wy))
-        y = torch.einsum("bhwc,uw->bhuc", x.float(), wx.float())
-        y = torch.einsum("bhuc,vh->bvuc", y, wy.float()).to(x.dtype)
-        hh, hw = y.shape[1] // 2, y.shape[2] // 2
-        return y[:, hh:, hw:].contiguous(), y[:, :hh, :hw].contiguous()
+        return _DCTSplitCL.apply(x, _f32(wx), _f32(wy))
 
     def forward(self, x):
         _need_device(x)
@@ -563,7 +653,7 @@ def D_init(d_inner, copies=-1, device=None, merge=True):
 # ----------------------------------------------------------------------------- SS2D
 class _LinearF32Out(torch.autograd.Function):
     """x (.., K) activations dtype, w (N, K) fp32 parameter-like -> (.., N) fp32 from the GEMM's fp32 accumulators
-    (the x_proj rows feed softplus / exp: keeping them unrounded matters).  Backward = two plain GEMMs."""
+    (the x_proj rows feed softplus / exp: keeping them unrounded matters).  Backward: tramba_linear_cl / tramba_wgrad_cl."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -575,11 +665,11 @@ class _LinearF32Out(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, wa = ctx.saved_tensors
-        ga = g.to(x.dtype)
-        gx = torch.matmul(ga, wa) if ctx.needs_input_grad[0] else None
+        ga = g.to(x.dtype).reshape(-1, g.shape[-1]).contiguous()
+        gx = _dgrad(ga, wa).view(x.shape) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
-            gw = _wgrad_tall(ga.reshape(-1, ga.shape[-1]), x.reshape(-1, x.shape[-1])).to(ctx.wdtype)
+            gw = _wgrad(ga, x.reshape(-1, x.shape[-1]))[0].to(ctx.wdtype)
         return gx, gw
 
 
@@ -619,11 +709,28 @@ class _SS2DCoreCL(torch.autograd.Function):
             order._flat_rows = flat
         xdf = xdbl.view(b, l * k, rg)
         ranks = xdf[:, flat, :r].view(b, k, l, r)                                          # (B,K,L,R) f32
-        cd = graw.dtype
-        # batched GEMMs on views (einsum would first copy the K-fold graw into its own layout)
-        g_dtw = torch.matmul(graw.transpose(-1, -2), ranks.to(cd)).float().sum(dim=0)       # (K,D,R)
         g_seq = torch.zeros((b, k, l, rg), dtype=torch.float32, device=x.device)           # gradients in sequence order
-        g_seq[..., :r] = torch.matmul(graw, dt_w.to(cd).unsqueeze(0))                        # (B,K,L,R)
+        # the two per-direction projections on the library's grouped kernels, straight on the (B,K,L,.) tensors:
+        #   d(dt_projs_weight)[k] = sum_{b,l} graw^T ranks   (TN, tramba_wgrad_cl with groups = K, batches = B)
+        #   d(ranks)              = graw @ dt_w[k]           (tramba_rows_gemm_cl into the first R floats of every row)
+        dtw_t = dt_w.transpose(1, 2).contiguous()                                          # (K, R, D)
+        if r % 8:                                   # the TN kernel moves 16-byte rows: pad the rank columns
+            ranks = F.pad(ranks, (0, 8 - r % 8))
+        if graw.dtype != torch.float32:
+            cd = graw.dtype
+            g_dtw = hip.wgrad_grouped_cl(graw, ranks.to(cd))                                # (K,D,R)
+            hip.rows_gemm_cl(graw.view(b * k, l, d), dtw_t.to(cd), g_seq.view(b * k, l, rg), r)
+        else:   # fp32 validation mode: three passes on bf16 splits
+            gh, gl = _split16(graw)
+            rh, rl = _split16(ranks)
+            wh, wl = _split16(dtw_t)
+            g_dtw = hip.wgrad_grouped_cl(gh, rh) + hip.wgrad_grouped_cl(gh, rl) + hip.wgrad_grouped_cl(gl, rh)
+            tmp = torch.empty_like(g_seq)
+            hip.rows_gemm_cl(gh.view(b * k, l, d), wh, g_seq.view(b * k, l, rg), r)
+            for ga_, wa_ in ((gh, wl), (gl, wh)):
+                hip.rows_gemm_cl(ga_.view(b * k, l, d), wa_, tmp.view(b * k, l, rg), r)
+                g_seq[..., :r] += tmp[..., :r]
+        g_dtw = g_dtw[..., :r]
         g_seq[..., r8] = g_b
         g_seq[..., r8 + 1] = g_c
         g_xd = torch.zeros_like(xdf)
@@ -982,10 +1089,10 @@ def _conv_cl(conv: nn.Conv2d, x_cl):
                               lambda: conv.weight.detach().permute(0, 2, 3, 1).reshape(conv.out_channels, -1)
                               .to(x_cl.dtype).contiguous())
         return hip.conv3x3s2_cl(x_cl, wk, _f32(conv.bias))
+    if torch.is_grad_enabled() and (x_cl.requires_grad or conv.weight.requires_grad):
+        return _ConvIm2colCL.apply(x_cl, conv.weight, conv.bias, conv.stride, conv.padding)
     x = from_cl(x_cl)
     b = None if conv.bias is None else conv.bias.to(x.dtype)
-    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
-        return to_cl(_ConvNative.apply(x.contiguous(), conv.weight.to(x.dtype), b, conv.stride, conv.padding, 1))
     w = conv.weight.to(x.dtype).contiguous(memory_format=torch.channels_last)
     return to_cl(F.conv2d(x, w, b, stride=conv.stride, padding=conv.padding))
 
@@ -1059,8 +1166,12 @@ class VSSMEncoder(nn.Module):
 
 
 def load_pretrained_Base(model, ckpt_path=""):
-    """vmamba.py:707-732: load a VMamba classification checkpoint into the encoder
-    (``layers.i.downsample.*`` -> ``downsample.i.*``, classifier dropped)."""
+    """vmamba.py:707-732: load a VMamba classification checkpoint (`{"model": state_dict}`) into the encoder.  Same rules:
+    keys containing "classifier" are skipped; `layers.<i>.downsample.*` is renamed `downsample.<i>.*` and must then exist
+    (AssertionError otherwise); a key the encoder does not have is reported and ignored; a shape mismatch is an
+    AssertionError -- except a 1x1-conv weight `(out, in, 1, 1)` for a Linear2d `(out, in)`, which is viewed (the
+    reshape of modules.py:15-19); parameters the checkpoint does not cover keep their initial values and
+    are reported."""
     import re
     print(f"Loading weights from: {ckpt_path}")
     ckpt = torch.load(ckpt_path, map_location="cpu")
@@ -1068,14 +1179,17 @@ def load_pretrained_Base(model, ckpt_path=""):
     loaded = set()
     for k, v in ckpt["model"].items():
         if "classifier" in k:
+            print(f"Passing weights: {k}")
             continue
         if "downsample" in k:
             i_ds = int(re.findall(r"layers\.(\d+)\.downsample", k)[0])
             k = k.replace(f"layers.{i_ds}.downsample", f"downsample.{i_ds}")
             assert k in model_dict, k
         if k in model_dict:
-            if v.shape != model_dict[k].shape:
-                v = v.view(model_dict[k].shape)  # (out,in,1,1) conv weights -> Linear2d
+            want = model_dict[k].shape
+            if v.shape != want and v.dim() == 4 and tuple(v.shape[2:]) == (1, 1) and tuple(v.shape[:2]) == tuple(want):
+                v = v.view(want)          # (out,in,1,1) conv weight -> Linear2d
+            assert v.shape == want, f"module: {k} Shape mismatch: {v.shape} vs {want}"
             model_dict[k] = v
             loaded.add(k)
         else:
