@@ -236,10 +236,10 @@ def helix_pair_roofline(step, nrep, batch, act_bytes):
     # the merged y
     alg = b * l * d * act_bytes + (r + 2) * k * b * l * 4 + b * l * d * act_bytes
     gbs = alg / ((us_s + us_m) * 1e-6) / 1e9
-    pmc_s, pmc_m = pmc_traffic("ss2d_scan_cl_kernel@helix96"), pmc_traffic("ss2d_merge_norm_deep_kernel@helix96")
+    pmc_s, pmc_m = pmc_traffic("ss2d_scan_dma_kernel@helix96"), pmc_traffic("ss2d_merge_norm_deep_kernel@helix96")
     traffic = pmc_s["bytes"] + pmc_m["bytes"] if pmc_s and pmc_m else None
     pair = {"bound": "hbm",
-            "kernel": "Helix-SS2D core at 96x96 (K=8, D=256, B=%d): ss2d_scan_cl_kernel + ss2d_merge_norm_deep_kernel" % b,
+            "kernel": "Helix-SS2D core at 96x96 (K=8, D=256, B=%d): ss2d_scan_dma_kernel + ss2d_merge_norm_deep_kernel" % b,
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "algorithmic_bytes": alg, "launches": ns,
             "avg_us": round(us_s + us_m, 2), "scan_us": round(us_s, 2), "merge_us": round(us_m, 2),
@@ -248,7 +248,7 @@ def helix_pair_roofline(step, nrep, batch, act_bytes):
                        "(it is this implementation's intermediate: roofline_kernel_boundary counts it)",
             "note": "both launches are VALU/transcendental-issue and latency bound, not HBM bound (DESIGN.md section 4: "
                     "SQ counters); average HIP-event durations inside eager single-stream forwards"}
-    kb = {"scan": {"bound": "hbm", "kernel": "ss2d_scan_cl_kernel (Helix 96x96)", "achieved": round(by_s / (ms_s * 1e-3) / 1e9, 1),
+    kb = {"scan": {"bound": "hbm", "kernel": "ss2d_scan_dma_kernel (Helix 96x96)", "achieved": round(by_s / (ms_s * 1e-3) / 1e9, 1),
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by_s / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                    "algorithmic_bytes": int(by_s / ns), "avg_us": round(us_s, 2), "traffic": (pmc_s or {}).get("bytes"),
                    "formula": "x once + x_proj rows (padded groups) + ys (B,K,L,D) written"},
@@ -469,7 +469,7 @@ def main():
         hip.profile_enable(hip.PROF_SCAN_FUSED, False)
         hip.profile_enable(hip.PROF_GEMM, False)
         gbs = nbytes / (ms * 1e-3) / 1e9
-        roof_all = {"bound": "hbm", "kernel": "ss2d_scan_cl_kernel + ss2d_seg_kernel, all shapes", "achieved": round(gbs, 1),
+        roof_all = {"bound": "hbm", "kernel": "ss2d_scan_dma_kernel + ss2d_scan_cl_kernel + ss2d_seg_kernel, all shapes", "achieved": round(gbs, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                     "launches": n, "avg_us": round(ms / n * 1e3, 2), "ms_per_step": round(ms / nrep, 3),
                     "note": "kernel-boundary bytes (x once + x_proj rows + ys) / HIP-event time, summed over every "

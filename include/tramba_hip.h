@@ -79,7 +79,7 @@ int tramba_profile_min_units(int which, double min_units);
 int tramba_tune_set(int knob, int value);
 int tramba_tune_get(int knob);
 #define TRAMBA_TUNE_MERGE_FORM 0
-#define TRAMBA_TUNE_SCAN_FORM 1      /* 1 = chained, 2 = wave-segment */
+#define TRAMBA_TUNE_SCAN_FORM 1      /* 1 = chained (register ring), 2 = wave-segment, 3 = chained on LDS-DMA staged operands */
 #define TRAMBA_TUNE_COUNT 2
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1

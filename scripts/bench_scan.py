@@ -30,8 +30,10 @@ def run(name, reps=20, b=4, dtype=torch.bfloat16):
     a = -torch.ones(k * d, device=dev)
     ds = torch.ones(k * d, device=dev)
     lw, lb = torch.ones(d, device=dev), torch.zeros(d, device=dev)
-    for ys_dtype, seg, mform in ((torch.float32, True, 0), (dtype, True, 0), (dtype, True, 1), (dtype, True, 2)):
+    for ys_dtype, seg, mform, sform in ((torch.float32, True, 0, 0), (dtype, True, 0, 0), (dtype, True, 1, 1), (dtype, True, 2, 2),
+                                       (dtype, True, 0, 3)):
         hip.tune_set(hip.TUNE_MERGE_FORM, mform)
+        hip.tune_set(hip.TUNE_SCAN_FORM, sform)
         for _ in range(3):
             ys = hip.ss2d_scan_cl(x, xdbl, order, dt_w, dt_b, a, ds, ys_dtype, segmented=seg)
             y = hip.ss2d_merge_norm_cl(ys, order, lw, lb, 1e-5, 2, dtype)
@@ -51,8 +53,9 @@ def run(name, reps=20, b=4, dtype=torch.bfloat16):
         dmax = float((y.float() - yref).abs().max())
         elems = b * k * l * d
         print(f"{name:7s} {'segmented' if seg else 'chained  '} ys={str(ys_dtype)[6:]:8s} scan {ts:8.1f} us ({elems / ts / 1e3:7.2f} Gelem/s)  "
-              f"merge[form {mform}] {tm:7.1f} us  |y - y(form 0)| {dmax:.2e}", flush=True)
+              f"merge[form {mform}] {tm:7.1f} us  |y - y(form 0)| {dmax:.2e}  scan form {sform}", flush=True)
     hip.tune_set(hip.TUNE_MERGE_FORM, 0)
+    hip.tune_set(hip.TUNE_SCAN_FORM, 0)
 
 
 if __name__ == "__main__":

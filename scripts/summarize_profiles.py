@@ -45,26 +45,46 @@ for name in ("bench", "bench_train"):
 json.dump(lines, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
 
 traffic = {}
+KERNELS = {"selective_scan_fwd": "selective_scan_fwd_kernel", "ss2d_scan_dma": "ss2d_scan_dma_kernel",
+           "ss2d_scan_cl": "ss2d_scan_cl_kernel", "ss2d_seg": "ss2d_seg_kernel", "merge_norm_deep": "ss2d_merge_norm_deep_kernel",
+           "merge_norm_stream": "ss2d_merge_norm_stream_kernel"}
 for cname, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     fs = glob.glob(os.path.join(src, d, "*", "*counter_collection.csv"))
     if not fs:
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if r["Counter_Name"] == cname and ("selective_scan_fwd" in r["Kernel_Name"] or "ss2d_scan_cl" in r["Kernel_Name"]):
-            kern = "selective_scan_fwd_kernel" if "selective_scan_fwd" in r["Kernel_Name"] else "ss2d_scan_cl_kernel"
+        if r["Counter_Name"] != cname:
+            continue
+        kern = next((v for k, v in KERNELS.items() if k in r["Kernel_Name"]), None)
+        if kern:
             agg[(kern, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     for (kern, grid), v in agg.items():
         v = v[1:] if len(v) > 1 else v  # first launch is cold
         traffic.setdefault(f"{kern}@grid{grid}", {})[cname + "_KiB"] = sum(v) / len(v)
-shapes = {"selective_scan_fwd_kernel@grid262144": ("L0 scan (4,1024,9216) bf16->f32", 4 * 1024 * 9216 * 8 + 2 * 4 * 4 * 9216 * 2),
-          "ss2d_scan_cl_kernel@grid131072": ("fused scan Helix 96x96 K=8 D=256 B=4, ys f32", 4 * 9216 * 256 * 2 + 4 * 9216 * 8 * 12 * 4 + 4 * 8 * 9216 * 256 * 4),
-          "ss2d_scan_cl_kernel@grid65536": ("fused scan raster 96x96 K=4 D=256 B=4, ys f32", 4 * 9216 * 256 * 2 + 4 * 9216 * 4 * 12 * 4 + 4 * 4 * 9216 * 256 * 4)}
+B, L, D = 4, 9216, 256
+x_b, ys8, ys4 = B * L * D * 2, B * 8 * L * D * 2, B * 4 * L * D * 2
+shapes = {  # key: (alias, what, algorithmic bytes at the kernel boundary)
+    "selective_scan_fwd_kernel@grid262144": ("selective_scan_fwd_kernel@grid262144", "L0 scan (4,1024,9216) bf16->f32",
+                                             4 * 1024 * 9216 * 8 + 2 * 4 * 4 * 9216 * 2),
+    "ss2d_scan_dma_kernel@grid262144": ("ss2d_scan_dma_kernel@helix96", "fused scan Helix 96x96 K=8 D=256 B=4, ys bf16",
+                                        x_b + B * L * 8 * 12 * 4 + ys8),
+    "ss2d_scan_dma_kernel@grid131072": ("ss2d_scan_dma_kernel@raster96", "fused scan raster 96x96 K=4 D=256 B=4, ys bf16",
+                                        x_b + B * L * 4 * 12 * 4 + ys4),
+    "ss2d_merge_norm_deep_kernel@grid2359296": ("ss2d_merge_norm_deep_kernel@helix96",
+                                                "merge + out_norm + GELU Helix 96x96 K=8 D=256 B=4, ys bf16", ys8 + x_b),
+    "ss2d_merge_norm_stream_kernel@grid147456": ("ss2d_merge_norm_stream_kernel@raster96",
+                                                 "merge + out_norm + GELU raster 96x96 K=4 D=256 B=4, ys bf16", ys4 + x_b),
+}
+out = {}
 for k, v in traffic.items():
     if "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
         v["traffic_bytes"] = (2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024
+    alias = k
     if k in shapes:
-        v["what"], v["algorithmic_bytes"] = shapes[k]
+        alias, v["what"], v["algorithmic_bytes"] = shapes[k]
+    out[alias] = v
+traffic = out
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 
@@ -73,5 +93,5 @@ print(json.dumps(traffic, indent=1))
 import subprocess
 tb = os.path.join(root, "scripts", "trace_by_grid.py")
 with open(os.path.join(dst, f"{tag}_scan_by_grid.txt"), "w") as f:
-    for pat in ("ss2d_s", "selective_scan"):
+    for pat in ("ss2d_s", "ss2d_merge", "selective_scan"):
         f.write(subprocess.run([sys.executable, tb, os.path.join(src, "trace"), pat], capture_output=True, text=True).stdout)

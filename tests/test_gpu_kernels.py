@@ -619,3 +619,51 @@ def test_ss2d_backward_small_contractions(b, kk, l, d, r):
     want2 = torch.einsum("bkld,krd->bklr", graw.double(), wt.double()).reshape(b * kk, l, r)
     assert float((y[..., :r].double() - want2).abs().max()) <= 1e-5 * float(want2.abs().max()) + 1e-5
     assert torch.all(y[..., r:] == 7.0)                           # columns past N untouched
+
+
+@pytest.mark.parametrize("fam,h,d,r,b", [("helix", 32, 64, 8, 2), ("helix", 40, 96, 8, 1), ("raster", 48, 32, 4, 3),
+                                         ("window", 96, 256, 8, 1)])
+@pytest.mark.parametrize("ys_dtype", [torch.float32, torch.bfloat16])
+def test_ss2d_scan_forms_agree(fam, h, d, r, b, ys_dtype):
+    """The three schedules of the fused scan -- chained on a register ring (8 waves per sequence), wave-segment (two
+    passes), chained on LDS-DMA staged operands (16 waves per sequence, the Helix 96x96 form) -- compute the same
+    recurrence; only the order in which tile aggregates are folded differs.  Ragged last super-chunks included (40x40 =
+    1600 positions = 3.125 super-chunks of 512).  The chained form itself is checked against the fp64 oracle above."""
+    H = hip()
+    g = torch.Generator().manual_seed(h * d + r)
+    order = H.scan_order(fam, h, h, torch.device(DEV))
+    k, l = order.k, h * h
+    x = torch.randn(b, l, d, generator=g).to(DEV, torch.bfloat16)
+    wx = (torch.randn(k, r + 2, d, generator=g) * d ** -0.5).to(DEV, torch.bfloat16)
+    xdbl = H.linear_cl(x, H.pad_x_proj_weight(wx), out_dtype=torch.float32)
+    dt_w = (torch.randn(k, d, r, generator=g) * r ** -0.5).to(DEV)
+    dt_b = (torch.randn(k * d, generator=g) * 0.5 - 3).to(DEV)
+    a = -(0.5 + torch.rand(k * d, generator=g)).to(DEV)
+    ds = (1 + 0.1 * torch.randn(k * d, generator=g)).to(DEV)
+    out = {}
+    try:
+        for form in (1, 2, 3):
+            H.tune_set(H.TUNE_SCAN_FORM, form)
+            out[form] = H.ss2d_scan_cl(x, xdbl, order, dt_w, dt_b, a, ds, ys_dtype).float()
+    finally:
+        H.tune_set(H.TUNE_SCAN_FORM, 0)
+    scale = float(out[1].abs().max())
+    tol = 2e-5 * scale if ys_dtype == torch.float32 else 1e-2 * scale
+    for form in (2, 3):
+        assert float((out[form] - out[1]).abs().max()) <= tol, (form, float((out[form] - out[1]).abs().max()), scale)
+    assert torch.isfinite(out[3]).all()
+
+
+def test_linear_epilogue_operands_are_validated():
+    """a residual in another dtype / shape, or a non-fp32 bias, would be misread by the kernel: host error."""
+    H = hip()
+    x = torch.randn(64, 128, device=DEV).to(torch.bfloat16)
+    w = torch.randn(64, 128, device=DEV).to(torch.bfloat16)
+    ok = H.linear_cl(x, w, torch.zeros(64, device=DEV), torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16))
+    assert ok.shape == (64, 64)
+    with pytest.raises(H.TrambaHipError, match="residual"):
+        H.linear_cl(x, w, None, torch.zeros(64, 64, device=DEV), out_dtype=torch.float32)     # fp32 residual
+    with pytest.raises(H.TrambaHipError, match="residual"):
+        H.linear_cl(x, w, None, torch.zeros(64, 32, device=DEV, dtype=torch.bfloat16))        # wrong shape
+    with pytest.raises(H.TrambaHipError, match="bias"):
+        H.linear_cl(x, w, torch.zeros(64, device=DEV, dtype=torch.bfloat16))                  # 16-bit bias

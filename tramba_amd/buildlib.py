@@ -62,7 +62,9 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+        # -z defs: an undefined symbol is a LINK error here, not a dlopen error on the GPU box (hipcc silently drops the
+        # launch stub of a kernel template whose body the host pass cannot digest, e.g. vector-register inline asm)
+        run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,-z,defs", "-o", LIB] + objs)
     return LIB
 
 

@@ -497,6 +497,203 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Chained form, 16 waves per sequence, operands staged by LDS-DMA (16-bit activations, dt_rank <= 8: the 96x96 maps).
+// The register-ring kernel above holds two tiles of gathered operands in VGPRs (~180 registers: 2 waves per SIMD, and the
+// SQ counters show each SIMD's VALU busy only ~55 % of the time at that occupancy).  Here the gathers of tile s+1 --
+// 32 x_dbl rows of 48 bytes and 32 token rows of 64 bytes per wave -- are written straight into a wave-private LDS slot by
+// buffer_load ... lds (no VGPRs), two slots per wave, and tile s is read from its slot right where it is consumed.  The
+// kernel then fits 128 registers: 16 waves per workgroup, 4 waves per SIMD, a super-chunk of 16 tiles per barrier.
+// A wave's own s_waitcnt vmcnt(0) orders its LDS reads behind its DMA (no barrier: the slots are wave-private); the DMA
+// of tile s+1 is issued at the top of step s and has the whole step to land.
+template <typename T, typename TY>
+__global__ __launch_bounds__(1024) void ss2d_scan_dma_kernel(
+    const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
+    const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
+    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass needs this kernel's launch stub, not its body, and hipcc
+                                      // silently drops the stub of a kernel template whose body holds vector-register asm
+    static_assert(sizeof(T) == 2, "16-bit activations");
+    constexpr int kW = 16;                      // waves per workgroup
+    constexpr int kRowP = 48;                   // bytes of one x_dbl group with R8 = 8: 8 ranks + B, C + 2 pad
+    constexpr int kUB = kTP * kTP * 2;          // token tile: 32 positions x 32 channels x 2 bytes
+    constexpr int kSlot = kUB + kTP * kRowP + 512;   // 4096 bytes: rows + the overshoot of the last 64-lane piece
+    __shared__ float agg[2][kW][2][kTP];
+    __shared__ __attribute__((aligned(16))) float stage[kW][3][kTP];
+    // two arrays, indexed statically: hipcc waits vmcnt(0) before an LDS read that may alias a pending LDS-DMA's destination;
+    // with the slots in distinct objects the read of slot A does not wait for the DMA into slot B
+    __shared__ __attribute__((aligned(16))) unsigned char ring0[kW][kSlot];
+    __shared__ __attribute__((aligned(16))) unsigned char ring1[kW][kSlot];
+    __shared__ __attribute__((aligned(16))) int idxbuf[kW][kWave];   // the index vector of the tile after next, by DMA too
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, hi = lane >> 5;
+    unsigned ct_, k_, b_;
+    xcd_work_item(ct_, k_, b_);
+    const int k = (int)k_, b = (int)b_, ctile = (int)ct_;
+    const int c = ctile * kTP + r32;            // D % 32 == 0 (host-checked): every channel exists
+    const int RG = xdbl_group_stride(R);        // 12
+    const int PC = K * RG;
+
+    ScanWave<T, 1, false> w;
+    w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + c, R, RG, PC, D, lane, c, &stage[wv][0][0]);
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
+    const __amdgpu_buffer_rsrc_t rp =
+        make_rsrc(xdbl + (long)b * L * PC + (long)k * RG, ((unsigned)(L - 1) * PC + RG) * 4u);
+    const unsigned yrow = (unsigned)D * (unsigned)sizeof(TY);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(ys + ((long)b * K + k) * L * D, (unsigned)L * yrow);
+    const int32_t *tk = table + (long)k * L;
+
+    const int span = kW * kTP;
+    const int nsuper = (L + span - 1) / span;
+    const int last = nsuper - 1;
+    const __amdgpu_buffer_rsrc_t rt = make_rsrc(tk, (unsigned)L * 4u);
+    auto idx_off = [&](int s) -> unsigned {     // byte offset of MY entry of tile s's index vector (clamped past the end)
+        const int l = (s < last ? s : last) * span + wv * kTP + r32;
+        return (unsigned)(l < L ? l : L - 1) * 4u;
+    };
+
+    // loop-invariant lane maps of the DMA pieces (16 bytes per lane, LDS destination = piece base + 16 * lane):
+    //   token tile  : 2 pieces; piece j, lane i -> position 16j + i/4, bytes 16*(i%4) .. +15 of this channel tile's 64
+    //   x_dbl rows  : 96 chunks of 16 bytes (3 per position); piece 0 = chunks 0..63, piece 1 = chunks 64..95 (lanes 0..31)
+    const unsigned ucol = (unsigned)(ctile * kTP * 2 + (lane & 3) * 16);
+    const int upos = lane >> 2;
+    const int pch0 = lane, pch1 = 64 + (lane & 31);
+    const int ppos0 = (pch0 * 171) >> 9, ppos1 = (pch1 * 171) >> 9;           // chunk / 3 for chunk < 128
+    const unsigned ppart0 = (unsigned)(pch0 - 3 * ppos0) * 16u, ppart1 = (unsigned)(pch1 - 3 * ppos1) * 16u;
+    typedef __attribute__((address_space(3))) void lds_void;
+    int *ib = &idxbuf[wv][0];
+    const unsigned iba = (unsigned)(size_t)(__attribute__((address_space(3))) int *)ib;
+
+    // No vector-memory LOAD the compiler can see lives in the tile loop: the index vector travels by LDS-DMA like the
+    // operands and every read of DMA-written LDS is a hand-written ds_read.  (hipcc orders a load result it can see, or an
+    // LDS read that may alias a pending DMA, with a vmcnt that -- the counter being in order -- also waits for most of the
+    // previous tile's 16 y stores: with 16 waves leaving the barrier together the whole CU then idles for a store round
+    // trip every step.)  The one counted wait at the top of a step covers exactly the DMAs of the step before.
+    auto dma = [&](unsigned char *base, int s_idx) {   // operands of the tile whose index vector sits in idxbuf -> base;
+        unsigned i0 = 0, i1 = 0, i2 = 0, i3 = 0;       // then the index vector of tile s_idx -> idxbuf
+        asm volatile(
+            "ds_read_b32 %0, %4\n\t"
+            "ds_read_b32 %1, %5\n\t"
+            "ds_read_b32 %2, %6\n\t"
+            "ds_read_b32 %3, %7\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
+            : "v"(iba + 4u * (unsigned)upos), "v"(iba + 4u * (unsigned)(16 + upos)), "v"(iba + 4u * (unsigned)ppos0),
+              "v"(iba + 4u * (unsigned)ppos1)
+            : "memory");
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(base), 16, i0 * w.xrow + ucol, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(base + 1024), 16, i1 * w.xrow + ucol, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_void *)(base + kUB), 16, i2 * w.prow + ppart0, 0, 0, 0);
+        // (lanes 32..63 repeat chunks 64..95 into the 512 bytes past the slot's x_dbl rows: kSlotPad)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_void *)(base + kUB + 1024), 16, i3 * w.prow + ppart1, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (lds_void *)ib, 4, idx_off(s_idx), 0, 0, 0);
+    };
+    // The slot is read by hand-written ds_reads: hipcc tracks LDS-DMA writes and, before an LDS read it can see, waits until
+    // only the DMA ops it has just issued are outstanding -- which, the counter being in order, also waits for the 16 y
+    // stores of the previous tile (the whole workgroup then idles for a store round trip every step: 16 waves leave the
+    // barrier together).  Reads the compiler cannot see are ordered by the counted wait at the top of the step instead.
+    auto from_lds = [&](const unsigned char *base, TileOps<T, 1> &o) {
+        const unsigned pa = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)(base + kUB + r32 * kRowP);
+        const unsigned ua = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)(base + hi * 4 * kTP * 2 + r32 * 2);
+        v4f v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        v2f bc = {0.f, 0.f};
+        unsigned u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0, u5 = 0, u6 = 0, u7 = 0, u8 = 0, u9 = 0, u10 = 0, u11 = 0, u12 = 0, u13 = 0,
+                 u14 = 0, u15 = 0;
+        asm volatile(
+            "ds_read_b128 %0, %19\n\t"
+            "ds_read_b128 %1, %19 offset:16\n\t"
+            "ds_read_b64 %2, %19 offset:32\n\t"
+            "ds_read_u16 %3, %20\n\t"
+            "ds_read_u16 %4, %20 offset:64\n\t"
+            "ds_read_u16 %5, %20 offset:128\n\t"
+            "ds_read_u16 %6, %20 offset:192\n\t"
+            "ds_read_u16 %7, %20 offset:512\n\t"
+            "ds_read_u16 %8, %20 offset:576\n\t"
+            "ds_read_u16 %9, %20 offset:640\n\t"
+            "ds_read_u16 %10, %20 offset:704\n\t"
+            "ds_read_u16 %11, %20 offset:1024\n\t"
+            "ds_read_u16 %12, %20 offset:1088\n\t"
+            "ds_read_u16 %13, %20 offset:1152\n\t"
+            "ds_read_u16 %14, %20 offset:1216\n\t"
+            "ds_read_u16 %15, %20 offset:1536\n\t"
+            "ds_read_u16 %16, %20 offset:1600\n\t"
+            "ds_read_u16 %17, %20 offset:1664\n\t"
+            "ds_read_u16 %18, %20 offset:1728\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(v0), "=&v"(v1), "=&v"(bc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(u5), "=&v"(u6),
+              "=&v"(u7), "=&v"(u8), "=&v"(u9), "=&v"(u10), "=&v"(u11), "=&v"(u12), "=&v"(u13), "=&v"(u14), "=&v"(u15)
+            : "v"(pa), "v"(ua)
+            : "memory");
+        o.araw[0][0] = v0.x; o.araw[0][1] = v0.y; o.araw[0][2] = v0.z; o.araw[0][3] = v0.w;
+        o.araw[0][4] = v1.x; o.araw[0][5] = v1.y; o.araw[0][6] = v1.z; o.araw[0][7] = v1.w;
+        o.bv = bc.x;
+        o.cv = bc.y;
+        const unsigned uu[16] = {u0, u1, u2, u3, u4, u5, u6, u7, u8, u9, u10, u11, u12, u13, u14, u15};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o.u[r] = (unsigned short)uu[r];
+    };
+
+    for (int i = threadIdx.x; i < 2 * kW * kTP; i += blockDim.x) {   // (every row is a live wave here; kept for symmetry)
+        agg[i / (kW * kTP)][(i / kTP) % kW][0][i % kTP] = 1.f;
+        agg[i / (kW * kTP)][(i / kTP) % kW][1][i % kTP] = 0.f;
+    }
+    __syncthreads();
+
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (lds_void *)ib, 4, idx_off(0), 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dma(&ring0[wv][0], 1);                                     // tile 0 -> slot 0, index vector of tile 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (no stores outstanding yet: a counted wait would not wait)
+    float carry = 0.f;
+    auto step = [&](auto slot_c, int s) {
+        constexpr int slot = decltype(slot_c)::value;
+        // tile s has landed in my slot and the index vector of tile s + 1 in idxbuf: everything but the 16 y stores of
+        // tile s - 1, the only vector-memory ops issued after those DMAs (the counter retires in order)
+        if (s > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        dma(slot ? &ring0[wv][0] : &ring1[wv][0], s + 2);       // tile s + 1 (clamped past the end: fetched, never used)
+        TileOps<T, 1> cur;
+        from_lds(slot ? &ring1[wv][0] : &ring0[wv][0], cur);
+        const int l0 = s * span + wv * kTP;
+        float Bp[16], Cp[16];
+        w.stage_bc(cur, Bp, Cp, false);
+        float a[16], bb[16], uf[16], preA[4], preH[4], runA, runH;
+        w.terms(cur, Bp, L - l0, a, bb, uf);
+        w.prefix(a, bb, preA, preH, runA, runH);
+        const int buf = s & 1;
+        if (hi == 0) {
+            agg[buf][wv][0][r32] = runA;
+            agg[buf][wv][1][r32] = runH;
+        }
+        // raw barrier: __syncthreads() would also wait vmcnt(0), i.e. for the DMA of the NEXT tile issued above
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        float h = carry, hin = carry;
+#pragma unroll
+        for (int q = 0; q < kW; ++q) {
+            if (q == wv) hin = h;
+            h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
+        }
+        carry = h;
+        w.read_stage4(2, Cp);                                  // C of my 16 positions, read where it is used
+        const unsigned yv = (unsigned)((l0 + 4 * hi) * D + c) * (unsigned)sizeof(TY);
+        if (l0 + kTP <= L) {  // wave-uniform: ragged only at the sequence end
+            w.template replay<TY, false>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, true, kTP);
+        } else {
+            w.template replay<TY, true>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, true, L - l0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int s = 0; s < nsuper; s += 2) {
+        step(std::integral_constant<int, 0>{}, s);
+        if (s + 1 < nsuper) step(std::integral_constant<int, 1>{}, s + 1);   // block-uniform
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward of the fused channels-last scan (training).  Same decomposition as ss2d_scan_cl_kernel -- a
 // workgroup of W waves owns 32 channels of one direction, tiles of 32 positions, dt_proj recomputed on the
 // matrix core from the gathered x_proj rows -- run twice over the sequence:
@@ -1106,8 +1303,8 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_deep_kernel(
     const float *__restrict__ ln_w, const float *__restrict__ ln_b, T *__restrict__ y, long npix, int B, int L,
     int D, int K, int H, float eps, int act)
 {
-    // rows per batch: 64 bytes per lane and buffer (2 buffers in flight = 8 KB per wave)
-    constexpr int RB = 64 / (NIT * V * (int)sizeof(TY)) > 0 ? 64 / (NIT * V * (int)sizeof(TY)) : 1;
+    // rows per batch: 32 bytes per lane and buffer (2 buffers in flight = 4 KB per wave; 58 VGPRs = 8 waves per SIMD)
+    constexpr int RB = 32 / (NIT * V * (int)sizeof(TY)) > 0 ? 32 / (NIT * V * (int)sizeof(TY)) : 1;
     const int lane = threadIdx.x & (kWave - 1);
     const long wid = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wid >= npix) return;   // wave-uniform, no barriers below
@@ -1381,7 +1578,32 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     // a single-segment sequence (no recompute at all, no barriers), or <= 128 sequences of >= 64 tiles.
     // (A caller that passes no workspace gets the chained form.)
     const bool seg_wins = p.nseg == 1 || ((long)batch * k * ct <= 128 && p.ntiles >= 64);
-    const bool use_seg = workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) && seg_wins;
+    const int form_tune = tramba_tune_get(TRAMBA_TUNE_SCAN_FORM);      // 1 = chained, 2 = wave-segment, 3 = chained on LDS-DMA
+    const bool use_seg = workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) &&
+                         (form_tune == 2 || (form_tune == 0 && seg_wins));   // (the LDS-DMA form below is tried first)
+    // ---- chained form, 16 waves per sequence on LDS-DMA staged operands (4 waves per SIMD): 16-bit maps with dt_rank <= 8
+    //      whose sequences fill the chip at 16 waves each (the Helix order at 96x96: 256 sequences x 16 = 4096 waves)
+    {
+        const int scan_tune = tramba_tune_get(TRAMBA_TUNE_SCAN_FORM);
+        const long seqs = (long)batch * k * ct;
+        const bool dma_ok = dtype != TRAMBA_F32 && r <= 8 && d % kTP == 0 && l >= 16 * kTP;
+        // (measured, scripts/bench_scan.py, 96x96 D=256 B=4: Helix K=8, 256 sequences: 83-90 us against 96 on the register ring;
+        //  raster K=4, 128 sequences -- half the CUs -- 78 against 85-89 for the wave-segment form)
+        if (dma_ok && (scan_tune == 3 || (scan_tune == 0 && seqs >= 128 && seqs * 16 <= 4096))) {
+            dim3 grid(ct, k, batch), block(16 * kWave);
+#define DMA_(T, TY) \
+    hipLaunchKernelGGL((ss2d_scan_dma_kernel<T, TY>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, dt_bias, A, Ds, \
+                       (TY *)ys, l, d, k, r)
+            if (dtype == TRAMBA_BF16) {
+                if (ys_dtype == TRAMBA_F32) DMA_(__hip_bfloat16, float); else DMA_(__hip_bfloat16, __hip_bfloat16);
+            } else {
+                if (ys_dtype == TRAMBA_F32) DMA_(__half, float); else DMA_(__half, __half);
+            }
+#undef DMA_
+            TRAMBA_LAUNCH_CHECK();
+            return TRAMBA_OK;
+        }
+    }
     if (use_seg) {
         // ---- wave-segment form: pass 0 -> pass 1 (single pass when one segment suffices)
         TRAMBA_CHECK(aligned16(workspace), "ss2d_scan_cl: workspace must be 16-byte aligned");
@@ -1512,8 +1734,10 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
         if ((long)hs * hs != l || hs % pw != 0) hs = 0;
     }
     // split-row form: a wide row (>= 4 wave iterations) on a map too small to fill the chip one wave per pixel
-    // (fp32 ys only: with 2-byte rows the one-wave-per-pixel form with 16-byte accesses is faster, 19.6 vs 26.5 us at 24x24 D=1024)
-    const bool split_form = !sum_only && !stream_form && tune != 1 && ys_dtype == TRAMBA_F32 && nit >= 4 && npix <= 16384;
+    // (bijective K = 4 orders, or fp32 rows: on the Helix tables with 2-byte rows the one-wave-per-pixel form with 16-byte
+    // accesses is faster -- 19.6 vs 26.5 us at 24x24 D=1024 K=8 -- while at K = 4 the split form wins, 11.7 vs 17.3 us)
+    const bool split_form = !sum_only && !stream_form && tune != 1 && (ys_dtype == TRAMBA_F32 || k <= 4) && nit >= 4 &&
+                            npix <= 16384;
     if (!stream_form && !split_form) {
         // one wave per pixel, deep row pipeline (Helix tables, small maps, merge-only): widest access that keeps 64 lanes
         // busy, 16 bytes at most

@@ -272,9 +272,12 @@ using namespace tramba;
 
 static void wgrad_plan(long m, int n, int k, int groups, int nbatch, int &nsplit, int &mchunk)
 {
+    // Token splits: enough workgroups to fill the chip (~1.5 per CU) but never chunks below 512 tokens -- a block reads
+    // 512 B per token and writes a 64 KB fp32 slab, so shorter chunks spend more bytes on partial sums than on operands
+    // (r02e trace: at ~1000 blocks for every shape the slab sums cost 60 % of the GEMM time).
     const long tiles = (long)((n + kWgTile - 1) / kWgTile) * ((k + kWgTile - 1) / kWgTile) * groups * nbatch;
-    long want = (1024 + tiles - 1) / tiles;                 // ~4 blocks per CU in flight
-    const long maxsplit = (m + 255) / 256;                  // at least 8 steps per block
+    long want = (384 + tiles - 1) / tiles;
+    const long maxsplit = m / 512 > 1 ? m / 512 : 1;
     if (want > maxsplit) want = maxsplit;
     if (want < 1) want = 1;
     long chunk = (m + want - 1) / want;
@@ -310,13 +313,15 @@ extern "C" int tramba_wgrad_cl(const void *gy, const void *x, float *out, void *
     TRAMBA_CHECK((long)groups * nbatch * nsplit <= 65535, "wgrad_cl: too many token chunks");
     hipStream_t s = (hipStream_t)stream;
     WgradArgs a;
-    a.gy = gy; a.x = x; a.part = (float *)workspace;
+    const bool direct = nsplit * nbatch == 1;          // one slab per group: it IS the result
+    a.gy = gy; a.x = x; a.part = direct ? out : (float *)workspace;
     a.gy_bs = gy_bs; a.gy_gs = gy_gs; a.x_bs = x_bs; a.x_gs = x_gs; a.gy_ld = gy_ld; a.x_ld = x_ld;
     a.M = (int)m; a.N = n; a.K = k; a.nbatch = nbatch; a.nsplit = nsplit; a.mchunk = mchunk; a.want_bias = want_bias;
     dim3 grid((k + kWgTile - 1) / kWgTile, (n + kWgTile - 1) / kWgTile, groups * nbatch * nsplit), block(256);
     if (dtype == TRAMBA_BF16) hipLaunchKernelGGL((wgrad_tn_kernel<__hip_bfloat16>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((wgrad_tn_kernel<__half>), grid, block, 0, s, a);
     TRAMBA_LAUNCH_CHECK();
+    if (direct) return TRAMBA_OK;
     const long slab = (long)n * k + n;
     dim3 g2((unsigned)((slab + 1023) / 1024), groups);
     hipLaunchKernelGGL(slab_sum_kernel, g2, dim3(256), 0, s, (const float *)workspace, out, slab, nbatch * nsplit);

@@ -313,6 +313,7 @@ def pad_x_proj_weight(x_proj_weight: torch.Tensor) -> torch.Tensor:
 
 
 _scan_ws = {}
+_scan_ws_retired = []
 
 
 def _scan_workspace(device, nbytes):
@@ -321,6 +322,8 @@ def _scan_workspace(device, nbytes):
     key = (str(device), _stream())
     ws = _scan_ws.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _scan_ws_retired.append(ws)      # a captured hipGraph may still replay launches that point at the old buffer
         ws = _scan_ws[key] = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
     return ws
 
@@ -523,6 +526,15 @@ def dct_split_cl(x, wx, wy):
     return high, low
 
 
+def _check_epilogue(what, bias, residual, dtype, m, n):
+    """the kernels read `bias` as (N) fp32 and `residual` as (M, N) in the INPUT dtype: anything else would be misread"""
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != n):
+        raise TrambaHipError(f"{what}: bias must be float32 with {n} elements, got {bias.dtype} x {bias.numel()}")
+    if residual is not None and (residual.dtype != dtype or residual.numel() != m * n):
+        raise TrambaHipError(f"{what}: residual must be {dtype} with {m} x {n} elements, got {residual.dtype} x "
+                             f"{residual.numel()}")
+
+
 def linear_cl(x, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
     """x: (..., K); w: (N, K) same dtype; -> (..., N)."""
     _dev(x, w, bias, residual)
@@ -533,6 +545,7 @@ def linear_cl(x, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
     y = torch.empty(x.shape[:-1] + (n,), dtype=out_dtype, device=x.device)
     if w.dtype != x.dtype or w.shape[1] != k:
         raise TrambaHipError("linear_cl: weight dtype/shape mismatch")
+    _check_epilogue("linear_cl", bias, residual, x.dtype, m, n)
     _check(lib().tramba_linear_cl(_ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), m, n, k, act, dt(x),
                                   dt(y), _stream()), "linear_cl")
     return y
@@ -546,6 +559,7 @@ def linear2_cl(x1, x2, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None
     m = x1.numel() // k1
     if x2.shape[:-1] != x1.shape[:-1] or w.shape[1] != k1 + k2 or w.dtype != x1.dtype or x2.dtype != x1.dtype:
         raise TrambaHipError("linear2_cl: operand shapes / dtypes do not match")
+    _check_epilogue("linear2_cl", bias, residual, x1.dtype, m, n)
     out_dtype = x1.dtype if out_dtype is None else out_dtype
     y = torch.empty(x1.shape[:-1] + (n,), dtype=out_dtype, device=x1.device)
     _check(lib().tramba_linear2_cl(_ptr(x1), _ptr(x2), k1, _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), m, n, k1 + k2,
