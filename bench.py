@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency protocol")
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step (config: 8)")
     ap.add_argument("--bucket-dtype", default="fp32", choices=["fp32", "bf16"], help="gradient all-reduce buckets")
+    ap.add_argument("--graph-dp", action="store_true",
+                    help="with N > 1 also capture the data-parallel step (RCCL all-reduces included) as one hipGraph; off by "
+                         "default: collective capture has only been exercised on one rank, and a rank stuck in a capture "
+                         "would take the whole multi-GPU run with it")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (gloo only to rehearse the N > 1 plumbing on a one-GPU box)")
     return ap.parse_args()
@@ -285,6 +289,35 @@ def latency_b1(model, img, graph_ok):
             "protocol": "Trambav6.py:219-255 (one event pair per forward)"}
 
 
+def graphed_train_leg(model, red, x, y, world, b, steps, timed):
+    """tramba_amd.GraphedTrainStep on the same model / batch: an optimisation, never a requirement -- any failure is
+    reported in the object instead of raised, and with several ranks the replay only runs if EVERY rank holds a graph."""
+    import torch
+    import torch.distributed as dist
+    import tramba_amd as ta
+    from tramba_amd import train
+    try:
+        gstep = ta.GraphedTrainStep(model, train.get_opt(1e-4, model, capturable=True), reducer=red)
+        ok, err = torch.ones(1, device="cuda"), "capture failed on another rank"
+        try:
+            for _ in range(2):
+                gstep(x, y)
+            torch.cuda.synchronize()
+        except Exception as e:
+            ok.zero_()
+            err = f"{type(e).__name__}: {e}"[:300]
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) <= 0:
+            return {"error": err}
+        gdt = timed(lambda: gstep(x, y))
+        return {"value": round(world * b * steps / gdt, 2), "unit": "img/s", "ms_per_step": round(gdt / steps * 1e3, 2),
+                "what": "tramba_amd.GraphedTrainStep: forward + loss + backward (+ bucketed all-reduce) + Adam + "
+                        "weight-shadow refresh as one hipGraph replay per step"}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def bench_train(args, world, rank, dtype, sync_all):
     """BASELINE configs[2]/[3]: fwd + bwd (BCE+IoU on 4 outputs) + two-group Adam, batch 8 per GPU, stochastic depth
     on; gradients averaged over RCCL in 32 MB buckets launched from autograd hooks (overlapped with backward) when
@@ -340,30 +373,11 @@ def bench_train(args, world, rank, dtype, sync_all):
                 "note": "all buckets reduced back to back with nothing else running; inside the step the buckets are "
                         "launched from autograd hooks and overlap the rest of backward"}
         # (the buckets now hold scribble; the next step's prepare() / fill overwrites them)
-    # the same step replayed as ONE hipGraph (collectives captured with it when world > 1)
-    graphed = None
-    try:
-        gopt = train.get_opt(1e-4, model, capturable=True)
-        gstep = ta.GraphedTrainStep(model, gopt, reducer=red)
-        ok, err = torch.ones(1, device="cuda"), "capture failed on another rank"
-        try:
-            for _ in range(2):
-                gstep(x, y)
-            torch.cuda.synchronize()
-        except Exception as e:
-            ok.zero_()
-            err = f"{type(e).__name__}: {e}"[:300]
-        if world > 1:       # replay only if EVERY rank holds a graph (a rank replaying alone would wait for ever)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok.item()) > 0:
-            gdt = timed(lambda: gstep(x, y))
-            graphed = {"value": round(world * b * steps / gdt, 2), "unit": "img/s", "ms_per_step": round(gdt / steps * 1e3, 2),
-                       "what": "tramba_amd.GraphedTrainStep: forward + loss + backward (+ bucketed all-reduce) + Adam + "
-                               "weight-shadow refresh as one hipGraph replay per step"}
-        else:
-            graphed = {"error": err}
-    except Exception as e:  # an optimisation, never a requirement
-        graphed = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # the same step replayed as ONE hipGraph (collectives captured with it when world > 1: opt-in, --graph-dp)
+    if world > 1 and not args.graph_dp:
+        graphed = {"skipped": "N > 1: pass --graph-dp to capture the data-parallel step (collectives included)"}
+    else:
+        graphed = graphed_train_leg(model, red, x, y, world, b, steps, timed)
     return {"metric": "images/sec fwd+bwd+Adam Tramba-V 384x384", "value": round(world * b * steps / dt, 2),
             "unit": "img/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2), "batch_per_gpu": b,
             "global_batch": b * world, "launch": "eager",

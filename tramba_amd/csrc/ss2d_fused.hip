@@ -705,11 +705,11 @@ __global__ __launch_bounds__(1024) void ss2d_scan_dma_kernel(
 // Outputs: gu (B,K,L,D) = dL/d(gathered x), graw (B,K,L,D) = dL/d(dt_raw = x_proj ranks . dt_w) in sequence
 // order (the small projections around them are left to batched GEMMs), gB / gC (B,K,L) summed over channels
 // (LDS transpose + atomics over the D/32 channel tiles), gpar (B,K,3,D) = per-channel dA, dD, dbias.
-template <typename T, int NK, bool SPLIT>
+template <typename T, int NK, bool SPLIT, typename TG>   // TG: dtype of the merged map's gradient (float or T)
 __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
-    const float *__restrict__ Ds, const float *__restrict__ gym, T *__restrict__ gu, T *__restrict__ graw,
+    const float *__restrict__ Ds, const TG *__restrict__ gym, T *__restrict__ gu, T *__restrict__ graw,
     float *__restrict__ gB, float *__restrict__ gC, float *__restrict__ gpar, float *__restrict__ hst, int L, int D,
     int K, int R, int W)
 {
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
     const __amdgpu_buffer_rsrc_t rp =
         make_rsrc(xdbl + (long)b * L * PC + (long)k * RG, ((unsigned)(L - 1) * PC + RG) * 4u);
-    const __amdgpu_buffer_rsrc_t rg = make_rsrc(gym + (long)b * L * D, (unsigned)L * (unsigned)D * 4u);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(gym + (long)b * L * D, (unsigned)L * (unsigned)D * (unsigned)sizeof(TG));
     const unsigned orow = (unsigned)D * (unsigned)sizeof(T);
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(gu + ((long)b * K + k) * L * D, (unsigned)L * orow);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(graw + ((long)b * K + k) * L * D, (unsigned)L * orow);
@@ -811,9 +811,10 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
             w.read_stage4(0, xo);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const unsigned off = __builtin_bit_cast(unsigned, xo[r]) / (unsigned)sizeof(T) * 4u + (unsigned)cc_ * 4u;
+                const unsigned off = __builtin_bit_cast(unsigned, xo[r]) / (unsigned)sizeof(T) * (unsigned)sizeof(TG) +
+                                     (unsigned)cc_ * (unsigned)sizeof(TG);
                 const bool ok = (r & 3) + 8 * (r >> 2) + 4 * hi < nvalid;
-                gy[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, ok ? off : kOutOfRange, 0, 0));
+                gy[r] = raw_to_f<TG>(buf_load_raw<TG>(rg, ok ? off : kOutOfRange));
             }
         }
         float Bp[16], Cp[16], a[16], bb[16], uf[16], tl[16], preA[4], preH[4], tA, tH;
@@ -1654,15 +1655,16 @@ extern "C" size_t tramba_ss2d_scan_bwd_workspace(int batch, int l, int d, int k)
 }
 
 extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
-                                       const float *dt_bias, const float *A, const float *Ds, const float *gym,
+                                       const float *dt_bias, const float *A, const float *Ds, const void *gym,
                                        void *gu, void *graw, float *gB, float *gC, float *gpar, void *workspace,
                                        size_t workspace_bytes, int batch, int l, int d, int k, int r, int dtype,
-                                       void *stream)
+                                       int gym_dtype, void *stream)
 {
     TRAMBA_CHECK(x && xdbl && table && dt_w && dt_bias && A && Ds && gym && gu && graw && gB && gC && gpar && workspace,
                  "ss2d_scan_bwd_cl: null tensor");
     TRAMBA_CHECK(batch > 0 && l > 0 && d > 0 && k > 0 && r > 0, "ss2d_scan_bwd_cl: empty shape");
     TRAMBA_CHECK(batch <= 65535 && k <= 65535 && r <= 64, "ss2d_scan_bwd_cl: B, K or dt_rank exceeds this build's limits");
+    TRAMBA_CHECK(gym_dtype == TRAMBA_F32 || gym_dtype == dtype, "ss2d_scan_bwd_cl: gym must be f32 or the activation dtype");
     TRAMBA_CHECK(aligned16(xdbl) && aligned16(workspace), "ss2d_scan_bwd_cl: xdbl / workspace must be 16-byte aligned");
     TRAMBA_CHECK(workspace_bytes >= tramba_ss2d_scan_bwd_workspace(batch, l, d, k), "ss2d_scan_bwd_cl: workspace too small");
     TRAMBA_CHECK(((double)l + 1024.0) * d * 4.0 < 2147483648.0 && (double)l * k * rg_bytes(r) < 2147483648.0,
@@ -1674,9 +1676,11 @@ extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const i
     while (W > 1 && (long)batch * k * ct * W > 2048) W >>= 1;
     if (W > (l + kTP - 1) / kTP) W = (l + kTP - 1) / kTP;
     dim3 grid(ct, k, batch), block(W * kWave);
-#define BWD_(T, NK_, SP_)                                                                                        \
-    hipLaunchKernelGGL((ss2d_scan_bwd_cl_kernel<T, NK_, SP_>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w,   \
-                       dt_bias, A, Ds, gym, (T *)gu, (T *)graw, gB, gC, gpar, (float *)workspace, l, d, k, r, W)
+#define BWD_G_(T, NK_, SP_, TG)                                                                                     \
+    hipLaunchKernelGGL((ss2d_scan_bwd_cl_kernel<T, NK_, SP_, TG>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, \
+                       dt_bias, A, Ds, (const TG *)gym, (T *)gu, (T *)graw, gB, gC, gpar, (float *)workspace, l, d, k, r, W)
+#define BWD_(T, NK_, SP_)                                                          \
+    if (gym_dtype == TRAMBA_F32) { BWD_G_(T, NK_, SP_, float); } else { BWD_G_(T, NK_, SP_, T); }
 #define BWD_NK_(T, SP_)                \
     switch (nk) {                      \
     case 1: BWD_(T, 1, SP_); break;    \
@@ -1693,6 +1697,7 @@ extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const i
     }
 #undef BWD_NK_
 #undef BWD_
+#undef BWD_G_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }

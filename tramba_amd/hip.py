@@ -48,7 +48,7 @@ SIGNATURES = {
     "tramba_ss2d_scan_workspace": (ctypes.c_size_t, [c_int] * 4),
     "tramba_ss2d_scan_cl": (c_int, [c_vp] * 9 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
     "tramba_ss2d_scan_bwd_workspace": (ctypes.c_size_t, [c_int] * 4),
-    "tramba_ss2d_scan_bwd_cl": (c_int, [c_vp] * 14 + [ctypes.c_size_t] + [c_int] * 6 + [c_vp]),
+    "tramba_ss2d_scan_bwd_cl": (c_int, [c_vp] * 14 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_layernorm_bwd_parts": (c_i64, [c_i64]),
@@ -365,8 +365,8 @@ def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym):
     _dev(x, xdbl, dt_w, dt_bias, A, Ds, gym)
     b, l, d = x.shape
     k, r = order.k, dt_w.shape[-1]
-    if gym.dtype != torch.float32 or gym.shape != x.shape:
-        raise TrambaHipError("ss2d_scan_bwd_cl: gym must be f32 (B, L, D)")
+    if gym.dtype not in (torch.float32, x.dtype) or gym.shape != x.shape:
+        raise TrambaHipError("ss2d_scan_bwd_cl: gym must be (B, L, D) in f32 or the activation dtype")
     gu = torch.empty((b, k, l, d), dtype=x.dtype, device=x.device)
     graw = torch.empty_like(gu)
     gB = torch.zeros((b, k, l), dtype=torch.float32, device=x.device)
@@ -376,7 +376,7 @@ def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     _check(lib().tramba_ss2d_scan_bwd_cl(_ptr(x), _ptr(xdbl), _ptr(order.table), _ptr(dt_w), _ptr(dt_bias), _ptr(A),
                                          _ptr(Ds), _ptr(gym), _ptr(gu), _ptr(graw), _ptr(gB), _ptr(gC), _ptr(gpar),
-                                         _ptr(ws), ws_bytes, b, l, d, k, r, dt(x), _stream()), "ss2d_scan_bwd_cl")
+                                         _ptr(ws), ws_bytes, b, l, d, k, r, dt(x), dt(gym), _stream()), "ss2d_scan_bwd_cl")
     return gu, graw, gB, gC, gpar
 
 

@@ -678,17 +678,19 @@ class _SS2DCoreCL(torch.autograd.Function):
     tensors with autograd, both directions HIP (training path): forward = the inference kernels, backward =
     tramba_ss2d_scan_bwd_cl (adjoint recurrence, gradients in sequence order) + the small projections as batched
     GEMMs.  x (B,L,D); xdbl (B,L,K*RG) f32; dt_w (K,D,R), dt_bias (K*D), a_neg (K*D) = -exp(A_logs), ds (K*D) f32.
-    Returns the merged map (B,L,D) f32 (before out_norm)."""
+    Returns the merged map (B,L,D) in x's dtype (before out_norm)."""
 
     @staticmethod
     def forward(ctx, x, xdbl, dt_w, dt_bias, a_neg, ds, order):
         x = x.contiguous()
         xdbl = xdbl.contiguous()
         dt_w, dt_bias, a_neg, ds = (t.detach().float().contiguous() for t in (dt_w, dt_bias, a_neg, ds))
-        ys = hip.ss2d_scan_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, torch.float32)
+        # per-direction outputs and the merged map travel in the activation dtype, as in inference (fp32 in the fp32
+        # validation mode): half the bytes of the K-fold intermediate, and out_norm / GELU / their backward run on 2-byte maps
+        ys = hip.ss2d_scan_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, x.dtype)
         ctx.save_for_backward(x, xdbl, dt_w, dt_bias, a_neg, ds)
         ctx.order = order
-        return hip.ss2d_merge_sum_cl(ys, order, torch.float32)
+        return hip.ss2d_merge_sum_cl(ys, order, x.dtype)
 
     @staticmethod
     def backward(ctx, gym):
@@ -698,8 +700,10 @@ class _SS2DCoreCL(torch.autograd.Function):
         k, r = order.k, dt_w.shape[-1]
         rg = hip.ss2d_group_stride(r)
         r8 = rg - 4
-        gu, graw, g_b, g_c, gpar = hip.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds,
-                                                       gym.contiguous().float())
+        gym = gym.contiguous()
+        if gym.dtype not in (torch.float32, x.dtype):
+            gym = gym.float()
+        gu, graw, g_b, g_c, gpar = hip.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, gym)
         gx = hip.ss2d_merge_sum_cl(gu, order, x.dtype)
         # row (l, k) of xdbl viewed as (B, L*K, RG) that sequence position (k, i) reads: table[k][i] * K + k.  One gather
         # and one index_add_ over all K directions instead of 4 launches per direction (660 small kernels per step)
