@@ -138,7 +138,8 @@ def test_tramba_v_fp32_matches_reference_golden(golden, golden_meta, tramba_v):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_tramba_v_low_precision_keeps_mae(golden_meta, dtype):
-    """bf16/fp16 inference: saliency within tolerance of the fp32 reference, MAE unchanged to 4 d.p."""
+    """bf16/fp16 inference keeps the MAE of the fp32 reference to 5e-4.  (A weak check by itself -- the golden map is at
+    chance level, MAE 0.516 -- the element-wise test below is the one that sees wrong logits.)"""
     import tramba_amd as ta
     m = ta.bulid_model(deep_supervision=True, use_pretrain=False, img_size=384)
     m = ta.prepare_inference(_load_synth(m), dtype)

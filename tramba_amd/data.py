@@ -216,10 +216,14 @@ class ImageLoader:
             yield s
 
 
-def _seed_worker(worker_id):
+_RANK_STRIDE = 1000003     # per-rank offset of the augmentation streams (data-parallel ranks are all seeded 1026)
+
+
+def _seed_worker(worker_id, rank=0):
     """Each DataLoader worker is a fork of the parent and would replay the parent's numpy stream: give every worker
-    its own stream derived from torch's per-worker seed (the reference leaves the workers on identical streams)."""
-    np.random.seed(torch.initial_seed() % (1 << 32))
+    its own stream derived from torch's per-worker seed (the reference leaves the workers on identical streams), offset
+    by the data-parallel rank so that two ranks do not augment their shards with the same draws."""
+    np.random.seed((torch.initial_seed() + _RANK_STRIDE * rank) % (1 << 32))
 
 
 def train_loader(root, img_size=384, batch_size=4, num_workers=8, rank=0, world_size=1, seed=1026, distinct_workers=True):
@@ -230,9 +234,14 @@ def train_loader(root, img_size=384, batch_size=4, num_workers=8, rank=0, world_
     if world_size > 1:
         from torch.utils.data.distributed import DistributedSampler
         sampler = DistributedSampler(ds, num_replicas=world_size, rank=rank, shuffle=True, seed=seed, drop_last=True)
+        if num_workers == 0:     # the samples are drawn in this process: move its numpy stream off the other ranks'
+            np.random.seed((seed + _RANK_STRIDE * rank) % (1 << 32))
+    import functools
     return DataLoader(ds, batch_size=batch_size, shuffle=sampler is None, sampler=sampler, pin_memory=True,
                       num_workers=num_workers, drop_last=world_size > 1,
-                      worker_init_fn=_seed_worker if (distinct_workers and num_workers > 0) else None)
+                      # workers started after the process has a HIP context must not be forks of it
+                      multiprocessing_context=("spawn" if num_workers > 0 and torch.cuda.is_initialized() else None),
+                      worker_init_fn=functools.partial(_seed_worker, rank=rank) if (distinct_workers and num_workers > 0) else None)
 
 
 def eval_loader(root, img_size=384, num_workers=8):
