@@ -210,6 +210,13 @@ int tramba_dct_split_cl(const void *x, const float *wx, const float *wy, float *
  * last.  MFMA path for f16/bf16. */
 int tramba_linear_cl(const void *x, const void *w, const float *bias, const void *residual, void *y,
                      int64_t m, int n, int k, int act, int dtype, int out_dtype, void *stream);
+/* LayerNorm2d followed by Linear2d as ONE launch (VSSBlock: norm -> op.in_proj, norm2 -> mlp.fc1, vmamba.py:384-396;
+ * the decoder blocks likewise): y = epilogue(LayerNorm_K(x) @ W^T + b) computed as rstd_m * (x @ W'^T - mean_m * colsum) + t
+ * with W' = W * gamma (rows of W scaled, in dtype), colsum (N) f32 = row sums of W' as rounded, bias (N) f32 = W beta + b.
+ * The block derives mean / rstd of its own rows; the normalised map is never written.  16-bit dtypes, K % 64 == 0,
+ * K <= 2048, N % 8 == 0; act / residual as tramba_linear_cl. */
+int tramba_linear_ln_cl(const void *x, const void *w_folded, const float *colsum, const float *bias, const void *residual,
+                        void *y, int64_t m, int n, int k, float eps, int act, int dtype, int out_dtype, void *stream);
 /* Same with the K dimension of x split over two tensors, x = [x1 (M, k1) | x2 (M, k - k1)]: Linear2d applied to
  * torch.cat((x1, x2), dim=-1) without materialising the concatenation (decoder concat_back_dim, Trambav6.py:124;
  * FreqSS2Dv6, freq_mamba.py:52).  16-bit dtypes, k1 % 64 == 0 and (k - k1) % 64 == 0. */

@@ -667,3 +667,43 @@ def test_linear_epilogue_operands_are_validated():
         H.linear_cl(x, w, None, torch.zeros(64, 32, device=DEV, dtype=torch.bfloat16))        # wrong shape
     with pytest.raises(H.TrambaHipError, match="bias"):
         H.linear_cl(x, w, torch.zeros(64, device=DEV, dtype=torch.bfloat16))                  # 16-bit bias
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k,act,res", [(2304, 1024, 512, 0, False), (2304, 2048, 512, 2, False), (576, 4096, 1024, 2, False),
+                                           (36864, 256, 128, 0, False), (1000, 72, 192, 0, True), (9216, 512, 256, 2, True)])
+def test_layernorm_folded_into_the_gemm(m, n, k, act, res, dtype):
+    """tramba_linear_ln_cl = LayerNorm2d then Linear2d (VSSBlock norm -> in_proj, norm2 -> fc1; vmamba.py:384-396) in one
+    launch, against an fp64 evaluation of the same rounded inputs, and against the two-launch path it replaces.  Rows with a
+    large mean (the cancellation case of the folded form) included."""
+    H = hip()
+    from tramba_amd.modules import _fold_layernorm
+    import tramba_amd as ta
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g) * 1.3 + 0.2
+    x[::7] += 6.0                                                        # rows whose mean is 5x their spread
+    x = x.to(DEV, dtype)
+    lin = ta.Linear2d(k, n, bias=True).to(DEV)
+    norm = ta.LayerNorm2d(k).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(n, k, generator=g) * k ** -0.5)
+        lin.bias.copy_(0.1 * torch.randn(n, generator=g))
+        norm.weight.copy_(1 + 0.2 * torch.randn(k, generator=g))
+        norm.bias.copy_(0.1 * torch.randn(k, generator=g))
+    r = torch.randn(m, n, generator=g).to(DEV, dtype) if res else None
+    wf, cs, tb = _fold_layernorm(lin, norm, dtype)
+    got = H.linear_ln_cl(x, wf, cs, tb, norm.eps, r, act).double().cpu()
+    xd = x.double().cpu()
+    ln = torch.nn.functional.layer_norm(xd, (k,), norm.weight.double().cpu(), norm.bias.double().cpu(), norm.eps)
+    want = ln @ lin.weight.double().cpu().t() + lin.bias.double().cpu()
+    if act == 2:
+        want = torch.nn.functional.gelu(want)
+    if res:
+        want = want + r.double().cpu()
+    two = H.linear_cl(H.layernorm_cl(x, norm.weight.detach(), norm.bias.detach(), norm.eps), lin.weight.detach().to(dtype),
+                      lin.bias.detach(), r, act).double().cpu()
+    scale = float(want.abs().max())
+    tol = (2e-2 if dtype == torch.bfloat16 else 3e-3) * scale
+    e_fused, e_two = float((got - want).abs().max()), float((two - want).abs().max())
+    assert e_fused <= tol, (e_fused, e_two, scale)
+    assert e_fused <= 2.0 * e_two + 1e-3 * scale, (e_fused, e_two)          # no worse than the path it replaces

@@ -178,8 +178,13 @@ __device__ __forceinline__ void acc_to_lds(ACC &acc, float *ep)   // ACC = acc16
 template <typename T, typename TO, int BM, int BN, int NWM = 2, typename ACC>
 __device__ __forceinline__ void tile_epilogue(ACC &acc, unsigned char *lds,
                                               const float *__restrict__ bias, const T *__restrict__ res,
-                                              TO *__restrict__ y, long M, int N, int act, long m0, int n0)
+                                              TO *__restrict__ y, long M, int N, int act, long m0, int n0,
+                                              const float *__restrict__ colsum = nullptr,
+                                              const float2 *__restrict__ rowstat = nullptr)
 {
+    // colsum / rowstat: LayerNorm of the INPUT rows folded into the GEMM (linear_lean_kernel<.., LNIN>): the accumulator
+    // holds x . W' with W' = W * gamma; the normalised product is rstd_m * (acc - mean_m * colsum_n), and beta . W rides
+    // in `bias`.  rowstat[row] = (mean, rstd) of the block's rows, in LDS behind the staging tile.
     const int tid = threadIdx.x;
     // ---- epilogue through LDS, block-wide: the four waves drop their accumulators into one BM x BN fp32
     // tile, then all 256 threads stream it out as 16-byte stores covering whole rows (a wave-private
@@ -205,6 +210,13 @@ __device__ __forceinline__ void tile_epilogue(ACC &acc, unsigned char *lds,
             o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
         }
         if (gcol + CPL <= N && (N & 7) == 0) {
+            if (colsum) {
+                const float2 st = rowstat[row];
+                float cs[CPL];
+                load_pack<float, CPL>(colsum + gcol, cs);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) o[q] = st.y * fmaf(-st.x, cs[q], o[q]);
+            }
             if (bias) {
                 float bv[CPL];
                 load_pack<float, CPL>(bias + gcol, bv);
@@ -224,6 +236,7 @@ __device__ __forceinline__ void tile_epilogue(ACC &acc, unsigned char *lds,
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 if (gcol + q < N) {
+                    if (colsum) o[q] = rowstat[row].y * fmaf(-rowstat[row].x, colsum[gcol + q], o[q]);
                     float t = apply_act(o[q] + (bias ? bias[gcol + q] : 0.f), act);
                     if (res) {
                         const float rv = Cvt<T>::to_f(res[grow * N + gcol + q]);
@@ -412,6 +425,15 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
 // BN = 128 a block tile holds whole groups, so LayerNorm over the group and the 1x1 head (C -> 1) run on the
 // accumulators: y (B, H*P, W*P) f32 = <LN(acc), head_w> + head_b.  Neither the (M, 2048) expand output nor the
 // (B, 384, 384, 128) normalised map is ever written (2 x 151 MB at batch 4) or read back.
+// LayerNorm of the INPUT rows folded into a GEMM (LayerNorm2d -> Linear2d pairs: VSSBlock norm -> in_proj, norm2 -> fc1,
+// vmamba.py:384-396): y = act(LN(x) W^T + b) = act(rstd * (x W'^T - mean * colsum) + t), W' = W * gamma (folded once per
+// weight version), colsum_n = sum_k W'_nk, t = W beta + b.  The block computes mean / rstd of its own 64 rows while its
+// first operand tiles are in flight; the normalised map is never written or re-read, and the LayerNorm launch disappears.
+struct LnIn {
+    const float *colsum;
+    float eps;
+};
+
 struct LnHead {
     const float *ln_w, *ln_b, *head_w;
     float head_b, eps;
@@ -499,12 +521,12 @@ __device__ __forceinline__ void tile_epilogue_ln_head(acc16_t (&acc)[BM / 64][2]
 //   * exactly nk steps run (ring trips + a statically indexed tail), so no zero-padded dummy steps.
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 
-template <typename T, typename TO, int BM, int BN, int PF, bool LNHEAD = false, int NWM = 2>
+template <typename T, typename TO, int BM, int BN, int PF, bool LNHEAD = false, int NWM = 2, bool LNIN = false>
 __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ x, const T *__restrict__ w,
                                                          const float *__restrict__ bias,
                                                          const T *__restrict__ res, TO *__restrict__ y, long M,
                                                          int N, int K, int act, const T *__restrict__ x2, int K1,
-                                                         LnHead hd = LnHead{})
+                                                         LnHead hd = LnHead{}, LnIn li = LnIn{nullptr, 0.f})
 {
     // x2 != nullptr: A = [x (M, K1) | x2 (M, K - K1)], both halves whole K steps (no concatenation in memory)
     using WL = WaveLayout<BM, BN, NWM>;
@@ -517,7 +539,8 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
     constexpr int LDS_BYTES = 2 * TILE_BYTES > EPI_BYTES ? 2 * TILE_BYTES : EPI_BYTES;
     constexpr int NS = PF + 1;
     static_assert(NS % 2 == 0, "the LDS buffer parity must be a compile-time constant");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    static_assert(!LNIN || (BM == 64 && NWM == 2 && !LNHEAD), "the input-LayerNorm form is written for 64-row tiles");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES + (LNIN ? BM * 8 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool compute = wave < NWM * WL::NWN;                     // (3 x 1 layout: the fourth wave only moves data)
@@ -606,6 +629,39 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
     lstore(0, pipe[0]);
 #pragma unroll
     for (int i = 1; i < NS; ++i) gload(i, pipe[i]);
+    if constexpr (LNIN) {
+        // mean / rstd of the block's 64 input rows, while the first operand tiles are in flight: 4 threads per row, 16-byte
+        // chunks (t & 3) + 4 j, eight loads in flight per thread; one-pass sums in fp32 over K <= 2048 exact bf16 values
+        float2 *rowstat = reinterpret_cast<float2 *>(lds + LDS_BYTES);
+        const int srow = tid >> 2, sub = tid & 3;
+        const int nch = K >> 5;                          // 16-byte chunks per thread (K % 64 == 0)
+        float s1 = 0.f, s2 = 0.f;
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+            v4u_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned off = c0 + j < nch ? (unsigned)srow * rowa + (unsigned)(sub + 4 * (c0 + j)) * 16u : kOutOfRange;
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const Pack<T, 8> pk = __builtin_bit_cast(Pack<T, 8>, v[j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = Cvt<T>::to_f(pk.v[e]);
+                    s1 += f;
+                    s2 = fmaf(f, f, s2);
+                }
+            }
+        }
+        s1 += __shfl_xor(s1, 1, 64);
+        s2 += __shfl_xor(s2, 1, 64);
+        s1 += __shfl_xor(s1, 2, 64);
+        s2 += __shfl_xor(s2, 2, 64);
+        const float mean = s1 / (float)K;
+        const float var = fmaxf(s2 / (float)K - mean * mean, 0.f);
+        if (sub == 0) rowstat[srow] = make_float2(mean, rsqrtf(var + li.eps));
+    }
     __syncthreads();
     // one K step; `par` (LDS half holding tile kt) is a literal at every call site
     auto kstep = [&](int kt, int par, Stage &load_into, const Stage &store_from) {
@@ -645,6 +701,9 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
     if constexpr (LNHEAD) {
         static_assert(BN == 128, "one tile = whole 128-channel groups");
         tile_epilogue_ln_head<T, BM>(acc, lds, hd, M, m0, n0);
+    } else if constexpr (LNIN) {
+        tile_epilogue<T, TO, BM, BN, NWM>(acc, lds, bias, res, y, M, N, act, m0, n0, li.colsum,
+                                          reinterpret_cast<const float2 *>(lds + LDS_BYTES));
     } else {
         tile_epilogue<T, TO, BM, BN, NWM>(acc, lds, bias, res, y, M, N, act, m0, n0);
     }
@@ -801,6 +860,43 @@ extern "C" int tramba_linear_cl(const void *x, const void *w, const float *bias,
         set_error("linear_cl: bad dtype %d", dtype);
         return TRAMBA_ERR_ARG;
     }
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_linear_ln_cl(const void *x, const void *w_folded, const float *colsum, const float *bias,
+                                   const void *residual, void *y, int64_t m, int n, int k, float eps, int act, int dtype,
+                                   int out_dtype, void *stream)
+{
+    TRAMBA_CHECK(x && w_folded && colsum && y, "linear_ln_cl: null tensor");
+    TRAMBA_CHECK(m > 0 && n > 0 && k > 0, "linear_ln_cl: empty shape");
+    TRAMBA_CHECK(dtype == TRAMBA_BF16 || dtype == TRAMBA_F16, "linear_ln_cl: 16-bit activations only");
+    TRAMBA_CHECK(out_dtype == dtype || out_dtype == TRAMBA_F32, "linear_ln_cl: output must be the input dtype or f32");
+    TRAMBA_CHECK(k % 64 == 0 && k <= 2048 && n % 8 == 0, "linear_ln_cl: needs K %% 64 == 0, K <= 2048, N %% 8 == 0");
+    TRAMBA_CHECK(aligned16(x) && aligned16(w_folded) && aligned16(y) && aligned16(colsum) && (!bias || aligned16(bias)) &&
+                     (!residual || aligned16(residual)),
+                 "linear_ln_cl: tensors must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(TRAMBA_PROF_GEMM, s, 2.0 * (double)m * n * k);
+    const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
+    const bool deep = k >= 1024 && tiles64 <= 320;       // the ring depth rule of launch_tiled
+    dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
+    const LnIn li{colsum, eps};
+#define LNIN_(T, TO)                                                                                                     \
+    if (deep)                                                                                                            \
+        hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 3, false, 2, true>), grid, block, 0, s, (const T *)x,       \
+                           (const T *)w_folded, bias, (const T *)residual, (TO *)y, m, n, k, act, (const T *)nullptr, 0,  \
+                           LnHead{}, li);                                                                                \
+    else                                                                                                                 \
+        hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 1, false, 2, true>), grid, block, 0, s, (const T *)x,       \
+                           (const T *)w_folded, bias, (const T *)residual, (TO *)y, m, n, k, act, (const T *)nullptr, 0,  \
+                           LnHead{}, li)
+    if (dtype == TRAMBA_BF16) {
+        if (out_dtype == TRAMBA_F32) { LNIN_(__hip_bfloat16, float); } else { LNIN_(__hip_bfloat16, __hip_bfloat16); }
+    } else {
+        if (out_dtype == TRAMBA_F32) { LNIN_(__half, float); } else { LNIN_(__half, __half); }
+    }
+#undef LNIN_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "tramba_dwconv_wgrad_cl": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_linear_ln_cl": (c_int, [c_vp] * 6 + [c_i64, c_int, c_int, c_f, c_int, c_int, c_int, c_vp]),
     "tramba_linear2_cl": (c_int, [c_vp, c_vp, c_int] + [c_vp] * 4 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_wgrad_workspace": (ctypes.c_size_t, [c_i64, c_int, c_int, c_int, c_int]),
     "tramba_wgrad_cl": (c_int, [c_vp] * 4 + [ctypes.c_size_t, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_int, c_i64,
@@ -548,6 +549,23 @@ def linear_cl(x, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
     _check_epilogue("linear_cl", bias, residual, x.dtype, m, n)
     _check(lib().tramba_linear_cl(_ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), m, n, k, act, dt(x),
                                   dt(y), _stream()), "linear_cl")
+    return y
+
+
+def linear_ln_cl(x, w_folded, colsum, bias, eps, residual=None, act=ACT_NONE, out_dtype=None):
+    """act(LayerNorm(x) @ W^T + b) in one launch: w_folded = W * gamma (N, K) in x's dtype, colsum (N) f32 its row sums,
+    bias (N) f32 = W @ beta + b (see include/tramba_hip.h)."""
+    _dev(x, w_folded, colsum, bias, residual)
+    k = x.shape[-1]
+    n = w_folded.shape[0]
+    m = x.numel() // k
+    if w_folded.dtype != x.dtype or w_folded.shape[1] != k or colsum.dtype != torch.float32 or colsum.numel() != n:
+        raise TrambaHipError("linear_ln_cl: operand shapes / dtypes do not match")
+    _check_epilogue("linear_ln_cl", bias, residual, x.dtype, m, n)
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    y = torch.empty(x.shape[:-1] + (n,), dtype=out_dtype, device=x.device)
+    _check(lib().tramba_linear_ln_cl(_ptr(x), _ptr(w_folded), _ptr(colsum), _ptr(bias), _ptr(residual), _ptr(y), m, n, k,
+                                     float(eps), act, dt(x), dt(y), _stream()), "linear_ln_cl")
     return y
 
 

@@ -36,6 +36,11 @@ from .ops import (CrossMerge, CrossMerge_Dilation, CrossMerge_Line, CrossMerge_W
 # a caller supplies scan classes of its own (scripts/ab_forward.py monkey-patches module attributes for A/B timing).
 
 
+# LayerNorm2d -> Linear2d pairs as one launch in 16-bit inference (a scheduling choice of the same arithmetic: A/B timing
+# scripts flip it, scripts/ab_forward.py tramba_amd.modules.FOLD_LAYERNORM)
+FOLD_LAYERNORM = True
+
+
 def to_cl(x: torch.Tensor) -> torch.Tensor:
     """NCHW-shaped -> (B,H,W,C) contiguous (free when x is already channels-last in memory)."""
     return x.permute(0, 2, 3, 1).contiguous()
@@ -363,6 +368,18 @@ class Linear2d(nn.Linear):
             y = y + residual
         return y if out_dtype is None else y.to(out_dtype)
 
+    def _forward_norm_cl(self, x, norm, act=hip.ACT_NONE, residual=None, out_dtype=None):
+        """self(norm(x)) for a LayerNorm2d `norm` over the input channels.  16-bit inference folds the LayerNorm into the
+        GEMM (tramba_linear_ln_cl: W * gamma cached per weight version, mean / rstd derived by the GEMM block from its own
+        rows), so the normalised map and the LayerNorm launch do not exist; elsewhere the two ops run one after the other."""
+        k = x.shape[-1]
+        if (FOLD_LAYERNORM and _infer(x, self.weight, norm.weight) and x.dtype != torch.float32 and k % 64 == 0 and k <= 2048
+                and self.weight.shape[0] % 8 == 0):
+            wf, cs, tb = _cache(self).get(("lnfold", x.dtype, id(norm)), (self.weight, self.bias, norm.weight, norm.bias),
+                                          lambda: _fold_layernorm(self, norm, x.dtype))
+            return hip.linear_ln_cl(x, wf, cs, tb, norm.eps, residual, act, out_dtype)
+        return self._forward_cl(norm._forward_cl(x), act=act, residual=residual, out_dtype=out_dtype)
+
     def _forward_cat_cl(self, x1, x2, act=hip.ACT_NONE, residual=None, out_dtype=None):
         """Linear2d(torch.cat((x1, x2), dim=-1)) -- in 16-bit inference the K loop reads the two tensors in turn
         (tramba_linear2_cl), so the concatenation never exists.  act = ACT_SIGMOID_GATE multiplies by `residual`."""
@@ -387,6 +404,18 @@ class Linear2d(nn.Linear):
             state_dict[key] = state_dict[key].view(self.weight.shape)
         return super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
                                              unexpected_keys, error_msgs)
+
+
+def _fold_layernorm(lin, norm, dtype):
+    """(W * gamma in `dtype`, its row sums as rounded, W beta + b) for the LayerNorm-folded GEMM; elementwise ops and
+    reductions only (no BLAS call even at cache-build time)."""
+    w = lin.weight.detach().float()
+    wf = (w * norm.weight.detach().float()[None, :]).to(dtype).contiguous()
+    colsum = wf.float().sum(dim=1).contiguous()
+    t = (w * norm.bias.detach().float()[None, :]).sum(dim=1)
+    if lin.bias is not None:
+        t = t + lin.bias.detach().float()
+    return wf, colsum, t.contiguous()
 
 
 class _LayerNormCL(torch.autograd.Function):
@@ -445,8 +474,12 @@ class Mlp(nn.Module):
         self.fc2 = Linear2d(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
 
-    def _forward_cl(self, x, residual=None):
-        h = self.fc1._forward_cl(x, act=hip.ACT_GELU)
+    def _forward_cl(self, x, residual=None, pre_norm=None):
+        """pre_norm: the LayerNorm2d the caller would apply to x first (folded into fc1 where possible)"""
+        if pre_norm is not None:
+            h = self.fc1._forward_norm_cl(x, pre_norm, act=hip.ACT_GELU)
+        else:
+            h = self.fc1._forward_cl(x, act=hip.ACT_GELU)
         h = self.drop(h)
         return self.drop(self.fc2._forward_cl(h, residual=residual))
 
@@ -860,8 +893,9 @@ class SS2D(nn.Module):
         y = self.out_norm._forward_cl(y, act=hip.ACT_GELU)
         return y.to(x.dtype)
 
-    def _forward_cl(self, x, residual=None):
-        x = self.in_proj._forward_cl(x)
+    def _forward_cl(self, x, residual=None, pre_norm=None):
+        """pre_norm: the LayerNorm2d the caller would apply to x first (folded into in_proj where possible)"""
+        x = self.in_proj._forward_norm_cl(x, pre_norm) if pre_norm is not None else self.in_proj._forward_cl(x)
         if self.with_dconv:
             if _infer(x, self.conv2d.weight):
                 cv = self.conv2d
@@ -911,8 +945,8 @@ class VSSBlock(_ResidualBlock):
                        drop=mlp_drop_rate, channels_first=channel_first)
 
     def _forward_cl(self, x):
-        x = self._residual(x, lambda res: self.op._forward_cl(self.norm._forward_cl(x), residual=res), self.drop_path)
-        x = self._residual(x, lambda res: self.mlp._forward_cl(self.norm2._forward_cl(x), residual=res), self.drop_path)
+        x = self._residual(x, lambda res: self.op._forward_cl(x, residual=res, pre_norm=self.norm), self.drop_path)
+        x = self._residual(x, lambda res: self.mlp._forward_cl(x, residual=res, pre_norm=self.norm2), self.drop_path)
         return x
 
     def forward(self, x):
@@ -957,8 +991,8 @@ class DWMSMlp(nn.Module):
         self.fc2 = Linear2d(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
 
-    def _forward_cl(self, x, residual=None):
-        h = self.fc1._forward_cl(x)
+    def _forward_cl(self, x, residual=None, pre_norm=None):
+        h = self.fc1._forward_norm_cl(x, pre_norm) if pre_norm is not None else self.fc1._forward_cl(x)
         c3, c5, c7 = self.dwc3.dw_conv, self.dwc5.dw_conv, self.dwc7.dw_conv
         if _infer(h, c3.weight, c5.weight, c7.weight):
             wt, bt = _cache(self).get(
@@ -996,8 +1030,8 @@ class MultiScaleDecoderBlock(_ResidualBlock):
                            drop=mlp_drop_rate, channels_first=channel_first)
 
     def _forward_cl(self, x):
-        x = self._residual(x, lambda res: self.op._forward_cl(self.norm1._forward_cl(x), residual=res), self.drop_path)
-        x = self._residual(x, lambda res: self.mlp._forward_cl(self.norm2._forward_cl(x), residual=res), self.drop_path)
+        x = self._residual(x, lambda res: self.op._forward_cl(x, residual=res, pre_norm=self.norm1), self.drop_path)
+        x = self._residual(x, lambda res: self.mlp._forward_cl(x, residual=res, pre_norm=self.norm2), self.drop_path)
         return x
 
     def forward(self, x):
@@ -1060,8 +1094,8 @@ class FreqBlockv6(nn.Module):
     def _forward_cl(self, x):
         x = x + self.drop_path(self.attn._forward_cl(self.norm1._forward_cl(x)))
         if isinstance(self.drop_path, nn.Identity):
-            return self.mlp._forward_cl(self.norm2._forward_cl(x), residual=x)
-        return x + self.drop_path(self.mlp._forward_cl(self.norm2._forward_cl(x)))
+            return self.mlp._forward_cl(x, residual=x, pre_norm=self.norm2)
+        return x + self.drop_path(self.mlp._forward_cl(x, pre_norm=self.norm2))
 
     def forward(self, x):
         _need_device(x)
