@@ -107,6 +107,19 @@ class VSSMDecoder(nn.Module):
             y = hip.shuffle_norm_head_cl(xe, hip._f32(fin.norm.weight), hip._f32(fin.norm.bias),
                                          hip._f32(conv.weight).view(-1), _bias_scalar(conv), fin.scale, fin.norm.eps)
             return y.unsqueeze(1)
+        if isinstance(self.stage_layers[-1], nn.Identity) and x_low.is_cuda and fin.output_dim % 8 == 0:
+            # training: LayerNorm over the C channels of an output pixel = over one contiguous C-group of the expanded row,
+            # and the C -> 1 head is a dot product per group: both run on the UN-shuffled (M * P * P, C) view, and only the
+            # scalar logits are rearranged -- the (B, 4H, 4W, C) map (302 MB at batch 8) is never permuted, forward or
+            # backward.  'b (p1 p2 c) h w -> b c (h p1) (w p2)' (modules.py:246-250): group g = p1 * P + p2.
+            from .modules import _RowDotCL
+            b, h, w, _ = x_low.shape
+            p, c = fin.scale, fin.output_dim
+            xe = fin.expand._forward_cl(x_low)                               # (B, H, W, P*P*C)
+            yn = fin.norm._forward_cl(xe.view(b, h, w * p * p, c))           # LayerNorm per C-group
+            lg = _RowDotCL.apply(yn, conv.weight, conv.bias)                 # (B, H, W*P*P) f32
+            lg = lg.view(b, h, w, p, p).permute(0, 1, 3, 2, 4).reshape(b, h * p, w * p)
+            return lg.unsqueeze(1)
         return self._seg_cl(conv, fin._forward_cl(x_low))
 
     def _forward_cl(self, skips_cl, guides=None):

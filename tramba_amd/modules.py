@@ -181,7 +181,7 @@ class _DwConvCL(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = hip.dwconv_cl(gy, wt.flip(0).contiguous(), torch.zeros_like(wt[0]), hip.ACT_NONE)
+            gx = hip.dwconv_cl(gy, wt.flip(0).contiguous(), _zeros_const(wt[0].shape, wt.dtype, wt.device), hip.ACT_NONE)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             ks = int(round(wt.shape[0] ** 0.5))
             gw, gb = hip.dwconv_wgrad_cl(x, gy, ks)
@@ -193,7 +193,7 @@ def _tap_major(conv: nn.Conv2d):
     w = conv.weight.float()
     c = w.shape[0]
     wt = w.reshape(c, -1).t()
-    bt = conv.bias.float() if conv.bias is not None else w.new_zeros(c)
+    bt = conv.bias.float() if conv.bias is not None else _zeros_const((c,), torch.float32, w.device)
     return wt, bt
 
 
@@ -236,12 +236,15 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = float(drop_prob)
 
+    def mask_for(self, x):
+        """per-sample keep mask scaled by 1 / keep, broadcastable to x"""
+        keep = 1.0 - self.drop_prob
+        return x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep).div_(keep)
+
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return x
-        keep = 1.0 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
-        return x * mask.div_(keep)
+        return x * self.mask_for(x)
 
     def extra_repr(self):
         return f"drop_prob={self.drop_prob}"
@@ -684,25 +687,51 @@ def D_init(d_inner, copies=-1, device=None, merge=True):
 
 
 # ----------------------------------------------------------------------------- SS2D
-class _LinearF32Out(torch.autograd.Function):
-    """x (.., K) activations dtype, w (N, K) fp32 parameter-like -> (.., N) fp32 from the GEMM's fp32 accumulators
-    (the x_proj rows feed softplus / exp: keeping them unrounded matters).  Backward: tramba_linear_cl / tramba_wgrad_cl."""
+_const_zeros = {}
+
+
+def _zeros_const(shape, dtype, device):
+    """A shared all-zero constant (never written): the zero bias of bias-free stencils, padding blocks -- a fresh
+    torch.zeros per call is one fill launch each, hundreds per training step."""
+    key = (tuple(shape), dtype, str(device))
+    t = _const_zeros.get(key)
+    if t is None:
+        t = _const_zeros[key] = torch.zeros(shape, dtype=dtype, device=device)
+    return t
+
+
+class _XProjCL(torch.autograd.Function):
+    """x_proj once in spatial order (vmamba.py:233-234 evaluated for all K directions at every pixel): x (.., D)
+    activations dtype, w the RAW parameter (K, R + 2, D) -> (.., K*RG) fp32 rows in the scan kernels' padded group layout
+    [R ranks, 0-pad to R8, B, C, 2 pad].  The padding lives inside the Function (one cat forward, one cat backward) instead
+    of a dozen autograd slice ops per call; the output comes from the GEMM's fp32 accumulators (the rows feed softplus /
+    exp).  Backward: tramba_linear_cl / tramba_wgrad_cl."""
 
     @staticmethod
     def forward(ctx, x, w):
-        wa = w.to(x.dtype).contiguous()
+        k, r2, d = w.shape
+        r = r2 - 2
+        rg = hip.ss2d_group_stride(r)
+        wl = w.detach().to(x.dtype)
+        parts = [wl[:, :r]]
+        if rg - 4 - r:
+            parts.append(_zeros_const((k, rg - 4 - r, d), x.dtype, x.device))
+        parts += [wl[:, r:], _zeros_const((k, 2, d), x.dtype, x.device)]
+        wa = torch.cat(parts, dim=1).view(k * rg, d)
         ctx.save_for_backward(x, wa)
-        ctx.wdtype = w.dtype
+        ctx.meta = (w.dtype, k, r, rg)
         return hip.linear_cl(x.contiguous(), wa, out_dtype=torch.float32)
 
     @staticmethod
     def backward(ctx, g):
         x, wa = ctx.saved_tensors
+        wdtype, k, r, rg = ctx.meta
         ga = g.to(x.dtype).reshape(-1, g.shape[-1]).contiguous()
         gx = _dgrad(ga, wa).view(x.shape) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
-            gw = _wgrad(ga, x.reshape(-1, x.shape[-1]))[0].to(ctx.wdtype)
+            gp = _wgrad(ga, x.reshape(-1, x.shape[-1]))[0].view(k, rg, -1)
+            gw = torch.cat((gp[:, :r], gp[:, rg - 4:rg - 2]), dim=1).to(wdtype)
         return gx, gw
 
 
@@ -866,7 +895,7 @@ class SS2D(nn.Module):
         b, h, w, d = x.shape
         order = hip.scan_order(self.scan._tramba_family, h, w, x.device)
         xf = x.reshape(b, h * w, d)
-        xdbl = _LinearF32Out.apply(xf, hip.pad_x_proj_weight(self.x_proj_weight.float()))
+        xdbl = _XProjCL.apply(xf, self.x_proj_weight)
         a_neg = -torch.exp(self.A_logs.float()).reshape(-1)
         ym = _SS2DCoreCL.apply(xf, xdbl, self.dt_projs_weight.float(), self.dt_projs_bias.float().reshape(-1), a_neg,
                                self.Ds.float(), order)
@@ -922,7 +951,8 @@ class _ResidualBlock(nn.Module):
     def _residual(self, x, branch, drop_path):
         """x + drop_path(branch(x_normed)); the add is fused into the branch's last GEMM when possible."""
         if isinstance(drop_path, DropPath) and drop_path.training and drop_path.drop_prob > 0.0:
-            return x + drop_path(branch(None))
+            y = branch(None)
+            return torch.addcmul(x, y, drop_path.mask_for(y))      # x + y * mask / keep in one launch
         return branch(x)
 
 
