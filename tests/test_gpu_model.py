@@ -286,6 +286,32 @@ def test_reducer_on_a_one_rank_rccl_group():
                 assert p.grad is not None and p.grad.dtype == p.dtype, n
                 assert float((p.grad - want[n]).abs().max()) <= tol * float(want[n].abs().max()) + 1e-12, n
             red.remove_hooks()
+        # the same collective path CAPTURED into the training step's hipGraph (GraphedTrainStep with a reducer): the
+        # all-reduces issued from the autograd hooks become graph nodes and replay
+        class Tiny(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                torch.manual_seed(1)
+                self.encoder = ta.VSSBlock(hidden_dim=64, drop_path=0.0, channel_first=True).to(DEV).train()
+                self.compute_dtype = None
+
+            def forward(self, z):
+                return [self.encoder(z).mean(dim=1, keepdim=True)]
+
+        model = Tiny()
+        ref = Tiny()
+        ref.load_state_dict(model.state_dict())
+        xs = torch.randn(2, 64, 24, 24, device=DEV)
+        ys = (torch.rand(2, 1, 24, 24, device=DEV) > 0.5).float()
+        red = parallel.GradBucketReducer(model, bucket_mb=0.05)
+        red.world = 2
+        step = ta.GraphedTrainStep(model, train.get_opt(1e-3, model, capturable=True), reducer=red)
+        got = [float(step(xs, ys)) for _ in range(3)]
+        opt = train.get_opt(1e-3, ref)
+        want = [float(train.train_step(ref, opt, xs, ys)) for _ in range(3)]
+        assert np.allclose(got, want, rtol=2e-3), (got, want)
+        assert want[2] < want[0]
+        red.remove_hooks()
     finally:
         dist.destroy_process_group()
 
