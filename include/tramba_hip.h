@@ -80,7 +80,8 @@ int tramba_tune_set(int knob, int value);
 int tramba_tune_get(int knob);
 #define TRAMBA_TUNE_MERGE_FORM 0
 #define TRAMBA_TUNE_SCAN_FORM 1      /* 1 = chained (register ring), 2 = wave-segment, 3 = chained on LDS-DMA staged operands */
-#define TRAMBA_TUNE_COUNT 2
+#define TRAMBA_TUNE_SCAN_W 2         /* waves per sequence of the register-ring chained scan (capped by the library's own choice) */
+#define TRAMBA_TUNE_COUNT 3
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1
 #define TRAMBA_PROF_GEMM 2          /* tramba_linear_cl (1x1-conv projections) */

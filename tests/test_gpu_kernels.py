@@ -622,11 +622,12 @@ def test_ss2d_backward_small_contractions(b, kk, l, d, r):
 
 
 @pytest.mark.parametrize("fam,h,d,r,b", [("helix", 32, 64, 8, 2), ("helix", 40, 96, 8, 1), ("raster", 48, 32, 4, 3),
-                                         ("window", 96, 256, 8, 1)])
+                                         ("window", 96, 256, 8, 1), ("raster", 48, 64, 16, 2), ("dilation", 24, 1024, 32, 4),
+                                         ("helix", 48, 128, 32, 1), ("window", 48, 512, 12, 4)])
 @pytest.mark.parametrize("ys_dtype", [torch.float32, torch.bfloat16])
 def test_ss2d_scan_forms_agree(fam, h, d, r, b, ys_dtype):
-    """The three schedules of the fused scan -- chained on a register ring (8 waves per sequence), wave-segment (two
-    passes), chained on LDS-DMA staged operands (16 waves per sequence, the Helix 96x96 form) -- compute the same
+    """The three schedules of the fused scan -- chained on a register ring (<= 8 waves per sequence), wave-segment (two
+    passes), chained on LDS-DMA staged operands (16 or 8 waves per sequence, padded dt_rank 8 / 16 / 32) -- compute the same
     recurrence; only the order in which tile aggregates are folded differs.  Ragged last super-chunks included (40x40 =
     1600 positions = 3.125 super-chunks of 512).  The chained form itself is checked against the fp64 oracle above."""
     H = hip()

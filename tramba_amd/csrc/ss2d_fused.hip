@@ -497,16 +497,26 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Chained form, 16 waves per sequence, operands staged by LDS-DMA (16-bit activations, dt_rank <= 8: the 96x96 maps).
-// The register-ring kernel above holds two tiles of gathered operands in VGPRs (~180 registers: 2 waves per SIMD, and the
-// SQ counters show each SIMD's VALU busy only ~55 % of the time at that occupancy).  Here the gathers of tile s+1 --
-// 32 x_dbl rows of 48 bytes and 32 token rows of 64 bytes per wave -- are written straight into a wave-private LDS slot by
-// buffer_load ... lds (no VGPRs), two slots per wave, and tile s is read from its slot right where it is consumed.  The
-// kernel then fits 128 registers: 16 waves per workgroup, 4 waves per SIMD, a super-chunk of 16 tiles per barrier.
-// A wave's own s_waitcnt vmcnt(0) orders its LDS reads behind its DMA (no barrier: the slots are wave-private); the DMA
-// of tile s+1 is issued at the top of step s and has the whole step to land.
-template <typename T, typename TY>
-__global__ __launch_bounds__(1024) void ss2d_scan_dma_kernel(
+// Chained form on LDS-DMA staged operands (16-bit activations, dt_rank padded to R8 in {8, 16, 32}; W = 16 or 8 waves per
+// sequence).  The register-ring kernel above holds two tiles of gathered operands in VGPRs (~180 registers: 2 waves per SIMD,
+// and the SQ counters show each SIMD's VALU busy only ~55 % of the time at that occupancy).  Here the gathers of the next
+// tile -- 32 token rows of 64 bytes and 32 x_dbl rows of (R8 + 4) floats per wave -- are written straight into a
+// wave-private LDS slot by buffer_load ... lds (no VGPRs): the kernel fits 128 registers = 4 waves per SIMD (16 waves per
+// workgroup, or two workgroups of 8 per CU).
+//   step s:  s_waitcnt vmcnt(16)      tile s has landed in my slot, the index vector of tile s + 1 in idxbuf: everything but
+//                                     the 16 y stores of tile s - 1, the only vector-memory ops issued after those DMAs (the
+//                                     counter retires in order)
+//            read the slot            hand-written ds_reads into registers (the operands of ONE tile: 8 NK + 2 + 16 values)
+//            DMA tile s + 1           into the SAME slot (its reads have completed), index vector of tile s + 2 into idxbuf
+//            compute, barrier, fold, replay, 16 stores
+// No vector-memory LOAD the compiler can see lives in the loop, and every read of DMA-written LDS is hand-written: hipcc
+// orders a load result it can see, or an LDS read that may alias a pending DMA, with a vmcnt that -- in order -- also waits
+// for most of the previous tile's y stores; with all waves of a workgroup leaving the barrier together the CU then idled for
+// a store round trip every step (first version: 83-90 us on the Helix launch, SQ_WAIT_ANY 49 % of wave-cycles; now 77-82).
+#define TRAMBA_LDS_RD_(INSTR, OUT, ADDR, OFF) asm volatile(INSTR " %0, %1 offset:" #OFF : "=v"(OUT) : "v"(ADDR) : "memory")
+
+template <typename T, typename TY, int NK, int R8, int W>
+__global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
     const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R)
@@ -514,17 +524,17 @@ __global__ __launch_bounds__(1024) void ss2d_scan_dma_kernel(
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass needs this kernel's launch stub, not its body, and hipcc
                                       // silently drops the stub of a kernel template whose body holds vector-register asm
     static_assert(sizeof(T) == 2, "16-bit activations");
-    constexpr int kW = 16;                      // waves per workgroup
-    constexpr int kRowP = 48;                   // bytes of one x_dbl group with R8 = 8: 8 ranks + B, C + 2 pad
+    static_assert((R8 == 8 && NK == 1) || (R8 == 16 && NK == 1) || (R8 == 32 && NK == 2), "padded rank / MFMA steps");
+    constexpr int kRowP = (R8 + 4) * 4;         // bytes of one x_dbl group: R8 ranks + B, C + 2 pad
+    constexpr int kCPR = kRowP / 16;            // 16-byte chunks per row: 3, 5, 9
+    constexpr int kNCH = kTP * kCPR;            // chunks per tile: 96, 160, 288
+    constexpr int kNP = (kNCH + kWave - 1) / kWave;   // 64-lane DMA pieces: 2, 3, 5 (the last one overshoots into padding)
     constexpr int kUB = kTP * kTP * 2;          // token tile: 32 positions x 32 channels x 2 bytes
-    constexpr int kSlot = kUB + kTP * kRowP + 512;   // 4096 bytes: rows + the overshoot of the last 64-lane piece
-    __shared__ float agg[2][kW][2][kTP];
-    __shared__ __attribute__((aligned(16))) float stage[kW][3][kTP];
-    // two arrays, indexed statically: hipcc waits vmcnt(0) before an LDS read that may alias a pending LDS-DMA's destination;
-    // with the slots in distinct objects the read of slot A does not wait for the DMA into slot B
-    __shared__ __attribute__((aligned(16))) unsigned char ring0[kW][kSlot];
-    __shared__ __attribute__((aligned(16))) unsigned char ring1[kW][kSlot];
-    __shared__ __attribute__((aligned(16))) int idxbuf[kW][kWave];   // the index vector of the tile after next, by DMA too
+    constexpr int kSlot = kUB + kNP * 1024;
+    __shared__ float agg[2][W][2][kTP];
+    __shared__ __attribute__((aligned(16))) float stage[W][3][kTP];
+    __shared__ __attribute__((aligned(16))) unsigned char ring[W][kSlot];
+    __shared__ __attribute__((aligned(16))) int idxbuf[W][kWave];   // the index vector of the next tile to fetch, by DMA too
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -533,10 +543,10 @@ __global__ __launch_bounds__(1024) void ss2d_scan_dma_kernel(
     xcd_work_item(ct_, k_, b_);
     const int k = (int)k_, b = (int)b_, ctile = (int)ct_;
     const int c = ctile * kTP + r32;            // D % 32 == 0 (host-checked): every channel exists
-    const int RG = xdbl_group_stride(R);        // 12
+    const int RG = R8 + 4;
     const int PC = K * RG;
 
-    ScanWave<T, 1, false> w;
+    ScanWave<T, NK, false> w;
     w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + c, R, RG, PC, D, lane, c, &stage[wv][0][0]);
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(1024) void ss2d_scan_dma_kernel(
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(ys + ((long)b * K + k) * L * D, (unsigned)L * yrow);
     const int32_t *tk = table + (long)k * L;
 
-    const int span = kW * kTP;
+    const int span = W * kTP;
     const int nsuper = (L + span - 1) / span;
     const int last = nsuper - 1;
     const __amdgpu_buffer_rsrc_t rt = make_rsrc(tk, (unsigned)L * 4u);
@@ -557,104 +567,106 @@ __global__ __launch_bounds__(1024) void ss2d_scan_dma_kernel(
 
     // loop-invariant lane maps of the DMA pieces (16 bytes per lane, LDS destination = piece base + 16 * lane):
     //   token tile  : 2 pieces; piece j, lane i -> position 16j + i/4, bytes 16*(i%4) .. +15 of this channel tile's 64
-    //   x_dbl rows  : 96 chunks of 16 bytes (3 per position); piece 0 = chunks 0..63, piece 1 = chunks 64..95 (lanes 0..31)
-    const unsigned ucol = (unsigned)(ctile * kTP * 2 + (lane & 3) * 16);
-    const int upos = lane >> 2;
-    const int pch0 = lane, pch1 = 64 + (lane & 31);
-    const int ppos0 = (pch0 * 171) >> 9, ppos1 = (pch1 * 171) >> 9;           // chunk / 3 for chunk < 128
-    const unsigned ppart0 = (unsigned)(pch0 - 3 * ppos0) * 16u, ppart1 = (unsigned)(pch1 - 3 * ppos1) * 16u;
+    //   x_dbl rows  : kNCH chunks of 16 bytes, kCPR per position; piece j = chunks 64j .. 64j + 63 (past the end: the last
+    //                 chunk again, landing in the slot's padding)
     typedef __attribute__((address_space(3))) void lds_void;
+    unsigned char *slot = &ring[wv][0];
     int *ib = &idxbuf[wv][0];
     const unsigned iba = (unsigned)(size_t)(__attribute__((address_space(3))) int *)ib;
+    const unsigned ucol = (unsigned)(ctile * kTP * 2 + (lane & 3) * 16);
+    unsigned ia[2 + kNP];                       // LDS addresses of the index entries my pieces need
+    unsigned ppart[kNP];
+    ia[0] = iba + 4u * (unsigned)(lane >> 2);
+    ia[1] = iba + 4u * (unsigned)(16 + (lane >> 2));
+#pragma unroll
+    for (int j = 0; j < kNP; ++j) {
+        const int ch = 64 * j + lane < kNCH ? 64 * j + lane : kNCH - 1;
+        const int pos = ch / kCPR;
+        ia[2 + j] = iba + 4u * (unsigned)pos;
+        ppart[j] = (unsigned)(ch - pos * kCPR) * 16u;
+    }
 
-    // No vector-memory LOAD the compiler can see lives in the tile loop: the index vector travels by LDS-DMA like the
-    // operands and every read of DMA-written LDS is a hand-written ds_read.  (hipcc orders a load result it can see, or an
-    // LDS read that may alias a pending DMA, with a vmcnt that -- the counter being in order -- also waits for most of the
-    // previous tile's 16 y stores: with 16 waves leaving the barrier together the whole CU then idles for a store round
-    // trip every step.)  The one counted wait at the top of a step covers exactly the DMAs of the step before.
-    auto dma = [&](unsigned char *base, int s_idx) {   // operands of the tile whose index vector sits in idxbuf -> base;
-        unsigned i0 = 0, i1 = 0, i2 = 0, i3 = 0;       // then the index vector of tile s_idx -> idxbuf
-        asm volatile(
-            "ds_read_b32 %0, %4\n\t"
-            "ds_read_b32 %1, %5\n\t"
-            "ds_read_b32 %2, %6\n\t"
-            "ds_read_b32 %3, %7\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
-            : "v"(iba + 4u * (unsigned)upos), "v"(iba + 4u * (unsigned)(16 + upos)), "v"(iba + 4u * (unsigned)ppos0),
-              "v"(iba + 4u * (unsigned)ppos1)
-            : "memory");
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(base), 16, i0 * w.xrow + ucol, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(base + 1024), 16, i1 * w.xrow + ucol, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_void *)(base + kUB), 16, i2 * w.prow + ppart0, 0, 0, 0);
-        // (lanes 32..63 repeat chunks 64..95 into the 512 bytes past the slot's x_dbl rows: kSlotPad)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_void *)(base + kUB + 1024), 16, i3 * w.prow + ppart1, 0, 0, 0);
+    auto dma = [&](int s_idx) {   // operands of the tile whose index vector sits in idxbuf -> my slot, then the index
+        unsigned iv[7] = {0, 0, 0, 0, 0, 0, 0};   // vector of tile s_idx -> idxbuf
+#pragma unroll
+        for (int j = 0; j < 2 + kNP; ++j) TRAMBA_LDS_RD_("ds_read_b32", iv[j], ia[j], 0);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(iv[0]), "+v"(iv[1]), "+v"(iv[2]), "+v"(iv[3]), "+v"(iv[4]), "+v"(iv[5]), "+v"(iv[6])
+                     :
+                     : "memory");
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(slot), 16, iv[0] * w.xrow + ucol, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void *)(slot + 1024), 16, iv[1] * w.xrow + ucol, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < kNP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_void *)(slot + kUB + 1024 * j), 16, iv[2 + j] * w.prow + ppart[j],
+                                                     0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (lds_void *)ib, 4, idx_off(s_idx), 0, 0, 0);
     };
-    // The slot is read by hand-written ds_reads: hipcc tracks LDS-DMA writes and, before an LDS read it can see, waits until
-    // only the DMA ops it has just issued are outstanding -- which, the counter being in order, also waits for the 16 y
-    // stores of the previous tile (the whole workgroup then idles for a store round trip every step: 16 waves leave the
-    // barrier together).  Reads the compiler cannot see are ordered by the counted wait at the top of the step instead.
-    auto from_lds = [&](const unsigned char *base, TileOps<T, 1> &o) {
-        const unsigned pa = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)(base + kUB + r32 * kRowP);
-        const unsigned ua = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)(base + hi * 4 * kTP * 2 + r32 * 2);
-        v4f v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-        v2f bc = {0.f, 0.f};
-        unsigned u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0, u5 = 0, u6 = 0, u7 = 0, u8 = 0, u9 = 0, u10 = 0, u11 = 0, u12 = 0, u13 = 0,
-                 u14 = 0, u15 = 0;
-        asm volatile(
-            "ds_read_b128 %0, %19\n\t"
-            "ds_read_b128 %1, %19 offset:16\n\t"
-            "ds_read_b64 %2, %19 offset:32\n\t"
-            "ds_read_u16 %3, %20\n\t"
-            "ds_read_u16 %4, %20 offset:64\n\t"
-            "ds_read_u16 %5, %20 offset:128\n\t"
-            "ds_read_u16 %6, %20 offset:192\n\t"
-            "ds_read_u16 %7, %20 offset:512\n\t"
-            "ds_read_u16 %8, %20 offset:576\n\t"
-            "ds_read_u16 %9, %20 offset:640\n\t"
-            "ds_read_u16 %10, %20 offset:704\n\t"
-            "ds_read_u16 %11, %20 offset:1024\n\t"
-            "ds_read_u16 %12, %20 offset:1088\n\t"
-            "ds_read_u16 %13, %20 offset:1152\n\t"
-            "ds_read_u16 %14, %20 offset:1216\n\t"
-            "ds_read_u16 %15, %20 offset:1536\n\t"
-            "ds_read_u16 %16, %20 offset:1600\n\t"
-            "ds_read_u16 %17, %20 offset:1664\n\t"
-            "ds_read_u16 %18, %20 offset:1728\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(v0), "=&v"(v1), "=&v"(bc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(u5), "=&v"(u6),
-              "=&v"(u7), "=&v"(u8), "=&v"(u9), "=&v"(u10), "=&v"(u11), "=&v"(u12), "=&v"(u13), "=&v"(u14), "=&v"(u15)
-            : "v"(pa), "v"(ua)
-            : "memory");
-        o.araw[0][0] = v0.x; o.araw[0][1] = v0.y; o.araw[0][2] = v0.z; o.araw[0][3] = v0.w;
-        o.araw[0][4] = v1.x; o.araw[0][5] = v1.y; o.araw[0][6] = v1.z; o.araw[0][7] = v1.w;
+    // my x_dbl row: ranks 16 kk + 8 hi .. +7 (a run past the padded ranks meets all-zero dt_w fragments: run 0 instead),
+    // then (B, C); my 16 token elements: positions (r&3) + 8 (r>>2) + 4 hi of channel r32
+    const unsigned prow_a = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)(slot + kUB + r32 * kRowP);
+    const unsigned pa0 = prow_a + (unsigned)((hi * 8 < R8 ? hi * 8 : 0) * 4);
+    const unsigned pa1 = prow_a + (unsigned)((16 + hi * 8 < R8 ? 16 + hi * 8 : 0) * 4);
+    const unsigned pb = prow_a + (unsigned)(R8 * 4);
+    const unsigned ua = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)(slot + hi * 4 * kTP * 2 + r32 * 2);
+    auto from_lds = [&](TileOps<T, NK> &o) {
+        v4f v[4];
+        v2f bc;
+        unsigned u[16];
+        TRAMBA_LDS_RD_("ds_read_b128", v[0], pa0, 0);
+        TRAMBA_LDS_RD_("ds_read_b128", v[1], pa0, 16);
+        if constexpr (NK == 2) {
+            TRAMBA_LDS_RD_("ds_read_b128", v[2], pa1, 0);
+            TRAMBA_LDS_RD_("ds_read_b128", v[3], pa1, 16);
+        } else {
+            v[2] = v[3] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        TRAMBA_LDS_RD_("ds_read_b64", bc, pb, 0);
+        TRAMBA_LDS_RD_("ds_read_u16", u[0], ua, 0);
+        TRAMBA_LDS_RD_("ds_read_u16", u[1], ua, 64);
+        TRAMBA_LDS_RD_("ds_read_u16", u[2], ua, 128);
+        TRAMBA_LDS_RD_("ds_read_u16", u[3], ua, 192);
+        TRAMBA_LDS_RD_("ds_read_u16", u[4], ua, 512);
+        TRAMBA_LDS_RD_("ds_read_u16", u[5], ua, 576);
+        TRAMBA_LDS_RD_("ds_read_u16", u[6], ua, 640);
+        TRAMBA_LDS_RD_("ds_read_u16", u[7], ua, 704);
+        TRAMBA_LDS_RD_("ds_read_u16", u[8], ua, 1024);
+        TRAMBA_LDS_RD_("ds_read_u16", u[9], ua, 1088);
+        TRAMBA_LDS_RD_("ds_read_u16", u[10], ua, 1152);
+        TRAMBA_LDS_RD_("ds_read_u16", u[11], ua, 1216);
+        TRAMBA_LDS_RD_("ds_read_u16", u[12], ua, 1536);
+        TRAMBA_LDS_RD_("ds_read_u16", u[13], ua, 1600);
+        TRAMBA_LDS_RD_("ds_read_u16", u[14], ua, 1664);
+        TRAMBA_LDS_RD_("ds_read_u16", u[15], ua, 1728);
+        // every destination named: no consumer may be scheduled above this wait (the reads above count as "done" to hipcc)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(bc), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]),
+                       "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]), "+v"(u[8]), "+v"(u[9]), "+v"(u[10]), "+v"(u[11]),
+                       "+v"(u[12]), "+v"(u[13]), "+v"(u[14]), "+v"(u[15])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            o.araw[kk][0] = v[2 * kk].x; o.araw[kk][1] = v[2 * kk].y; o.araw[kk][2] = v[2 * kk].z; o.araw[kk][3] = v[2 * kk].w;
+            o.araw[kk][4] = v[2 * kk + 1].x; o.araw[kk][5] = v[2 * kk + 1].y; o.araw[kk][6] = v[2 * kk + 1].z;
+            o.araw[kk][7] = v[2 * kk + 1].w;
+        }
         o.bv = bc.x;
         o.cv = bc.y;
-        const unsigned uu[16] = {u0, u1, u2, u3, u4, u5, u6, u7, u8, u9, u10, u11, u12, u13, u14, u15};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o.u[r] = (unsigned short)uu[r];
+        for (int r = 0; r < 16; ++r) o.u[r] = (unsigned short)u[r];
     };
-
-    for (int i = threadIdx.x; i < 2 * kW * kTP; i += blockDim.x) {   // (every row is a live wave here; kept for symmetry)
-        agg[i / (kW * kTP)][(i / kTP) % kW][0][i % kTP] = 1.f;
-        agg[i / (kW * kTP)][(i / kTP) % kW][1][i % kTP] = 0.f;
-    }
-    __syncthreads();
 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (lds_void *)ib, 4, idx_off(0), 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    dma(&ring0[wv][0], 1);                                     // tile 0 -> slot 0, index vector of tile 1
+    dma(1);                                                    // tile 0 -> my slot, index vector of tile 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (no stores outstanding yet: a counted wait would not wait)
     float carry = 0.f;
-    auto step = [&](auto slot_c, int s) {
-        constexpr int slot = decltype(slot_c)::value;
-        // tile s has landed in my slot and the index vector of tile s + 1 in idxbuf: everything but the 16 y stores of
-        // tile s - 1, the only vector-memory ops issued after those DMAs (the counter retires in order)
+    for (int s = 0; s < nsuper; ++s) {
         if (s > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        dma(slot ? &ring0[wv][0] : &ring1[wv][0], s + 2);       // tile s + 1 (clamped past the end: fetched, never used)
-        TileOps<T, 1> cur;
-        from_lds(slot ? &ring1[wv][0] : &ring0[wv][0], cur);
+        TileOps<T, NK> cur;
+        from_lds(cur);
+        dma(s + 2);                                             // tile s + 1 (clamped past the end: fetched, never used)
         const int l0 = s * span + wv * kTP;
         float Bp[16], Cp[16];
         w.stage_bc(cur, Bp, Cp, false);
@@ -672,7 +684,7 @@ __global__ __launch_bounds__(1024) void ss2d_scan_dma_kernel(
         asm volatile("" ::: "memory");
         float h = carry, hin = carry;
 #pragma unroll
-        for (int q = 0; q < kW; ++q) {
+        for (int q = 0; q < W; ++q) {
             if (q == wv) hin = h;
             h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
         }
@@ -685,13 +697,10 @@ __global__ __launch_bounds__(1024) void ss2d_scan_dma_kernel(
             w.template replay<TY, true>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, true, L - l0);
         }
         __builtin_amdgcn_wave_barrier();
-    };
-    for (int s = 0; s < nsuper; s += 2) {
-        step(std::integral_constant<int, 0>{}, s);
-        if (s + 1 < nsuper) step(std::integral_constant<int, 1>{}, s + 1);   // block-uniform
     }
 #endif
 }
+#undef TRAMBA_LDS_RD_
 
 // ---------------------------------------------------------------------------------------------
 // Backward of the fused channels-last scan (training).  Same decomposition as ss2d_scan_cl_kernel -- a
@@ -1582,24 +1591,35 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     const int form_tune = tramba_tune_get(TRAMBA_TUNE_SCAN_FORM);      // 1 = chained, 2 = wave-segment, 3 = chained on LDS-DMA
     const bool use_seg = workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) &&
                          (form_tune == 2 || (form_tune == 0 && seg_wins));   // (the LDS-DMA form below is tried first)
-    // ---- chained form, 16 waves per sequence on LDS-DMA staged operands (4 waves per SIMD): 16-bit maps with dt_rank <= 8
-    //      whose sequences fill the chip at 16 waves each (the Helix order at 96x96: 256 sequences x 16 = 4096 waves)
+    // ---- chained form on LDS-DMA staged operands (4 waves per SIMD): 16-bit maps with dt_rank <= 32 whose sequences fill
+    //      the chip at 16 or at 8 waves each
     {
         const int scan_tune = tramba_tune_get(TRAMBA_TUNE_SCAN_FORM);
         const long seqs = (long)batch * k * ct;
-        const bool dma_ok = dtype != TRAMBA_F32 && r <= 8 && d % kTP == 0 && l >= 16 * kTP;
-        // (measured, scripts/bench_scan.py, 96x96 D=256 B=4: Helix K=8, 256 sequences: 83-90 us against 96 on the register ring;
-        //  raster K=4, 128 sequences -- half the CUs -- 78 against 85-89 for the wave-segment form)
-        if (dma_ok && (scan_tune == 3 || (scan_tune == 0 && seqs >= 128 && seqs * 16 <= 4096))) {
-            dim3 grid(ct, k, batch), block(16 * kWave);
-#define DMA_(T, TY) \
-    hipLaunchKernelGGL((ss2d_scan_dma_kernel<T, TY>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, dt_bias, A, Ds, \
-                       (TY *)ys, l, d, k, r)
+        const int r8 = xdbl_rank_pad(r);
+        const int wdma = seqs * 16 <= 4096 ? 16 : 8;
+        const bool dma_ok = dtype != TRAMBA_F32 && (r8 == 8 || r8 == 16 || r8 == 32) && d % kTP == 0 && l >= 2 * wdma * kTP &&
+                            seqs * wdma <= 4096;
+        // (measured, scripts/bench_scan.py / bench_scan_w.py, B=4: Helix 96x96 K=8, 256 sequences: 77-82 us against 96 on the
+        //  register ring; raster 96x96 K=4, 128 sequences -- half the CUs -- 72 against 85-89 for the wave-segment form; Helix
+        //  48x48, 512 sequences x 8 waves: 42 against 52; no gain below ~4 super-chunks per sequence -- 24x24: 25 = 25 --
+        //  where the two memory round trips of the prologue weigh as much as the tiles)
+        if (dma_ok && (scan_tune == 3 || (scan_tune == 0 && seqs * wdma >= 2048 && p.ntiles >= 4 * wdma))) {
+            dim3 grid(ct, k, batch), block(wdma * kWave);
+#define DMA_(T, TY, NK_, R8_, W_) \
+    hipLaunchKernelGGL((ss2d_scan_dma_kernel<T, TY, NK_, R8_, W_>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, dt_bias, \
+                       A, Ds, (TY *)ys, l, d, k, r)
+#define DMA_W_(T, TY, NK_, R8_) \
+    if (wdma == 16) { DMA_(T, TY, NK_, R8_, 16); } else { DMA_(T, TY, NK_, R8_, 8); }
+#define DMA_R_(T, TY) \
+    if (r8 == 8) { DMA_W_(T, TY, 1, 8) } else if (r8 == 16) { DMA_W_(T, TY, 1, 16) } else { DMA_W_(T, TY, 2, 32) }
             if (dtype == TRAMBA_BF16) {
-                if (ys_dtype == TRAMBA_F32) DMA_(__hip_bfloat16, float); else DMA_(__hip_bfloat16, __hip_bfloat16);
+                if (ys_dtype == TRAMBA_F32) { DMA_R_(__hip_bfloat16, float) } else { DMA_R_(__hip_bfloat16, __hip_bfloat16) }
             } else {
-                if (ys_dtype == TRAMBA_F32) DMA_(__half, float); else DMA_(__half, __half);
+                if (ys_dtype == TRAMBA_F32) { DMA_R_(__half, float) } else { DMA_R_(__half, __half) }
             }
+#undef DMA_R_
+#undef DMA_W_
 #undef DMA_
             TRAMBA_LAUNCH_CHECK();
             return TRAMBA_OK;
@@ -1635,6 +1655,10 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     int W = kMaxW;
     while (W > 1 && (long)batch * k * ct * W > 2048) W >>= 1;
     if (W > (l + kTP - 1) / kTP) W = (l + kTP - 1) / kTP;
+    if (tramba_tune_get(TRAMBA_TUNE_SCAN_W) > 0) {   // A/B timing hook (scripts/bench_scan.py)
+        W = tramba_tune_get(TRAMBA_TUNE_SCAN_W) < kMaxW ? tramba_tune_get(TRAMBA_TUNE_SCAN_W) : kMaxW;
+        if (W > (l + kTP - 1) / kTP) W = (l + kTP - 1) / kTP;
+    }
     dim3 grid(ct, k, batch), block(W * kWave);
 #define GO_(T, TY, NK_, SP_)                                                                               \
     hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK_, SP_>), grid, block, 0, s, (const T *)x, xdbl, table, \

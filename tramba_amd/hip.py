@@ -206,7 +206,7 @@ def scan_order(family: str, h: int, w: int, device, param: int = 0) -> ScanOrder
 
 
 # ----------------------------------------------------------------------------- profiling / tuning
-TUNE_MERGE_FORM, TUNE_SCAN_FORM = 0, 1
+TUNE_MERGE_FORM, TUNE_SCAN_FORM, TUNE_SCAN_W = 0, 1, 2
 
 
 def tune_set(knob: int, value: int):
