@@ -30,13 +30,16 @@ Rank 0 prints ONE JSON line.  Objects on that line besides the contract's fields
   cpu_baseline  the CPU oracle (a port of the reference forward, oracle/) timed on this host (N = 1 only)
   train         BASELINE configs[2]/[3]: fwd + bwd + two-group Adam at batch 8 per GPU, gradients averaged over RCCL
                 when N > 1 (bucketed, overlapped with backward), eager launches and -- when the capture succeeds on every
-                rank -- the same step replayed as one hipGraph
+                rank -- the same step replayed as one hipGraph; `train.roofline` = the forward + input-gradient GEMMs of
+                the step against the dense MFMA peak.  The leg runs under a watchdog (--train-timeout): if a collective
+                never completes, rank 0 still prints the line, with train = {"error": ...}
 """
 import argparse
 import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -70,6 +73,10 @@ def parse():
                     help="with N > 1 also capture the data-parallel step (RCCL all-reduces included) as one hipGraph; off by "
                          "default: collective capture has only been exercised on one rank, and a rank stuck in a capture "
                          "would take the whole multi-GPU run with it")
+    ap.add_argument("--train-timeout", type=float, default=420.0,
+                    help="seconds the training leg (and the final barrier) may take before every rank gives up on it: rank 0 "
+                         "then prints the line with the forward result and train = {error}, so that a stuck collective "
+                         "cannot cost the run its forward measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (gloo only to rehearse the N > 1 plumbing on a one-GPU box)")
     return ap.parse_args()
@@ -378,6 +385,20 @@ def bench_train(args, world, rank, dtype, sync_all):
                         "launched from autograd hooks and overlap the rest of backward"}
         # (the buckets now hold scribble; the next step's prepare() / fill overwrites them)
     # the same step replayed as ONE hipGraph (collectives captured with it when world > 1: opt-in, --graph-dp)
+    # the dominant kernel family of the step: forward + input-gradient GEMMs (tramba_linear_cl), HIP-event pairs around
+    # every launch of two extra eager steps (not part of the timed region)
+    from tramba_amd import hip
+    hip.profile_enable(hip.PROF_GEMM, True)
+    for _ in range(2):
+        train.train_step(model, opt, x, y, reducer=red)
+    ng, msg, flops = hip.profile_read(hip.PROF_GEMM)
+    hip.profile_enable(hip.PROF_GEMM, False)
+    tfs = flops / (msg * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": "linear_lean_kernel / linear_tiled_kernel: forward + input-gradient GEMMs of the step",
+            "achieved": round(tfs, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_PEAK_TFS, 4),
+            "traffic": None, "launches": ng // 2, "avg_us": round(msg / ng * 1e3, 2), "ms_per_step": round(msg / 2, 3),
+            "note": "2*M*N*K of every tramba_linear_cl launch / HIP-event time, two eager steps; the weight-gradient GEMMs "
+                    "(wgrad_tn_kernel) and the scan backward are the next two families (profiles/*_train_kernel_stats.csv)"}
     if world > 1 and not args.graph_dp:
         graphed = {"skipped": "N > 1: pass --graph-dp to capture the data-parallel step (collectives included)"}
     else:
@@ -391,7 +412,7 @@ def bench_train(args, world, rank, dtype, sync_all):
             "parallelism": f"dp{world}" + ((", RCCL all-reduce (ncclAvg)" if args.backend == "nccl" else ", gloo all-reduce")
                                             + " of gradient buckets from autograd hooks" if world > 1 else ", no collective"),
             "stochastic_depth": "on (0.6 enc / 0.2 dec)", "dtype": args.dtype + " activations, fp32 master weights",
-            "graphed": graphed}
+            "roofline": roof, "graphed": graphed}
 
 
 def main():
@@ -501,16 +522,7 @@ def main():
                   "note": "2*M*N*K of every tramba_linear_cl launch of a step / their HIP-event time; these GEMMs are "
                           "small (M = 576..36864, K <= 4096): LDS- and latency-bound, far from the dense MFMA peak"}
         roof_b = boundary_scan_roofline(dtype)
-    train_obj = None
-    if not args.no_train:
-        train_obj = bench_train(args, world, rank, dtype, sync_all)
-    # the CPU baseline runs LAST: its OpenMP team keeps spinning on the host cores for a while and slows the eager launch
-    # thread of whatever follows (r02: 60.5 instead of 55 ms per eager training step right after it)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.img, args.cpu_baseline_full)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    line = None
     if rank == 0:
         line = {
             "metric": "images/sec fwd Tramba-V 384x384", "value": round(value, 2), "unit": "img/s",
@@ -524,10 +536,46 @@ def main():
                                  ("" if args.no_overlap else ", decoder guide branches on a side stream")},
             "latency_b1": lat,
             "roofline": roof, "roofline_kernel_boundary": roof_kb, "roofline_fused_scan_all": roof_all,
-            "roofline_boundary": roof_b, "roofline_gemm": roof_g, "cpu_baseline": cpu, "train": train_obj,
+            "roofline_boundary": roof_b, "roofline_gemm": roof_g, "cpu_baseline": None, "train": None,
         }
-        print(json.dumps(line), flush=True)
+    # From here on the ranks exchange gradients.  A watchdog thread bounds the leg: if it (or the final barrier) has not
+    # finished in --train-timeout seconds, rank 0 prints the line it already holds and every rank leaves -- a collective that
+    # never completes must not cost the run its forward measurement.
+    done = threading.Event()
 
+    def watchdog():
+        if done.wait(args.train_timeout):
+            return
+        if rank == 0:
+            line["train"] = {"error": f"training leg not finished after {args.train_timeout:.0f} s (rank 0 gave up; "
+                                      f"N = {world}, backend {args.backend})"}
+            print(json.dumps(line), flush=True)
+        os._exit(0 if rank == 0 else 3)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    train_obj = None
+    if not args.no_train:
+        ok = torch.ones(1, device="cuda")
+        try:
+            train_obj = bench_train(args, world, rank, dtype, sync_all)
+        except Exception as e:   # reported, not raised: the forward result stands on its own
+            train_obj = {"error": f"{type(e).__name__}: {e}"[:400]}
+            ok.zero_()
+            print(f"bench.py: rank {rank}: training leg failed: {train_obj['error']}", file=sys.stderr)
+        if world > 1 and float(ok.item()) > 0:
+            dist.barrier()
+    if world > 1 and (train_obj is None or "error" not in train_obj):
+        dist.destroy_process_group()
+    done.set()
+    # the CPU baseline runs LAST: its OpenMP team keeps spinning on the host cores for a while and slows the eager launch
+    # thread of whatever follows (r02: 60.5 instead of 55 ms per eager training step right after it)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.img, args.cpu_baseline_full)
+        line["train"] = train_obj
+        print(json.dumps(line), flush=True)
+    if world > 1 and train_obj is not None and "error" in train_obj:
+        os._exit(0 if rank == 0 else 3)   # peers may be parked in a collective this rank never joins: leave without teardown
 
 if __name__ == "__main__":
     main()

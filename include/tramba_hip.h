@@ -53,7 +53,10 @@ typedef enum {
 } tramba_scan_family;
 
 typedef enum { TRAMBA_ACT_NONE = 0, TRAMBA_ACT_SILU = 1, TRAMBA_ACT_GELU = 2,
-               TRAMBA_ACT_SIGMOID_GATE = 3 /* GEMM epilogue only: y = sigmoid(acc + bias) * residual */ } tramba_act;
+               TRAMBA_ACT_SIGMOID_GATE = 3 /* GEMM epilogue only: y = sigmoid(acc + bias) * residual */,
+               TRAMBA_ACT_GELU_GRAD_MUL = 4 /* GEMM epilogue only: y = (acc + bias) * gelu'(residual) -- the input gradient
+                                               of `Linear(GELU(h))` in one launch, residual = h (training path) */
+             } tramba_act;
 
 #define TRAMBA_OK 0
 #define TRAMBA_ERR_ARG (-1)
@@ -241,6 +244,15 @@ int tramba_wgrad_cl(const void *gy, const void *x, float *out, void *workspace, 
  * of the SS2D backward (vmamba.py:236 under autograd): d(x_dbl ranks) = d(dt_raw) @ dt_projs_weight[k]. */
 int tramba_rows_gemm_cl(const void *x, const void *w, float *y, int nz, int64_t m, int n, int k, int groups, int ldy,
                         int dtype, void *stream);
+/* The 16-bit copies of a model's fp32 master weights that the next training step reads (the reference keeps fp32 weights
+ * and lets autocast cast per call, Trambav6.py:151-154 / train.py:74-89): for every table entry t,
+ *   dst[t] (rows, cols) = (dtype) src[t],   dst_t[t] (cols, rows) = its transpose      (either pointer may be 0: skipped)
+ * table: DEVICE array of ntensors x 6 int64 {src, dst, dst_t, rows, cols, first_tile}; a tensor owns
+ * ceil(rows/64)*ceil(cols/64) consecutive tiles starting at first_tile (ascending), total_tiles = their sum. */
+int tramba_shadow_cast_multi(const void *table, int ntensors, int64_t total_tiles, int dtype, void *stream);
+/* out[i] = sum over s < nslab of part[s*n + i], i < n, summed in slab order (deterministic): the per-workgroup partial sums
+ * of the LayerNorm / depth-wise / scan parameter gradients.  n % 4 == 0, 16-byte aligned. */
+int tramba_slab_sum(const float *part, float *out, int64_t n, int nslab, void *stream);
 
 /* The whole last decoder stage in one kernel (FinalPatchExpand_X4 + seg_layers[-1], Trambav6.py:132-137):
  * y (B, H*P, W*P) f32 = head(LayerNorm_128(pixel_shuffle_P(x @ w^T))).  x (B, H, W, Cin) dtype, w (P*P*128, Cin) dtype

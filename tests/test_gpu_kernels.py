@@ -574,6 +574,52 @@ def test_linear2_cl_matches_concatenated_gemm(dtype, cfg):
     np.testing.assert_allclose(gate.cpu().double().numpy(), want.cpu().numpy(), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mnk", [(2304, 512, 2048), (576, 1024, 512), (333, 72, 136), (100, 30, 50)])
+def test_linear_gelu_grad_epilogue(dtype, mnk):
+    """TRAMBA_ACT_GELU_GRAD_MUL: y = (x @ w^T + b) * gelu'(h) -- the input gradient of Linear(GELU(h)) in one launch --
+    against fp64 autograd of the exact (erf) GELU; tiled and fallback kernels (ragged / unaligned shapes), and the gate /
+    gradient modes refuse to run without their second operand."""
+    m, n, k = mnk
+    H = hip()
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dtype).to(DEV)
+    h = (torch.randn(m, n, generator=g) * 1.5).to(dtype).to(DEV)
+    hd = h.double().requires_grad_(True)
+    (dg,) = torch.autograd.grad(F.gelu(hd).sum(), hd)
+    want = (x.double() @ w.double().T) * dg
+    got = H.linear_cl(x, w, None, h, H.ACT_GELU_GRAD_MUL)
+    assert got.dtype == dtype
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.cpu().numpy(), rtol=tol, atol=tol * max(1.0, float(want.abs().max())))
+    for act in (H.ACT_GELU_GRAD_MUL, H.ACT_SIGMOID_GATE):
+        with pytest.raises(H.TrambaHipError, match="residual"):
+            H.linear_cl(x, w, None, None, act)
+
+
+def test_shadow_cast_multi_matches_cast_and_transpose():
+    """tramba_shadow_cast_multi: one launch writes the 16-bit copy and the 16-bit transpose of every matrix in a device
+    table (ragged shapes, shapes below one tile, a skipped destination) == .to(dtype) / .t() bit for bit."""
+    H = hip()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(512, 2048), (2048, 512), (136, 1024), (1, 128), (40, 8), (65, 67), (3, 5), (1024, 1024)]
+    for dtype in (torch.bfloat16, torch.float16):
+        src = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+        dst = [torch.full(s, 7.0, dtype=dtype, device=DEV) for s in shapes]
+        dst_t = [torch.full((s[1], s[0]), 7.0, dtype=dtype, device=DEV) for s in shapes]
+        rows, first = [], 0
+        for i, (a, b, c) in enumerate(zip(src, dst, dst_t)):
+            r, cc = a.shape
+            rows.append([a.data_ptr(), 0 if i == 3 else b.data_ptr(), 0 if i == 4 else c.data_ptr(), r, cc, first])
+            first += ((r + 63) // 64) * ((cc + 63) // 64)
+        table = torch.tensor(rows, dtype=torch.int64).to(DEV)
+        H.shadow_cast_multi(table, len(rows), first, dtype)
+        for i, (a, b, c) in enumerate(zip(src, dst, dst_t)):
+            assert torch.equal(b, torch.full_like(b, 7.0) if i == 3 else a.to(dtype)), (i, dtype)
+            assert torch.equal(c, torch.full_like(c, 7.0) if i == 4 else a.to(dtype).t()), (i, dtype)
+
+
 # ----------------------------------------------------------------------------- training-path GEMMs (train_gemm.hip)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,n,k", [(576, 128, 512), (2304, 256, 128), (1000, 8, 136), (33, 264, 72), (9216, 48, 256),

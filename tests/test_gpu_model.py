@@ -478,9 +478,20 @@ def test_training_weight_shadows_follow_the_optimizer():
     sh = M._lowp(lin.weight, torch.bfloat16)
     assert sh.data_ptr() == M._lowp_shadow[id(lin.weight)][0].data_ptr()           # the shadow, not a new tensor
     assert torch.equal(sh, lin.weight.detach().to(torch.bfloat16))
+    # every Linear2d weight: shadow == cast, transposed shadow == its transpose (one multi-tensor launch wrote them all)
+    nlin = 0
+    for mod in m.modules():
+        if isinstance(mod, ta.Linear2d):
+            w16 = mod.weight.detach().to(torch.bfloat16)
+            assert torch.equal(M._lowp(mod.weight, torch.bfloat16), w16)
+            wt = M._lowp_t(mod.weight, torch.bfloat16)
+            assert wt is not None and wt.shape == (w16.shape[1], w16.shape[0]) and torch.equal(wt, w16.t())
+            nlin += 1
+    assert nlin > 100
     with torch.no_grad():
         lin.weight.mul_(0.5)                                                        # out-of-band update: version moves on
     fresh = M._lowp(lin.weight, torch.bfloat16)
     assert fresh.data_ptr() != sh.data_ptr() and torch.equal(fresh, lin.weight.detach().to(torch.bfloat16))
+    assert M._lowp_t(lin.weight, torch.bfloat16) is None                           # stale: the caller transposes
     l2 = float(train.train_step(m, opt, x, y))                                      # and training goes on
     assert np.isfinite(l2)

@@ -140,6 +140,20 @@ __device__ __forceinline__ float geluf_(float x)
 {
     return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752440f));
 }
+// d/dx of the exact GELU: Phi(x) + x phi(x), with the same erf as the forward
+__device__ __forceinline__ float gelu_gradf_(float x)
+{
+    const float cdf = 0.5f * (1.f + erf_as(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.5f * x * x * 1.44269504088896f);
+    return fmaf(x, pdf, cdf);
+}
+// how a GEMM epilogue combines its activated value with the `residual` operand
+__device__ __forceinline__ float combine_residual(float o, float r, int act)
+{
+    if (act == TRAMBA_ACT_SIGMOID_GATE) return o * r;
+    if (act == TRAMBA_ACT_GELU_GRAD_MUL) return o * gelu_gradf_(r);
+    return o + r;
+}
 __device__ __forceinline__ float apply_act(float x, int act)
 {
     if (act == TRAMBA_ACT_SILU) return siluf_(x);

@@ -74,7 +74,7 @@ __device__ __forceinline__ void store_tile(const acc16_t &acc, TO *__restrict__ 
         const long row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M) {
             float v = apply_act(acc[r] + bv, act);
-            if (res) v += Cvt<T>::to_f(res[row * N + col]);
+            if (res) v = combine_residual(v, Cvt<T>::to_f(res[row * N + col]), act);
             y[row * N + col] = Cvt<TO>::from_f(v);
         }
     }
@@ -229,7 +229,7 @@ __device__ __forceinline__ void tile_epilogue(ACC &acc, unsigned char *lds,
                 float rv[CPL];
                 load_pack<T, CPL>(res + grow * N + gcol, rv);
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) o[q] = act == TRAMBA_ACT_SIGMOID_GATE ? o[q] * rv[q] : o[q] + rv[q];
+                for (int q = 0; q < CPL; ++q) o[q] = combine_residual(o[q], rv[q], act);
             }
             store_pack<TO, CPL>(y + grow * N + gcol, o);
         } else {
@@ -240,7 +240,7 @@ __device__ __forceinline__ void tile_epilogue(ACC &acc, unsigned char *lds,
                     float t = apply_act(o[q] + (bias ? bias[gcol + q] : 0.f), act);
                     if (res) {
                         const float rv = Cvt<T>::to_f(res[grow * N + gcol + q]);
-                        t = act == TRAMBA_ACT_SIGMOID_GATE ? t * rv : t + rv;
+                        t = combine_residual(t, rv, act);
                     }
                     y[grow * N + gcol + q] = Cvt<TO>::from_f(t);
                 }
@@ -818,6 +818,9 @@ extern "C" int tramba_linear_cl(const void *x, const void *w, const float *bias,
     TRAMBA_CHECK(x && w && y, "linear_cl: null tensor");
     TRAMBA_CHECK(m > 0 && n > 0 && k > 0, "linear_cl: empty shape");
     TRAMBA_CHECK(out_dtype == dtype || out_dtype == TRAMBA_F32, "linear_cl: out dtype must be dtype or f32");
+    TRAMBA_CHECK(act >= TRAMBA_ACT_NONE && act <= TRAMBA_ACT_GELU_GRAD_MUL, "linear_cl: unknown activation %d", act);
+    TRAMBA_CHECK(residual || (act != TRAMBA_ACT_SIGMOID_GATE && act != TRAMBA_ACT_GELU_GRAD_MUL),
+                 "linear_cl: activation %d combines with a `residual` operand, none given", act);
     const long gy = (m + 127) / 128, gx = (n + 127) / 128;
     TRAMBA_CHECK(gy <= 65535, "linear_cl: M=%ld exceeds grid limits", (long)m);
     hipStream_t s = (hipStream_t)stream;

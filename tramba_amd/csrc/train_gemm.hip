@@ -17,6 +17,12 @@
 // 2. rows_gemm: y[z][t][0..N) = x[z][t][:] . w[z % groups][n][:], N <= 64, fp32 rows written with a row stride -- the
 //    dt_rank projection of the SS2D backward (graw (B,K,L,D) x dt_w (K,D,R) -> the first R floats of every x_dbl-gradient
 //    row), one launch for all (b, k).
+// 3. shadow_cast_multi: the 16-bit copies of the fp32 master weights that the next step's GEMMs read -- W (N,K) for the
+//    forward and W^T (K,N) for the input gradient (dx = gy @ W runs on the forward kernel with the transposed weight) --
+//    written for EVERY 2-D weight of a model by one launch after the optimizer step, from a device-resident table of
+//    tensors (64 x 64 tiles, tile -> tensor by binary search).  Replaces ~230 cast and ~230 transpose launches per step.
+// 4. slab_sum: out[i] = sum_s part[s][i] in a fixed order -- the partial sums of the LayerNorm / depth-wise / scan
+//    parameter gradients.
 #include "common.h"
 
 namespace tramba {
@@ -266,6 +272,79 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const T *__restrict__ x,
     }
 }
 
+// ---- multi-tensor cast (+ transpose) of fp32 matrices: table[t] = {src, dst, dst_t, rows, cols, first_tile} (int64 each)
+constexpr int kShadowTile = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void shadow_cast_multi_kernel(const long *__restrict__ table, int ntensors)
+{
+    __shared__ T tile[kShadowTile][kShadowTile + 2];
+    const long tileid = blockIdx.x;
+    int lo = 0, hi = ntensors - 1;                  // last tensor whose first tile is <= tileid
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(long)mid * 6 + 5] <= tileid) lo = mid; else hi = mid - 1;
+    }
+    const long *e = table + (long)lo * 6;
+    const float *src = reinterpret_cast<const float *>(e[0]);
+    T *dst = reinterpret_cast<T *>(e[1]);
+    T *dst_t = reinterpret_cast<T *>(e[2]);
+    const long rows = e[3], cols = e[4];
+    const long local = tileid - e[5];
+    const long tiles_c = (cols + kShadowTile - 1) / kShadowTile;
+    const long r0 = (local / tiles_c) * kShadowTile, c0 = (local % tiles_c) * kShadowTile;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const bool vec = (cols & 3) == 0;               // 16-byte loads / 8-byte stores of whole quads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long r = r0 + ty + 16 * i, c = c0 + 4 * tx;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            if (vec && c + 4 <= cols) {
+                const float4 q = *reinterpret_cast<const float4 *>(src + r * cols + c);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < cols) v[j] = src[r * cols + c + j];
+            }
+        }
+        T o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = Cvt<T>::from_f(v[j]);
+            tile[ty + 16 * i][4 * tx + j] = o[j];
+        }
+        if (dst && r < rows) {
+            if (vec && c + 4 <= cols) {
+                *reinterpret_cast<uint2 *>(dst + r * cols + c) = *reinterpret_cast<const uint2 *>(o);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < cols) dst[r * cols + c + j] = o[j];
+            }
+        }
+    }
+    if (!dst_t) return;                              // (uniform over the block)
+    __syncthreads();
+    const bool vec_t = (rows & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long c = c0 + ty + 16 * i, r = r0 + 4 * tx;   // output row = source column
+        if (c >= cols) continue;
+        T o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = tile[4 * tx + j][ty + 16 * i];
+        if (vec_t && r + 4 <= rows) {
+            *reinterpret_cast<uint2 *>(dst_t + c * rows + r) = *reinterpret_cast<const uint2 *>(o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r + j < rows) dst_t[c * rows + r + j] = o[j];
+        }
+    }
+}
+
 }  // namespace tramba
 
 using namespace tramba;
@@ -345,6 +424,31 @@ extern "C" int tramba_rows_gemm_cl(const void *x, const void *w, float *y, int n
     else
         hipLaunchKernelGGL((rows_gemm_kernel<__half>), grid, block, 0, s, (const __half *)x, (const __half *)w, y, (int)m, n,
                            k, groups, ldy);
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_shadow_cast_multi(const void *table, int ntensors, int64_t total_tiles, int dtype, void *stream)
+{
+    TRAMBA_CHECK(table && ntensors > 0 && total_tiles > 0, "shadow_cast_multi: empty table");
+    TRAMBA_CHECK(dtype == TRAMBA_BF16 || dtype == TRAMBA_F16, "shadow_cast_multi: 16-bit shadows only");
+    TRAMBA_CHECK(total_tiles < (1ll << 31), "shadow_cast_multi: too many tiles");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)total_tiles), block(256);
+    if (dtype == TRAMBA_BF16)
+        hipLaunchKernelGGL((shadow_cast_multi_kernel<__hip_bfloat16>), grid, block, 0, s, (const long *)table, ntensors);
+    else
+        hipLaunchKernelGGL((shadow_cast_multi_kernel<__half>), grid, block, 0, s, (const long *)table, ntensors);
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_slab_sum(const float *part, float *out, int64_t n, int nslab, void *stream)
+{
+    TRAMBA_CHECK(part && out && n > 0 && nslab > 0, "slab_sum: empty input");
+    TRAMBA_CHECK(aligned16(part) && aligned16(out) && n % 4 == 0, "slab_sum: rows of whole, 16-byte aligned float4s");
+    dim3 grid((unsigned)((n / 4 + 255) / 256), 1);
+    hipLaunchKernelGGL(slab_sum_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, out, (long)n, nslab);
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }

@@ -141,9 +141,12 @@ class GraphedTrainStep:
                 train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        from .modules import _mask_pool
+        _mask_pool.forget_draw()                            # the step's one stochastic-depth draw must be IN the graph
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):                       # records, executes nothing
             loss = train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
+        _mask_pool.forget_draw()                            # (the table drawn during capture lives in the graph's pool)
         self._restore(saved)
         torch.cuda.set_rng_state(rng, dev)
         return graph, sx, sy, loss

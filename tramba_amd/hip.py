@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libtramba_hip.so")
 
 F32, F16, BF16 = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_GELU, ACT_SIGMOID_GATE = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_SIGMOID_GATE, ACT_GELU_GRAD_MUL = 0, 1, 2, 3, 4
 SCAN_RASTER, SCAN_LINE, SCAN_HELIX, SCAN_WINDOW, SCAN_DILATION = range(5)
 FAMILY = {"raster": SCAN_RASTER, "line": SCAN_LINE, "helix": SCAN_HELIX, "window": SCAN_WINDOW,
           "dilation": SCAN_DILATION}
@@ -69,6 +69,8 @@ SIGNATURES = {
     "tramba_wgrad_cl": (c_int, [c_vp] * 4 + [ctypes.c_size_t, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_int, c_i64,
                                              c_i64, c_int, c_int, c_int, c_vp]),
     "tramba_rows_gemm_cl": (c_int, [c_vp] * 3 + [c_int, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_shadow_cast_multi": (c_int, [c_vp, c_int, c_i64, c_int, c_vp]),
+    "tramba_slab_sum": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     "tramba_expand_norm_head_cl": (c_int, [c_vp] * 5 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_conv3x3s2_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
     "tramba_stem_conv_ln_gelu": (c_int, [c_vp] * 6 + [c_int] * 3 + [c_f, c_int, c_int, c_vp]),
@@ -645,6 +647,15 @@ def rows_gemm_cl(x, w, y, n):
     _check(lib().tramba_rows_gemm_cl(_ptr(x), _ptr(w), _ptr(y), z, m, n, k, w.shape[0], y.shape[-1], dt(x), _stream()),
            "rows_gemm_cl")
     return y
+
+
+def shadow_cast_multi(table, ntensors, total_tiles, dtype):
+    """One launch over a device-resident table (ntensors, 6) int64 {src f32, dst, dst_t, rows, cols, first_tile}: every
+    dst = src cast to `dtype`, every dst_t = its transpose (tramba_amd.modules.refresh_lowp_shadows builds the table)."""
+    _dev(table)
+    if table.dtype != torch.int64 or table.shape != (ntensors, 6) or not table.is_contiguous():
+        raise TrambaHipError("shadow_cast_multi: table must be a contiguous (ntensors, 6) int64 tensor")
+    _check(lib().tramba_shadow_cast_multi(_ptr(table), ntensors, total_tiles, _DT[dtype], _stream()), "shadow_cast_multi")
 
 
 def conv3x3s2_cl(x, w_kmajor, bias):

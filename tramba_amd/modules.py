@@ -118,9 +118,10 @@ def _wgrad(gy2, x2, want_bias=False):
     return gw, (gy2.sum(0) if want_bias else None)
 
 
-def _dgrad(gy2, wa):
-    """Input gradient of y = x @ W^T: gy2 (M, N) @ wa (N, K) on the forward GEMM kernel, with the weight transposed once."""
-    return hip.linear_cl(gy2, wa.t().contiguous())
+def _dgrad(gy2, wa, wa_t=None):
+    """Input gradient of y = x @ W^T: gy2 (M, N) @ wa (N, K) on the forward GEMM kernel, which wants the weight transposed
+    (wa_t (K, N): the shadow kept for that purpose, or a transpose made here)."""
+    return hip.linear_cl(gy2, wa.t().contiguous() if wa_t is None else wa_t)
 
 
 class _ConvIm2colCL(torch.autograd.Function):
@@ -229,6 +230,42 @@ def _dwms_train_cl(h, c3: nn.Conv2d, c5: nn.Conv2d, c7: nn.Conv2d):
     return _DwConvCL.apply(h.contiguous(), wf.reshape(c, 49).t(), bt)
 
 
+class _MaskPool:
+    """Stochastic-depth masks of a whole training step from ONE bernoulli draw: every DropPath instance owns a row of a
+    (slots, batch) table that is redrawn when an instance comes back for its second mask (= the next step).  ~50 blocks x
+    (bernoulli_ + div_) launches per step become three."""
+
+    def __init__(self):
+        self.slots, self.keep, self.used, self.buf, self.probs = {}, [], set(), None, None
+
+    def take(self, mod, keep, batch, dtype, device):
+        import weakref
+        ent = self.slots.get(id(mod))
+        if ent is None or ent[1]() is not mod or self.keep[ent[0]] != keep:
+            if len(self.keep) > 8192:                     # ids of modules long gone: start over
+                self.slots, self.keep = {}, []
+            ent = self.slots[id(mod)] = (len(self.keep), weakref.ref(mod))
+            self.keep.append(keep)
+            self.buf = None
+        i = ent[0]
+        if (self.buf is None or i in self.used or self.buf.shape[1] != batch or self.buf.dtype != dtype
+                or self.buf.device != device):
+            n = len(self.keep)
+            if self.probs is None or self.probs.shape != (n, 1) or self.probs.device != device:
+                self.probs = torch.tensor(self.keep, dtype=torch.float32).view(n, 1).to(device)
+            self.buf = (torch.bernoulli(self.probs.expand(n, batch)) / self.probs).to(dtype)
+            self.used = set()
+        self.used.add(i)
+        return self.buf[i]
+
+    def forget_draw(self):
+        """the next take() draws a fresh table whatever the bookkeeping says (around a hipGraph capture)"""
+        self.buf = None
+
+
+_mask_pool = _MaskPool()
+
+
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm.models.layers.DropPath semantics)."""
 
@@ -239,7 +276,10 @@ class DropPath(nn.Module):
     def mask_for(self, x):
         """per-sample keep mask scaled by 1 / keep, broadcastable to x"""
         keep = 1.0 - self.drop_prob
-        return x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep).div_(keep)
+        shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+        if x.is_cuda:
+            return _mask_pool.take(self, keep, x.shape[0], x.dtype, x.device).view(shape)
+        return x.new_empty(shape).bernoulli_(keep).div_(keep)
 
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
@@ -251,31 +291,50 @@ class DropPath(nn.Module):
 
 
 # ----------------------------------------------------------------------------- basic layers
-# Low-precision shadows of the fp32 master weights for the training forward: 250 per-layer `weight.to(bf16)` kernels per
-# step become one multi-tensor copy after the optimizer step (train.train_step -> refresh_lowp_shadows).  A shadow is used
-# only while the parameter's version counter still equals the one it was cast at; otherwise the layer casts as before.
-_lowp_shadow = {}
+# Low-precision shadows of the fp32 master weights for the training step: the 16-bit W (N,K) the forward GEMM reads and the
+# 16-bit W^T (K,N) the input-gradient GEMM reads (dx = gy @ W runs on the forward kernel with the transposed weight).
+# ~230 per-layer `weight.to(bf16)` and as many `w.t().contiguous()` launches per step become ONE launch after the
+# optimizer step (train.train_step -> refresh_lowp_shadows -> tramba_shadow_cast_multi, driven by a device-resident table
+# of the model's weights).  A shadow is used only while the parameter's version counter still equals the one it was cast
+# at; otherwise the layer casts / transposes as before.
+_lowp_shadow = {}        # id(p) -> [shadow, version, weakref(p), shadow_t or None]
+
+
+def _shadow_params(model):
+    return [p for m in model.modules() if isinstance(m, Linear2d) for p in (m.weight,)
+            if p is not None and p.is_cuda and p.dtype == torch.float32 and p.dim() == 2]
 
 
 @torch.no_grad()
 def refresh_lowp_shadows(model, dtype):
     if dtype is None or dtype == torch.float32:
         return 0
-    params = [p for m in model.modules() if isinstance(m, Linear2d) for p in (m.weight, m.bias)
-              if p is not None and p.is_cuda and p.dtype == torch.float32]
+    import weakref
+    plan = model.__dict__.get("_tramba_shadow_plan")     # (signature, table, ntensors, total_tiles, dtype, params)
+    params = plan[5] if plan is not None else _shadow_params(model)
     if not params:
         return 0
-    for key in [k for k, ent in _lowp_shadow.items() if ent[2]() is None]:   # parameters of models that no longer exist
-        del _lowp_shadow[key]
-    dst = []
-    for p in params:
-        ent = _lowp_shadow.get(id(p))
-        if ent is None or ent[0].dtype != dtype or ent[0].shape != p.shape or ent[0].device != p.device or ent[2]() is not p:
-            import weakref
-            ent = [torch.empty_like(p, dtype=dtype), -1, weakref.ref(p)]
-            _lowp_shadow[id(p)] = ent
-        dst.append(ent[0])
-    torch._foreach_copy_(dst, params)
+    sig = (dtype,) + tuple((p.data_ptr(), tuple(p.shape)) for p in params)
+    if plan is None or plan[0] != sig:
+        params = _shadow_params(model)
+        sig = (dtype,) + tuple((p.data_ptr(), tuple(p.shape)) for p in params)
+        for key in [k for k, ent in _lowp_shadow.items() if ent[2]() is None]:   # parameters of models that no longer exist
+            del _lowp_shadow[key]
+        rows, first = [], 0
+        for p in params:
+            ent = _lowp_shadow.get(id(p))
+            if (ent is None or ent[0].dtype != dtype or ent[0].shape != p.shape or ent[0].device != p.device
+                    or ent[2]() is not p or ent[3] is None):
+                ent = [torch.empty_like(p, dtype=dtype), -1, weakref.ref(p),
+                       torch.empty((p.shape[1], p.shape[0]), dtype=dtype, device=p.device)]
+                _lowp_shadow[id(p)] = ent
+            n, k = p.shape
+            rows.append([p.data_ptr(), ent[0].data_ptr(), ent[3].data_ptr(), n, k, first])
+            first += ((n + 63) // 64) * ((k + 63) // 64)
+        table = torch.tensor(rows, dtype=torch.int64).to(params[0].device)
+        plan = (sig, table, len(rows), first, dtype, params)
+        model.__dict__["_tramba_shadow_plan"] = plan
+    hip.shadow_cast_multi(plan[1], plan[2], plan[3], dtype)
     for p in params:
         _lowp_shadow[id(p)][1] = p._version
     return len(params)
@@ -286,10 +345,9 @@ def restamp_lowp_shadows(model):
     version bump of the parameters: tramba_amd.graph.GraphedTrainStep)."""
     for m in model.modules():
         if isinstance(m, Linear2d):
-            for p in (m.weight, m.bias):
-                ent = None if p is None else _lowp_shadow.get(id(p))
-                if ent is not None and ent[2]() is p:
-                    ent[1] = p._version
+            ent = _lowp_shadow.get(id(m.weight))
+            if ent is not None and ent[2]() is m.weight:
+                ent[1] = m.weight._version
 
 
 def _lowp(p, dtype):
@@ -300,6 +358,14 @@ def _lowp(p, dtype):
     if ent is not None and ent[1] == p._version and ent[0].dtype == dtype and ent[2]() is p:
         return ent[0]
     return p.to(dtype)
+
+
+def _lowp_t(p, dtype):
+    """p^T cast to dtype when a current shadow holds it, else None (the caller transposes)"""
+    ent = _lowp_shadow.get(id(p))
+    if ent is not None and ent[1] == p._version and ent[0].dtype == dtype and ent[2]() is p:
+        return ent[3]
+    return None
 
 
 class _LinearTrainCL(torch.autograd.Function):
@@ -313,6 +379,8 @@ class _LinearTrainCL(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         ctx.save_for_backward(x2, wa)
+        # the transposed shadow is rewritten only by the refresh that follows this step's optimizer update
+        ctx.wa_t = _lowp_t(w, x.dtype)
         ctx.wdtype, ctx.has_bias, ctx.xshape = w.dtype, b is not None, x.shape
         y = hip.linear_cl(x2, wa, None if b is None else b.detach().float().contiguous())
         return y.view(x.shape[:-1] + (wa.shape[0],))
@@ -324,11 +392,44 @@ class _LinearTrainCL(torch.autograd.Function):
         gy2 = gy.reshape(-1, gy.shape[-1])
         gy2 = gy2 if gy2.is_contiguous() and gy2.dtype == x2.dtype else gy2.to(x2.dtype).contiguous()
         if ctx.needs_input_grad[0]:
-            gx = _dgrad(gy2, wa).view(ctx.xshape)
+            gx = _dgrad(gy2, wa, ctx.wa_t).view(ctx.xshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = _wgrad(gy2, x2, ctx.has_bias)
             gw = gw.to(ctx.wdtype)
         return gx, gw, gb
+
+
+class _GeluLinearTrainCL(torch.autograd.Function):
+    """y = gelu(h) @ w^T + b (training path): the activation belongs to the Linear that consumes it, so that its gradient
+    rides in the epilogue of that Linear's input-gradient GEMM -- gh = (gy @ W) * gelu'(h) is ONE launch
+    (TRAMBA_ACT_GELU_GRAD_MUL) instead of a GEMM and an elementwise kernel over the widest maps of the model (the 4x-wide
+    Mlp hidden layer, the SS2D inner width)."""
+
+    @staticmethod
+    def forward(ctx, h, w, b):
+        wa = _lowp(w, h.dtype).detach().contiguous()
+        h2 = h.reshape(-1, h.shape[-1])
+        h2 = h2 if h2.is_contiguous() else h2.contiguous()
+        a2 = F.gelu(h2)
+        ctx.save_for_backward(h2, a2, wa)
+        ctx.wa_t = _lowp_t(w, h.dtype)
+        ctx.wdtype, ctx.has_bias, ctx.hshape = w.dtype, b is not None, h.shape
+        y = hip.linear_cl(a2, wa, None if b is None else b.detach().float().contiguous())
+        return y.view(h.shape[:-1] + (wa.shape[0],))
+
+    @staticmethod
+    def backward(ctx, gy):
+        h2, a2, wa = ctx.saved_tensors
+        gh = gw = gb = None
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        gy2 = gy2 if gy2.is_contiguous() and gy2.dtype == h2.dtype else gy2.to(h2.dtype).contiguous()
+        if ctx.needs_input_grad[0]:
+            wt = wa.t().contiguous() if ctx.wa_t is None else ctx.wa_t
+            gh = hip.linear_cl(gy2, wt, None, h2, hip.ACT_GELU_GRAD_MUL).view(ctx.hshape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = _wgrad(gy2, a2, ctx.has_bias)
+            gw = gw.to(ctx.wdtype)
+        return gh, gw, gb
 
 
 class _RowDotCL(torch.autograd.Function):
@@ -362,11 +463,14 @@ class _RowDotCL(torch.autograd.Function):
 class Linear2d(nn.Linear):
     """1x1 convolution stored as an (out,in) matrix (modules.py:10-19)."""
 
-    def _forward_cl(self, x, act=hip.ACT_NONE, residual=None, out_dtype=None):
+    def _forward_cl(self, x, act=hip.ACT_NONE, residual=None, out_dtype=None, gelu_in=False):
+        """gelu_in: x is a pre-activation whose GELU this layer applies first (training path: the producer leaves the
+        activation to its consumer, see _GeluLinearTrainCL)"""
         if _infer(x, self.weight):
             w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
-            return hip.linear_cl(x, w.detach(), _f32(self.bias), residual, act, out_dtype)
-        y = _act_torch(_LinearTrainCL.apply(x, self.weight, self.bias), act)
+            return hip.linear_cl(F.gelu(x) if gelu_in else x, w.detach(), _f32(self.bias), residual, act, out_dtype)
+        fn = _GeluLinearTrainCL if gelu_in else _LinearTrainCL
+        y = _act_torch(fn.apply(x, self.weight, self.bias), act)
         if residual is not None:
             y = y + residual
         return y if out_dtype is None else y.to(out_dtype)
@@ -479,12 +583,15 @@ class Mlp(nn.Module):
 
     def _forward_cl(self, x, residual=None, pre_norm=None):
         """pre_norm: the LayerNorm2d the caller would apply to x first (folded into fc1 where possible)"""
+        # training: the GELU is applied by fc2 (its gradient rides in fc2's input-gradient GEMM)
+        defer = (not _infer(x, self.fc1.weight, self.fc2.weight)) and isinstance(self.act, nn.GELU) and self.drop.p == 0.0
+        act = hip.ACT_NONE if defer else hip.ACT_GELU
         if pre_norm is not None:
-            h = self.fc1._forward_norm_cl(x, pre_norm, act=hip.ACT_GELU)
+            h = self.fc1._forward_norm_cl(x, pre_norm, act=act)
         else:
-            h = self.fc1._forward_cl(x, act=hip.ACT_GELU)
+            h = self.fc1._forward_cl(x, act=act)
         h = self.drop(h)
-        return self.drop(self.fc2._forward_cl(h, residual=residual))
+        return self.drop(self.fc2._forward_cl(h, residual=residual, gelu_in=defer))
 
     def forward(self, x):
         _need_device(x)
@@ -891,7 +998,7 @@ class SS2D(nn.Module):
 
     def _core_train_cl(self, x):
         """Training path of forward_corev2 without leaving channels-last: x_proj once in spatial order (autograd
-        GEMM), then _SS2DCoreCL, out_norm (HIP LayerNorm autograd) and GELU."""
+        GEMM), then _SS2DCoreCL and out_norm (HIP LayerNorm autograd); returns the PRE-activation of vmamba.py:270's GELU."""
         b, h, w, d = x.shape
         order = hip.scan_order(self.scan._tramba_family, h, w, x.device)
         xf = x.reshape(b, h * w, d)
@@ -899,7 +1006,8 @@ class SS2D(nn.Module):
         a_neg = -torch.exp(self.A_logs.float()).reshape(-1)
         ym = _SS2DCoreCL.apply(xf, xdbl, self.dt_projs_weight.float(), self.dt_projs_bias.float().reshape(-1), a_neg,
                                self.Ds.float(), order)
-        y = self.out_norm._forward_cl(ym.view(b, h, w, d), act=hip.ACT_GELU)
+        # out_norm only: the GELU (vmamba.py:270) is applied by out_proj, whose input-gradient GEMM carries its gradient
+        y = self.out_norm._forward_cl(ym.view(b, h, w, d))
         return y.to(x.dtype)
 
     def _core_plugin_cl(self, x):
@@ -934,13 +1042,15 @@ class SS2D(nn.Module):
                 x = F.silu(_dwconv_train_cl(x, self.conv2d))
         else:
             x = F.silu(x)
+        gelu_in = False
         if self._fused_ok(x):
             y = self._core_fused_cl(x)
         elif self._train_fused_ok(x):
             y = self._core_train_cl(x)
+            gelu_in = True
         else:
             y = self._core_plugin_cl(x)
-        return self.dropout(self.out_proj._forward_cl(y, residual=residual))
+        return self.dropout(self.out_proj._forward_cl(y, residual=residual, gelu_in=gelu_in))
 
     def forward(self, x):
         _need_device(x)
@@ -1029,10 +1139,13 @@ class DWMSMlp(nn.Module):
                 "dwms", (c3.weight, c3.bias, c5.weight, c5.bias, c7.weight, c7.bias),
                 lambda: hip.dw_pack(c7.weight, c7.bias, c3.weight, c3.bias, c5.weight, c5.bias))
             g = hip.dwconv_cl(h, wt, bt, hip.ACT_GELU)
+            defer = False
         else:
-            g = F.gelu(_dwms_train_cl(h, c3, c5, c7))
+            defer = self.drop.p == 0.0     # the GELU is applied by fc2 (gradient in fc2's input-gradient GEMM)
+            g = _dwms_train_cl(h, c3, c5, c7)
+            g = g if defer else F.gelu(g)
         g = self.drop(g)
-        return self.drop(self.fc2._forward_cl(g, residual=residual))
+        return self.drop(self.fc2._forward_cl(g, residual=residual, gelu_in=defer))
 
     def forward(self, x):
         _need_device(x)

@@ -42,6 +42,9 @@ class GradBucketReducer:
         self._sig = None
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._native_avg = backend == "nccl"          # RCCL: ncclAvg; gloo has SUM only
+        # no process group at all and full-precision buckets: nothing to exchange, nothing to round -- the gradients stay
+        # where autograd put them (no bucket fill: 446 MB read + written per step on Tramba-V)
+        self._passthrough = (not dist.is_initialized()) and bucket_dtype is None
         self._build()
 
     # ------------------------------------------------------------------ bucket layout
@@ -120,6 +123,9 @@ class GradBucketReducer:
         all-reduce.  The .grad fields are pointed at the result in finish()."""
         bucket, views = self.buckets[bi], self._views[bi]
         have = [p.grad is not None for p in bucket]
+        if self._passthrough:
+            self._have_local[bi] = have
+            return
         dst = [v for v, p, h in zip(views, bucket, have) if h and p.grad is not v]
         src = [p.grad for v, p, h in zip(views, bucket, have) if h and p.grad is not v]
         unused = [v for v, h in zip(views, have) if not h]
@@ -158,6 +164,10 @@ class GradBucketReducer:
         for h in self._handles:
             h.wait()
         self._handles = []
+        if self._passthrough:
+            self._have_local = {}
+            self._armed = False
+            return
         for bi, bucket in enumerate(self.buckets):
             have = self._have_local.get(bi, [True] * len(bucket))
             if self.world > 1:
