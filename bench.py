@@ -30,7 +30,8 @@ Rank 0 prints ONE JSON line.  Objects on that line besides the contract's fields
   cpu_baseline  the CPU oracle (a port of the reference forward, oracle/) timed on this host (N = 1 only)
   train         BASELINE configs[2]/[3]: fwd + bwd + two-group Adam at batch 8 per GPU, gradients averaged over RCCL
                 when N > 1 (bucketed, overlapped with backward), eager launches and -- when the capture succeeds on every
-                rank -- the same step replayed as one hipGraph; `train.roofline` = the forward + input-gradient GEMMs of
+                rank -- the same step replayed as one hipGraph (`train.value` = the faster of the two, both reported as
+                `train.eager` / `train.graphed`); `train.roofline` = the forward + input-gradient GEMMs of
                 the step against the dense MFMA peak.  The leg runs under a watchdog (--train-timeout): if a collective
                 never completes, rank 0 still prints the line, with train = {"error": ...}
 """
@@ -403,17 +404,22 @@ def bench_train(args, world, rank, dtype, sync_all):
         graphed = {"skipped": "N > 1: pass --graph-dp to capture the data-parallel step (collectives included)"}
     else:
         graphed = graphed_train_leg(model, red, x, y, world, b, steps, timed)
-    return {"metric": "images/sec fwd+bwd+Adam Tramba-V 384x384", "value": round(world * b * steps / dt, 2),
-            "unit": "img/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2), "batch_per_gpu": b,
-            "global_batch": b * world, "launch": "eager",
+    eager = {"value": round(world * b * steps / dt, 2), "unit": "img/s", "ms_per_step": round(dt / steps * 1e3, 2)}
+    # `value` = the faster of the product's two ways to run the step (train.train_step launch by launch, whose rate follows the
+    # host CPU of the box: ~3400 launches per step; tramba_amd.GraphedTrainStep = fit(graph=True)); both are reported
+    best, launch = eager, "eager"
+    if isinstance(graphed, dict) and graphed.get("value", 0.0) > eager["value"]:
+        best, launch = graphed, "hipGraph replay (tramba_amd.GraphedTrainStep)"
+    return {"metric": "images/sec fwd+bwd+Adam Tramba-V 384x384", "value": best["value"],
+            "unit": "img/s", "steps": steps, "ms_per_step": best["ms_per_step"], "batch_per_gpu": b,
+            "global_batch": b * world, "launch": launch,
             "grad_bytes_per_step": red.bytes_per_step() if world > 1 else 0,
             "grad_bucket_bytes": red.bytes_per_step(), "grad_buckets": len(red.buckets),
             "grad_bucket_dtype": args.bucket_dtype, "allreduce": comm,
             "parallelism": f"dp{world}" + ((", RCCL all-reduce (ncclAvg)" if args.backend == "nccl" else ", gloo all-reduce")
                                             + " of gradient buckets from autograd hooks" if world > 1 else ", no collective"),
             "stochastic_depth": "on (0.6 enc / 0.2 dec)", "dtype": args.dtype + " activations, fp32 master weights",
-            "roofline": roof, "graphed": graphed}
-
+            "roofline": roof, "eager": eager, "graphed": graphed}
 
 def main():
     args = parse()

@@ -170,10 +170,10 @@ int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr, const int3
 /* y = act(LayerNorm_C(x));  x, y: (rows, C).  w, b f32. */
 int tramba_layernorm_cl(const void *x, const float *w, const float *b, void *y, int64_t rows, int c,
                         float eps, int act, int dtype, void *stream);
-/* Training: LayerNorm backward over the last dim of (rows, C): dx in dtype; part (P, 2, C) f32 receives one partial
- * (dgamma, dbeta) row per wave, P = tramba_layernorm_bwd_parts(rows): the caller sums over P (fixed order ->
- * reproducible).  mean / rstd are recomputed from x. */
-int64_t tramba_layernorm_bwd_parts(int64_t rows);
+/* Training: LayerNorm backward over the last dim of (rows, C): dx in dtype; part (P, 2, C) f32 receives P partial
+ * (dgamma, dbeta) rows (one per wave, or per workgroup for short rows), P = tramba_layernorm_bwd_parts(rows, c, dtype): the
+ * caller sums over P (tramba_slab_sum: fixed order -> reproducible).  mean / rstd are recomputed from x. */
+int64_t tramba_layernorm_bwd_parts(int64_t rows, int c, int dtype);
 int tramba_layernorm_bwd_cl(const void *x, const void *dy, const float *w, void *dx, float *part, int64_t rows,
                             int c, float eps, int dtype, void *stream);
 /* x: (B, H, W, P*P*C) -> y: (B, H*P, W*P, C) with y[b,hP+p1,wP+p2,:] = LN(x[b,h,w,(p1*P+p2)*C : +C]). */

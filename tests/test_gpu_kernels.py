@@ -598,6 +598,20 @@ def test_linear_gelu_grad_epilogue(dtype, mnk):
             H.linear_cl(x, w, None, None, act)
 
 
+@pytest.mark.parametrize("shape", [(576, 2, 512), (1024, 2, 128), (192, 10, 1024), (8, 4, 3, 1024), (7, 12), (300, 36), (5, 3),
+                                   (1, 64)])
+def test_slab_sum_fixed_order(shape):
+    """tramba_slab_sum: the partial-sum tables of the backward kernels summed over their first axis -- equal to an fp64 sum
+    to fp32 rounding, bitwise reproducible, any slab count (the row lanes of a block see ragged tails)."""
+    H = hip()
+    part = torch.randn(shape, generator=torch.Generator().manual_seed(sum(shape))).to(DEV)
+    got = H.slab_sum(part)
+    assert got.shape == part.shape[1:] and got.dtype == torch.float32
+    want = part.double().sum(0)
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5 * shape[0] ** 0.5)
+    assert torch.equal(got, H.slab_sum(part))
+
+
 def test_shadow_cast_multi_matches_cast_and_transpose():
     """tramba_shadow_cast_multi: one launch writes the 16-bit copy and the 16-bit transpose of every matrix in a device
     table (ragged shapes, shapes below one tile, a skipped destination) == .to(dtype) / .t() bit for bit."""

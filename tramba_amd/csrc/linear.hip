@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void linear_tiled_kernel(const T *__restrict__
 // (B, 384, 384, 128) normalised map is ever written (2 x 151 MB at batch 4) or read back.
 // LayerNorm of the INPUT rows folded into a GEMM (LayerNorm2d -> Linear2d pairs: VSSBlock norm -> in_proj, norm2 -> fc1,
 // vmamba.py:384-396): y = act(LN(x) W^T + b) = act(rstd * (x W'^T - mean * colsum) + t), W' = W * gamma (folded once per
-// weight version), colsum_n = sum_k W'_nk, t = W beta + b.  The block computes mean / rstd of its own 64 rows while its
-// first operand tiles are in flight; the normalised map is never written or re-read, and the LayerNorm launch disappears.
+// weight version), colsum_n = sum_k W'_nk, t = W beta + b.  The block derives mean / rstd of its own 64 rows from the A tiles it stages anyway (sums taken from
+// the staging registers, see lstore); the normalised map is never written or re-read, and the LayerNorm launch disappears.
 struct LnIn {
     const float *colsum;
     float eps;
@@ -520,6 +520,30 @@ __device__ __forceinline__ void tile_epilogue_ln_head(acc16_t (&acc)[BM / 64][2]
 //     XOR of bits 5-6 (chunk swizzle), and the buffer half is a compile-time immediate;
 //   * exactly nk steps run (ring trips + a statically indexed tail), so no zero-padded dummy steps.
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+
+// acc + lo + hi and acc + lo^2 + hi^2 of one packed pair of 16-bit elements
+template <typename T> __device__ __forceinline__ float dot2_ones(unsigned v, float acc);
+template <typename T> __device__ __forceinline__ float dot2_self(unsigned v, float acc);
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 hf2_t __attribute__((ext_vector_type(2)));
+template <> __device__ __forceinline__ float dot2_ones<__hip_bfloat16>(unsigned v, float acc)
+{
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, v), __builtin_bit_cast(bf2_t, 0x3f803f80u), acc, false);
+}
+template <> __device__ __forceinline__ float dot2_self<__hip_bfloat16>(unsigned v, float acc)
+{
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, v), __builtin_bit_cast(bf2_t, v), acc, false);
+}
+template <> __device__ __forceinline__ float dot2_ones<__half>(unsigned v, float acc)
+{
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(hf2_t, v), __builtin_bit_cast(hf2_t, 0x3c003c00u), acc, false);
+}
+template <> __device__ __forceinline__ float dot2_self<__half>(unsigned v, float acc)
+{
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(hf2_t, v), __builtin_bit_cast(hf2_t, v), acc, false);
+}
+template <> __device__ __forceinline__ float dot2_ones<float>(unsigned, float acc) { return acc; }
+template <> __device__ __forceinline__ float dot2_self<float>(unsigned, float acc) { return acc; }
 
 template <typename T, typename TO, int BM, int BN, int PF, bool LNHEAD = false, int NWM = 2, bool LNIN = false>
 __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ x, const T *__restrict__ w,
@@ -616,12 +640,30 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) st.b[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, bg[i], so, 0);
     };
-    auto lstore = [&](int par, const Stage &st) {
+    // LNIN: sum and sum of squares of the A rows, taken from the staging registers on their way to LDS -- thread t stages
+    // chunk t & 7 of rows (t >> 3) + 32 i at every K step, so the row statistics cost no load of their own (a prologue
+    // that re-read the block's rows moved 1.5x the operand bytes and two dependent round trips: +4..6 us per launch).
+    // v_dot2c_f32_bf16 / _f16: two elements per instruction straight from the packed dword, exact products, fp32 sums.
+    float rs1[A_PER_T], rs2[A_PER_T];
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) rs1[i] = rs2[i] = 0.f;
+    auto lstore = [&](int par, const Stage &st, bool real = true) {
         unsigned char *base = lds + par * TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) *reinterpret_cast<v4u_t *>(base + al[i]) = st.a[i];
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) *reinterpret_cast<v4u_t *>(base + bl[i]) = st.b[i];
+        if constexpr (LNIN) {
+            if (real) {   // (block-uniform) a tile past the end of K holds the next rows' elements: not part of the statistics
+#pragma unroll
+                for (int i = 0; i < A_PER_T; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        rs1[i] = dot2_ones<T>(st.a[i][e], rs1[i]);
+                        rs2[i] = dot2_self<T>(st.a[i][e], rs2[i]);
+                    }
+            }
+        }
     };
 
     Stage pipe[NS];
@@ -629,39 +671,6 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
     lstore(0, pipe[0]);
 #pragma unroll
     for (int i = 1; i < NS; ++i) gload(i, pipe[i]);
-    if constexpr (LNIN) {
-        // mean / rstd of the block's 64 input rows, while the first operand tiles are in flight: 4 threads per row, 16-byte
-        // chunks (t & 3) + 4 j, eight loads in flight per thread; one-pass sums in fp32 over K <= 2048 exact bf16 values
-        float2 *rowstat = reinterpret_cast<float2 *>(lds + LDS_BYTES);
-        const int srow = tid >> 2, sub = tid & 3;
-        const int nch = K >> 5;                          // 16-byte chunks per thread (K % 64 == 0)
-        float s1 = 0.f, s2 = 0.f;
-        for (int c0 = 0; c0 < nch; c0 += 8) {
-            v4u_t v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned off = c0 + j < nch ? (unsigned)srow * rowa + (unsigned)(sub + 4 * (c0 + j)) * 16u : kOutOfRange;
-                v[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const Pack<T, 8> pk = __builtin_bit_cast(Pack<T, 8>, v[j]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = Cvt<T>::to_f(pk.v[e]);
-                    s1 += f;
-                    s2 = fmaf(f, f, s2);
-                }
-            }
-        }
-        s1 += __shfl_xor(s1, 1, 64);
-        s2 += __shfl_xor(s2, 1, 64);
-        s1 += __shfl_xor(s1, 2, 64);
-        s2 += __shfl_xor(s2, 2, 64);
-        const float mean = s1 / (float)K;
-        const float var = fmaxf(s2 / (float)K - mean * mean, 0.f);
-        if (sub == 0) rowstat[srow] = make_float2(mean, rsqrtf(var + li.eps));
-    }
     __syncthreads();
     // one K step; `par` (LDS half holding tile kt) is a literal at every call site
     auto kstep = [&](int kt, int par, Stage &load_into, const Stage &store_from) {
@@ -680,7 +689,7 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(b[j], a[i], acc[i][j]);   // swapped: see acc_to_lds
         }
-        lstore(par ^ 1, store_from);
+        lstore(par ^ 1, store_from, kt + 1 < nk);
         __syncthreads();
     };
     constexpr int UNR = 4 * NS;   // hipcc drains vmcnt at the top of every loop trip: long trips
@@ -702,6 +711,19 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
         static_assert(BN == 128, "one tile = whole 128-channel groups");
         tile_epilogue_ln_head<T, BM>(acc, lds, hd, M, m0, n0);
     } else if constexpr (LNIN) {
+        float2 *rowstat = reinterpret_cast<float2 *>(lds + LDS_BYTES);   // read by the epilogue behind its own barrier
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            float s1 = rs1[i], s2 = rs2[i];
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {      // the 8 lanes that stage one row
+                s1 += __shfl_xor(s1, m, 64);
+                s2 += __shfl_xor(s2, m, 64);
+            }
+            const float mean = s1 / (float)K;
+            const float var = fmaxf(s2 / (float)K - mean * mean, 0.f);
+            if ((tid & 7) == 0) rowstat[(tid >> 3) + 32 * i] = make_float2(mean, rsqrtf(var + li.eps));
+        }
         tile_epilogue<T, TO, BM, BN, NWM>(acc, lds, bias, res, y, M, N, act, m0, n0, li.colsum,
                                           reinterpret_cast<const float2 *>(lds + LDS_BYTES));
     } else {

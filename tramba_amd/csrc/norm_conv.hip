@@ -317,10 +317,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const T *__rest
                                                                 int rpw)
 {
     constexpr int RPW = kWave / LPR;
+    __shared__ float red[4][2 * LPR * V];     // the four waves' (dgamma, dbeta) rows, folded before they leave the block
     const int lane = threadIdx.x & (kWave - 1);
-    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long r0 = wave * rpw;
-    if (r0 >= rows) return;   // wave-uniform, no barriers
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wv;
+    const long r0 = wave * rpw;               // a wave past the end runs no row and contributes zeros
     const long rend = r0 + rpw < rows ? r0 + rpw : rows;
     const int sub = lane % LPR, slot = lane / LPR;
     const int c0 = sub * V;
@@ -391,13 +392,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const T *__rest
             gw[v] += __shfl_xor(gw[v], o, kWave);
             gb[v] += __shfl_xor(gb[v], o, kWave);
         }
-    if (slot == 0 && cok) {
-        float *pw = part + wave * 2 * C;
+    if (slot == 0) {
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            pw[c0 + v] = gw[v];
-            pw[C + c0 + v] = gb[v];
+            red[wv][c0 + v] = gw[v];
+            red[wv][LPR * V + c0 + v] = gb[v];
         }
+    }
+    __syncthreads();
+    // ONE partial row per block (a quarter of the rows the caller has to sum), waves added in a fixed order
+    float *pw = part + (long)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int j = i < C ? i : LPR * V + (i - C);
+        pw[i] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
     }
 }
 
@@ -833,11 +840,19 @@ static long ln_bwd_rows_per_wave(long rows)
     return rpw < 8 ? 8 : (rpw > 128 ? 128 : rpw);
 }
 
-extern "C" int64_t tramba_layernorm_bwd_parts(int64_t rows)
+// rows of at most 64 lanes x 16 bytes: several rows per wave (layernorm_bwd_rows_kernel), one partial row per BLOCK
+static bool ln_bwd_rows_form(int c, int dtype)
 {
-    if (rows <= 0) return 0;
+    const int vm = dtype == TRAMBA_F32 ? 4 : 8;
+    return c % vm == 0 && c <= kWave * vm;
+}
+
+extern "C" int64_t tramba_layernorm_bwd_parts(int64_t rows, int c, int dtype)
+{
+    if (rows <= 0 || c <= 0) return 0;
     const long rpw = ln_bwd_rows_per_wave(rows);
-    return (rows + rpw - 1) / rpw;
+    const long waves = (rows + rpw - 1) / rpw;
+    return ln_bwd_rows_form(c, dtype) ? (waves + 3) / 4 : waves;
 }
 
 extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const float *w, void *dx, float *part,
@@ -853,9 +868,8 @@ extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const floa
     const long waves = (rows + rpw - 1) / rpw;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     // short rows: several rows per wave, 16-byte accesses; longer rows: one row per wave
-    const bool rows_form = true;
     const int vm = dtype == TRAMBA_F32 ? 4 : 8;
-    if (rows_form && c % vm == 0 && c <= kWave * vm) {
+    if (ln_bwd_rows_form(c, dtype)) {
         int lpr = 1;
         while (lpr < c / vm) lpr <<= 1;
 #define GOB_(T, V_, L_)                                                                                             \

@@ -57,7 +57,7 @@ ProfScope::~ProfScope()
 using namespace tramba;
 
 extern "C" const char *tramba_last_error(void) { return g_err; }
-extern "C" int tramba_abi_version(void) { return 2; }   // 2: round 2 (training GEMMs, tuning hook, gym dtype)
+extern "C" int tramba_abi_version(void) { return 3; }   // 3: layernorm_bwd_parts(rows, c, dtype), shadow / slab-sum entries
 
 static int g_tune[TRAMBA_TUNE_COUNT] = {0};
 extern "C" int tramba_tune_set(int knob, int value)

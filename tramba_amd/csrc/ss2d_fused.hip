@@ -252,11 +252,16 @@ struct ScanWave {
 
     // dt_proj on the matrix core + per-element decay / input terms.  nvalid = positions of this tile
     // inside the sequence (>= 32: all of them)
+    // UF_READY: uf already holds the 16 inputs as floats (the LDS-DMA kernel reads bf16 straight into the upper half of
+    // a zeroed register), cur.u is not looked at
+    template <bool UF_READY = false>
     __device__ __forceinline__ void terms(const TileOps<T, NK> &cur, const float (&Bp)[16], int nvalid, float (&a)[16],
                                           float (&bb)[16], float (&uf)[16], float *tl = nullptr) const
     {
+        if constexpr (!UF_READY) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) uf[r] = raw_to_f<T>(cur.u[r]);
+            for (int r = 0; r < 16; ++r) uf[r] = raw_to_f<T>(cur.u[r]);
+        }
         acc16_t acc;
         if (nvalid < kTP) {  // wave-uniform: only the last tile of a sequence / segment
 #pragma unroll
@@ -609,10 +614,18 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
     const unsigned pa1 = prow_a + (unsigned)((16 + hi * 8 < R8 ? 16 + hi * 8 : 0) * 4);
     const unsigned pb = prow_a + (unsigned)(R8 * 4);
     const unsigned ua = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)(slot + hi * 4 * kTP * 2 + r32 * 2);
-    auto from_lds = [&](TileOps<T, NK> &o) {
+    // bf16 inputs: ds_read_u16_d16_hi drops the 16 bits into the UPPER half of its destination and leaves the lower half
+    // alone -- registers zeroed once before the loop then hold the element as an fp32 value, no widening shift per element
+    // (16 VALU instructions per tile of a kernel that is VALU-issue bound)
+    constexpr bool kHiLoad = std::is_same<T, __hip_bfloat16>::value;
+    unsigned ubits[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ubits[r] = 0u;
+    auto from_lds = [&](TileOps<T, NK> &o, float (&uf)[16]) {
         v4f v[4];
         v2f bc;
-        unsigned u[16];
+        unsigned ulocal[16];
+        unsigned (&u)[16] = *(kHiLoad ? &ubits : &ulocal);    // no copy between a read and the wait that covers it
         TRAMBA_LDS_RD_("ds_read_b128", v[0], pa0, 0);
         TRAMBA_LDS_RD_("ds_read_b128", v[1], pa0, 16);
         if constexpr (NK == 2) {
@@ -622,22 +635,17 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
             v[2] = v[3] = v4f{0.f, 0.f, 0.f, 0.f};
         }
         TRAMBA_LDS_RD_("ds_read_b64", bc, pb, 0);
-        TRAMBA_LDS_RD_("ds_read_u16", u[0], ua, 0);
-        TRAMBA_LDS_RD_("ds_read_u16", u[1], ua, 64);
-        TRAMBA_LDS_RD_("ds_read_u16", u[2], ua, 128);
-        TRAMBA_LDS_RD_("ds_read_u16", u[3], ua, 192);
-        TRAMBA_LDS_RD_("ds_read_u16", u[4], ua, 512);
-        TRAMBA_LDS_RD_("ds_read_u16", u[5], ua, 576);
-        TRAMBA_LDS_RD_("ds_read_u16", u[6], ua, 640);
-        TRAMBA_LDS_RD_("ds_read_u16", u[7], ua, 704);
-        TRAMBA_LDS_RD_("ds_read_u16", u[8], ua, 1024);
-        TRAMBA_LDS_RD_("ds_read_u16", u[9], ua, 1088);
-        TRAMBA_LDS_RD_("ds_read_u16", u[10], ua, 1152);
-        TRAMBA_LDS_RD_("ds_read_u16", u[11], ua, 1216);
-        TRAMBA_LDS_RD_("ds_read_u16", u[12], ua, 1536);
-        TRAMBA_LDS_RD_("ds_read_u16", u[13], ua, 1600);
-        TRAMBA_LDS_RD_("ds_read_u16", u[14], ua, 1664);
-        TRAMBA_LDS_RD_("ds_read_u16", u[15], ua, 1728);
+#define TRAMBA_U16_(R, OFF)                                                                         \
+    if constexpr (kHiLoad) {                                                                        \
+        asm volatile("ds_read_u16_d16_hi %0, %1 offset:" #OFF : "+v"(u[R]) : "v"(ua) : "memory");  \
+    } else {                                                                                        \
+        TRAMBA_LDS_RD_("ds_read_u16", u[R], ua, OFF);                                               \
+    }
+        TRAMBA_U16_(0, 0) TRAMBA_U16_(1, 64) TRAMBA_U16_(2, 128) TRAMBA_U16_(3, 192)
+        TRAMBA_U16_(4, 512) TRAMBA_U16_(5, 576) TRAMBA_U16_(6, 640) TRAMBA_U16_(7, 704)
+        TRAMBA_U16_(8, 1024) TRAMBA_U16_(9, 1088) TRAMBA_U16_(10, 1152) TRAMBA_U16_(11, 1216)
+        TRAMBA_U16_(12, 1536) TRAMBA_U16_(13, 1600) TRAMBA_U16_(14, 1664) TRAMBA_U16_(15, 1728)
+#undef TRAMBA_U16_
         // every destination named: no consumer may be scheduled above this wait (the reads above count as "done" to hipcc)
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(bc), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]),
@@ -654,7 +662,13 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
         o.bv = bc.x;
         o.cv = bc.y;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o.u[r] = (unsigned short)u[r];
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (kHiLoad) {
+                uf[r] = __builtin_bit_cast(float, u[r]);
+            } else {
+                uf[r] = raw_to_f<T>(u[r]);
+            }
+        }
     };
 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (lds_void *)ib, 4, idx_off(0), 0, 0, 0);
@@ -665,13 +679,14 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
     for (int s = 0; s < nsuper; ++s) {
         if (s > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         TileOps<T, NK> cur;
-        from_lds(cur);
+        float uf[16];
+        from_lds(cur, uf);
         dma(s + 2);                                             // tile s + 1 (clamped past the end: fetched, never used)
         const int l0 = s * span + wv * kTP;
         float Bp[16], Cp[16];
         w.stage_bc(cur, Bp, Cp, false);
-        float a[16], bb[16], uf[16], preA[4], preH[4], runA, runH;
-        w.terms(cur, Bp, L - l0, a, bb, uf);
+        float a[16], bb[16], preA[4], preH[4], runA, runH;
+        w.template terms<true>(cur, Bp, L - l0, a, bb, uf);
         w.prefix(a, bb, preA, preH, runA, runH);
         const int buf = s & 1;
         if (hi == 0) {

@@ -272,6 +272,47 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const T *__restrict__ x,
     }
 }
 
+// out[i] = sum_s part[s][i] for the many small partial-sum tables of the backward pass (LayerNorm / depth-wise / scan
+// parameter gradients: 10..1000 slabs of 256..12288 floats).  A block owns 32 consecutive floats (one 128-byte line per
+// slab) and spreads the slabs over 32 row lanes, eight loads in flight per thread; the row lanes are folded through LDS in a
+// fixed order.  ~200 launches per training step of Tramba-V: about half the time of a general-purpose reduction each.
+__global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ part, float *__restrict__ out, long n,
+                                                     int nslab)
+{
+    __shared__ float4 red[32][8];
+    const int q = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const long i4 = ((long)blockIdx.x * 8 + q) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < n) {
+        const float *p = part + i4;
+        int s = rl;
+        for (; s + 7 * 32 < nslab; s += 8 * 32) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(p + (long)(s + 32 * j) * n);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
+            }
+        }
+        for (; s < nslab; s += 32) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + (long)s * n);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[rl][q] = acc;
+    __syncthreads();
+    if (rl == 0 && i4 < n) {
+        float4 t = red[0][q];
+#pragma unroll
+        for (int r = 1; r < 32; ++r) {
+            const float4 v = red[r][q];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + i4) = t;
+    }
+}
+
 // ---- multi-tensor cast (+ transpose) of fp32 matrices: table[t] = {src, dst, dst_t, rows, cols, first_tile} (int64 each)
 constexpr int kShadowTile = 64;
 
@@ -447,8 +488,8 @@ extern "C" int tramba_slab_sum(const float *part, float *out, int64_t n, int nsl
 {
     TRAMBA_CHECK(part && out && n > 0 && nslab > 0, "slab_sum: empty input");
     TRAMBA_CHECK(aligned16(part) && aligned16(out) && n % 4 == 0, "slab_sum: rows of whole, 16-byte aligned float4s");
-    dim3 grid((unsigned)((n / 4 + 255) / 256), 1);
-    hipLaunchKernelGGL(slab_sum_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, out, (long)n, nslab);
+    dim3 grid((unsigned)((n / 4 + 7) / 8));
+    hipLaunchKernelGGL(col_sum_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, out, (long)n, nslab);
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }

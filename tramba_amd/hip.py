@@ -51,7 +51,7 @@ SIGNATURES = {
     "tramba_ss2d_scan_bwd_cl": (c_int, [c_vp] * 14 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
-    "tramba_layernorm_bwd_parts": (c_i64, [c_i64]),
+    "tramba_layernorm_bwd_parts": (c_i64, [c_i64, c_int, c_int]),
     "tramba_layernorm_bwd_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_f, c_int, c_vp]),
     "tramba_shuffle_norm_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_shuffle_norm_head_cl": (c_int, [c_vp] * 4 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
@@ -409,10 +409,10 @@ def layernorm_bwd_cl(x, dy, w, eps=1e-5):
     c = x.shape[-1]
     rows = x.numel() // c
     dx = torch.empty_like(x)
-    part = torch.empty((lib().tramba_layernorm_bwd_parts(rows), 2, c), dtype=torch.float32, device=x.device)
+    part = torch.empty((lib().tramba_layernorm_bwd_parts(rows, c, dt(x)), 2, c), dtype=torch.float32, device=x.device)
     _check(lib().tramba_layernorm_bwd_cl(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(part), rows, c, eps, dt(x), _stream()),
            "layernorm_bwd_cl")
-    s = part.sum(dim=0)
+    s = slab_sum(part)
     return dx, s[0], s[1]
 
 
@@ -511,7 +511,7 @@ def dwconv_wgrad_cl(x, gy, ks):
     part = torch.empty((lib().tramba_dwconv_wgrad_parts(bb, h), ks * ks + 1, c), dtype=torch.float32, device=x.device)
     _check(lib().tramba_dwconv_wgrad_cl(_ptr(x), _ptr(gy), _ptr(part), bb, h, wd, c, ks, dt(x), _stream()),
            "dwconv_wgrad_cl")
-    s = part.sum(dim=0)
+    s = slab_sum(part)
     return s[:ks * ks], s[ks * ks]
 
 
@@ -647,6 +647,19 @@ def rows_gemm_cl(x, w, y, n):
     _check(lib().tramba_rows_gemm_cl(_ptr(x), _ptr(w), _ptr(y), z, m, n, k, w.shape[0], y.shape[-1], dt(x), _stream()),
            "rows_gemm_cl")
     return y
+
+
+def slab_sum(part):
+    """part (S, ...) f32 -> sum over the first axis, slabs added in a fixed order (tramba_slab_sum); the small partial-sum
+    tables of the backward kernels."""
+    _dev(part)
+    nslab = part.shape[0]
+    n = part.numel() // max(nslab, 1)
+    if part.dtype != torch.float32 or not part.is_contiguous() or n % 4 or nslab == 0:
+        return part.sum(dim=0)
+    out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+    _check(lib().tramba_slab_sum(_ptr(part), _ptr(out), n, nslab, _stream()), "slab_sum")
+    return out
 
 
 def shadow_cast_multi(table, ntensors, total_tiles, dtype):

@@ -231,36 +231,45 @@ def _dwms_train_cl(h, c3: nn.Conv2d, c5: nn.Conv2d, c7: nn.Conv2d):
 
 
 class _MaskPool:
-    """Stochastic-depth masks of a whole training step from ONE bernoulli draw: every DropPath instance owns a row of a
-    (slots, batch) table that is redrawn when an instance comes back for its second mask (= the next step).  ~50 blocks x
-    (bernoulli_ + div_) launches per step become three."""
+    """Stochastic-depth masks of a whole training step from ONE bernoulli draw: the k-th use of a DropPath instance within
+    a step owns a row of a (slots, batch) table (a VSSBlock uses its DropPath twice per forward, vmamba.py:384-396), and
+    the table is redrawn at the first use after begin_step() -- called by the models' forward in training mode and by
+    train.train_step.  ~50 x (bernoulli_ + div_) launches per step become three.  Code that never calls begin_step()
+    still gets independent masks: uses simply keep taking new rows, and the 16th use of an instance starts a new table."""
 
     def __init__(self):
-        self.slots, self.keep, self.used, self.buf, self.probs = {}, [], set(), None, None
+        self.slots, self.keep, self.count, self.buf, self.probs, self.fresh = {}, [], {}, None, None, False
+
+    def begin_step(self):
+        self.count = {}
+        self.fresh = False
+
+    def forget_draw(self):
+        """the next take() draws a fresh table whatever the bookkeeping says (around a hipGraph capture)"""
+        self.fresh = False
 
     def take(self, mod, keep, batch, dtype, device):
         import weakref
-        ent = self.slots.get(id(mod))
+        k = self.count.get(id(mod), 0)
+        if k >= 16:
+            self.begin_step()
+            k = 0
+        self.count[id(mod)] = k + 1
+        ent = self.slots.get((id(mod), k))
         if ent is None or ent[1]() is not mod or self.keep[ent[0]] != keep:
             if len(self.keep) > 8192:                     # ids of modules long gone: start over
                 self.slots, self.keep = {}, []
-            ent = self.slots[id(mod)] = (len(self.keep), weakref.ref(mod))
+            ent = self.slots[(id(mod), k)] = (len(self.keep), weakref.ref(mod))
             self.keep.append(keep)
-            self.buf = None
-        i = ent[0]
-        if (self.buf is None or i in self.used or self.buf.shape[1] != batch or self.buf.dtype != dtype
+            self.fresh = False
+        if (not self.fresh or self.buf is None or self.buf.shape != (len(self.keep), batch) or self.buf.dtype != dtype
                 or self.buf.device != device):
             n = len(self.keep)
             if self.probs is None or self.probs.shape != (n, 1) or self.probs.device != device:
                 self.probs = torch.tensor(self.keep, dtype=torch.float32).view(n, 1).to(device)
             self.buf = (torch.bernoulli(self.probs.expand(n, batch)) / self.probs).to(dtype)
-            self.used = set()
-        self.used.add(i)
-        return self.buf[i]
-
-    def forget_draw(self):
-        """the next take() draws a fresh table whatever the bookkeeping says (around a hipGraph capture)"""
-        self.buf = None
+            self.fresh = True
+        return self.buf[ent[0]]
 
 
 _mask_pool = _MaskPool()
@@ -908,7 +917,7 @@ class _SS2DCoreCL(torch.autograd.Function):
         g_seq[..., r8 + 1] = g_c
         g_xd = torch.zeros_like(xdf)
         g_xd.index_add_(1, flat, g_seq.view(b, k * l, rg))
-        gp = gpar.sum(dim=0)                                                              # (K,3,D)
+        gp = hip.slab_sum(gpar)                                                           # (K,3,D)
         return (gx, g_xd.view(b, l, k * rg), g_dtw, gp[:, 2].reshape(-1), gp[:, 0].reshape(-1), gp[:, 1].reshape(-1),
                 None)
 
