@@ -153,13 +153,15 @@ int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32_t *table, 
  * gradient of the MERGED map (CrossMerge output, before out_norm); the kernel gathers it through `table`.  Outputs, in SEQUENCE
  * order like ys: gu (B,K,L,D) dtype = dL/d(gathered x) -- merge it with tramba_ss2d_merge_norm_cl(eps < 0) to get
  * dL/dx; graw (B,K,L,D) dtype = dL/d(x_proj ranks . dt_w) before bias and softplus; gB, gC (B,K,L) f32 ACCUMULATED
- * (zero them first); gpar (B,K,3,D) f32 = per-channel dA, dD, d(dt_bias) (sum over B for the parameters).
+ * (zero them first), element (b,k,l) at gB[((b*K + k)*L + l) * bc_stride] -- bc_stride = 1 for packed arrays, or the row
+ * stride of a (B,K,L,RG) x_dbl-gradient table whose B / C columns the two pointers address; gpar (B,3,K,D) f32 = per-channel dA, dD, d(dt_bias) planes (sum over B for the parameters).
  * workspace: tramba_ss2d_scan_bwd_workspace() bytes of device scratch. */
 size_t tramba_ss2d_scan_bwd_workspace(int batch, int l, int d, int k);
 int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
                             const float *dt_bias, const float *A, const float *Ds, const void *gym, void *gu,
-                            void *graw, float *gB, float *gC, float *gpar, void *workspace, size_t workspace_bytes,
-                            int batch, int l, int d, int k, int r, int dtype, int gym_dtype, void *stream);
+                            void *graw, float *gB, float *gC, int bc_stride, float *gpar, void *workspace,
+                            size_t workspace_bytes, int batch, int l, int d, int k, int r, int dtype, int gym_dtype,
+                            void *stream);
 /* y[b,p,:] = act(LayerNorm_D(sum_{e in inv[p]} ys[b, e/L, e%L, :]));  y: (B, L, D) dtype.
  * eps < 0: the plain sum (CrossMerge alone), ln_w / ln_b / act ignored. */
 int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr, const int32_t *inv_idx,

@@ -728,14 +728,14 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
 // gy is the gradient of the MERGED output gathered through the table (ys' gradient is never materialised).
 // Outputs: gu (B,K,L,D) = dL/d(gathered x), graw (B,K,L,D) = dL/d(dt_raw = x_proj ranks . dt_w) in sequence
 // order (the small projections around them are left to batched GEMMs), gB / gC (B,K,L) summed over channels
-// (LDS transpose + atomics over the D/32 channel tiles), gpar (B,K,3,D) = per-channel dA, dD, dbias.
+// (LDS transpose + atomics over the D/32 channel tiles), gpar (B,3,K,D) = per-channel dA, dD, dbias.
 template <typename T, int NK, bool SPLIT, typename TG>   // TG: dtype of the merged map's gradient (float or T)
 __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
     const float *__restrict__ Ds, const TG *__restrict__ gym, T *__restrict__ gu, T *__restrict__ graw,
     float *__restrict__ gB, float *__restrict__ gC, float *__restrict__ gpar, float *__restrict__ hst, int L, int D,
-    int K, int R, int W)
+    int K, int R, int W, int bcs)
 {
     constexpr int kTS = 36;   // LDS row stride (floats) of the position-sum transposes: 16-byte aligned rows
     __shared__ float agg[2][kMaxW][2][kTP];
@@ -947,8 +947,8 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
             sbc[which] = sv + __shfl_xor(sv, 32, 64);
         }
         if (hi == 0 && l0 + r32 < L) {
-            atomicAdd(gB + ((long)b * K + k) * L + l0 + r32, sbc[0]);
-            atomicAdd(gC + ((long)b * K + k) * L + l0 + r32, sbc[1]);
+            atomicAdd(gB + (((long)b * K + k) * L + l0 + r32) * bcs, sbc[0]);   // bcs: floats between positions (1, or
+            atomicAdd(gC + (((long)b * K + k) * L + l0 + r32) * bcs, sbc[1]);   // the row stride of an x_dbl-gradient table)
         }
     }
     // ---- per-channel sums: two half-waves, then the W waves
@@ -968,10 +968,11 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
             sD += red[q][1][r32];
             sb2 += red[q][2][r32];
         }
-        float *gp = gpar + ((long)b * K + k) * 3 * D + c;
+        // (B, 3, K, D): the three parameter gradients are contiguous (K, D) planes once the batch is summed
+        float *gp = gpar + ((long)b * 3 * K + k) * D + c;
         gp[0] = sA;
-        gp[D] = sD;
-        gp[2 * D] = sb2;
+        gp[(long)K * D] = sD;
+        gp[2l * K * D] = sb2;
     }
 }
 
@@ -1695,10 +1696,11 @@ extern "C" size_t tramba_ss2d_scan_bwd_workspace(int batch, int l, int d, int k)
 
 extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
                                        const float *dt_bias, const float *A, const float *Ds, const void *gym,
-                                       void *gu, void *graw, float *gB, float *gC, float *gpar, void *workspace,
-                                       size_t workspace_bytes, int batch, int l, int d, int k, int r, int dtype,
-                                       int gym_dtype, void *stream)
+                                       void *gu, void *graw, float *gB, float *gC, int bc_stride, float *gpar,
+                                       void *workspace, size_t workspace_bytes, int batch, int l, int d, int k, int r,
+                                       int dtype, int gym_dtype, void *stream)
 {
+    TRAMBA_CHECK(bc_stride >= 1, "ss2d_scan_bwd_cl: bc_stride must be >= 1");
     TRAMBA_CHECK(x && xdbl && table && dt_w && dt_bias && A && Ds && gym && gu && graw && gB && gC && gpar && workspace,
                  "ss2d_scan_bwd_cl: null tensor");
     TRAMBA_CHECK(batch > 0 && l > 0 && d > 0 && k > 0 && r > 0, "ss2d_scan_bwd_cl: empty shape");
@@ -1717,7 +1719,7 @@ extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const i
     dim3 grid(ct, k, batch), block(W * kWave);
 #define BWD_G_(T, NK_, SP_, TG)                                                                                     \
     hipLaunchKernelGGL((ss2d_scan_bwd_cl_kernel<T, NK_, SP_, TG>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, \
-                       dt_bias, A, Ds, (const TG *)gym, (T *)gu, (T *)graw, gB, gC, gpar, (float *)workspace, l, d, k, r, W)
+                       dt_bias, A, Ds, (const TG *)gym, (T *)gu, (T *)graw, gB, gC, gpar, (float *)workspace, l, d, k, r, W, bc_stride)
 #define BWD_(T, NK_, SP_)                                                          \
     if (gym_dtype == TRAMBA_F32) { BWD_G_(T, NK_, SP_, float); } else { BWD_G_(T, NK_, SP_, T); }
 #define BWD_NK_(T, SP_)                \

@@ -48,7 +48,7 @@ SIGNATURES = {
     "tramba_ss2d_scan_workspace": (ctypes.c_size_t, [c_int] * 4),
     "tramba_ss2d_scan_cl": (c_int, [c_vp] * 9 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
     "tramba_ss2d_scan_bwd_workspace": (ctypes.c_size_t, [c_int] * 4),
-    "tramba_ss2d_scan_bwd_cl": (c_int, [c_vp] * 14 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
+    "tramba_ss2d_scan_bwd_cl": (c_int, [c_vp] * 12 + [c_int, c_vp, c_vp, ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_layernorm_bwd_parts": (c_i64, [c_i64, c_int, c_int]),
@@ -362,23 +362,32 @@ def ss2d_merge_sum_cl(ys, order: ScanOrder, out_dtype):
     return y
 
 
-def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym):
+def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym, g_seq=None):
     """Backward of ss2d_scan_cl + merge.  gym (B, L, D) f32 = gradient of the merged map.
-    Returns gu, graw (B,K,L,D) x.dtype, gB, gC (B,K,L) f32, gpar (B,K,3,D) f32 (dA, dD, dbias per channel)."""
-    _dev(x, xdbl, dt_w, dt_bias, A, Ds, gym)
+    Returns gu, graw (B,K,L,D) x.dtype, gB, gC (B,K,L) f32, gpar (B,3,K,D) f32 (dA, dD, dbias planes).
+    g_seq: a ZEROED (B,K,L,RG) f32 x_dbl-gradient table in sequence order -- gB / gC are then accumulated straight into its
+    B / C columns (RG - 4, RG - 3) and returned as views of it."""
+    _dev(x, xdbl, dt_w, dt_bias, A, Ds, gym, g_seq)
     b, l, d = x.shape
     k, r = order.k, dt_w.shape[-1]
     if gym.dtype not in (torch.float32, x.dtype) or gym.shape != x.shape:
         raise TrambaHipError("ss2d_scan_bwd_cl: gym must be (B, L, D) in f32 or the activation dtype")
     gu = torch.empty((b, k, l, d), dtype=x.dtype, device=x.device)
     graw = torch.empty_like(gu)
-    gB = torch.zeros((b, k, l), dtype=torch.float32, device=x.device)
-    gC = torch.zeros_like(gB)
-    gpar = torch.empty((b, k, 3, d), dtype=torch.float32, device=x.device)
+    if g_seq is None:
+        gB = torch.zeros((b, k, l), dtype=torch.float32, device=x.device)
+        gC = torch.zeros_like(gB)
+        bcs = 1
+    else:
+        rg = ss2d_group_stride(r)
+        if g_seq.shape != (b, k, l, rg) or g_seq.dtype != torch.float32 or not g_seq.is_contiguous():
+            raise TrambaHipError(f"ss2d_scan_bwd_cl: g_seq must be a contiguous float32 (B, K, L, {rg}) tensor")
+        gB, gC, bcs = g_seq[..., rg - 4], g_seq[..., rg - 3], rg
+    gpar = torch.empty((b, 3, k, d), dtype=torch.float32, device=x.device)
     ws_bytes = lib().tramba_ss2d_scan_bwd_workspace(b, l, d, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     _check(lib().tramba_ss2d_scan_bwd_cl(_ptr(x), _ptr(xdbl), _ptr(order.table), _ptr(dt_w), _ptr(dt_bias), _ptr(A),
-                                         _ptr(Ds), _ptr(gym), _ptr(gu), _ptr(graw), _ptr(gB), _ptr(gC), _ptr(gpar),
+                                         _ptr(Ds), _ptr(gym), _ptr(gu), _ptr(graw), _ptr(gB), _ptr(gC), bcs, _ptr(gpar),
                                          _ptr(ws), ws_bytes, b, l, d, k, r, dt(x), dt(gym), _stream()), "ss2d_scan_bwd_cl")
     return gu, graw, gB, gC, gpar
 

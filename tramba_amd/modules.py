@@ -881,7 +881,9 @@ class _SS2DCoreCL(torch.autograd.Function):
         gym = gym.contiguous()
         if gym.dtype not in (torch.float32, x.dtype):
             gym = gym.float()
-        gu, graw, g_b, g_c, gpar = hip.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, gym)
+        # gradients of the x_dbl rows in sequence order: the kernel accumulates dB / dC straight into their columns
+        g_seq = torch.zeros((b, k, l, rg), dtype=torch.float32, device=x.device)
+        gu, graw, _, _, gpar = hip.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, gym, g_seq)
         gx = hip.ss2d_merge_sum_cl(gu, order, x.dtype)
         # row (l, k) of xdbl viewed as (B, L*K, RG) that sequence position (k, i) reads: table[k][i] * K + k.  One gather
         # and one index_add_ over all K directions instead of 4 launches per direction (660 small kernels per step)
@@ -891,35 +893,32 @@ class _SS2DCoreCL(torch.autograd.Function):
             order._flat_rows = flat
         xdf = xdbl.view(b, l * k, rg)
         ranks = xdf[:, flat, :r].view(b, k, l, r)                                          # (B,K,L,R) f32
-        g_seq = torch.zeros((b, k, l, rg), dtype=torch.float32, device=x.device)           # gradients in sequence order
         # the two per-direction projections on the library's grouped kernels, straight on the (B,K,L,.) tensors:
         #   d(dt_projs_weight)[k] = sum_{b,l} graw^T ranks   (TN, tramba_wgrad_cl with groups = K, batches = B)
         #   d(ranks)              = graw @ dt_w[k]           (tramba_rows_gemm_cl into the first R floats of every row)
-        dtw_t = dt_w.transpose(1, 2).contiguous()                                          # (K, R, D)
         if r % 8:                                   # the TN kernel moves 16-byte rows: pad the rank columns
             ranks = F.pad(ranks, (0, 8 - r % 8))
         if graw.dtype != torch.float32:
             cd = graw.dtype
             g_dtw = hip.wgrad_grouped_cl(graw, ranks.to(cd))                                # (K,D,R)
-            hip.rows_gemm_cl(graw.view(b * k, l, d), dtw_t.to(cd), g_seq.view(b * k, l, rg), r)
+            dtw_t = torch.empty((k, r, d), dtype=cd, device=x.device).copy_(dt_w.transpose(1, 2))   # transpose + cast: 1 launch
+            hip.rows_gemm_cl(graw.view(b * k, l, d), dtw_t, g_seq.view(b * k, l, rg), r)
         else:   # fp32 validation mode: three passes on bf16 splits
             gh, gl = _split16(graw)
             rh, rl = _split16(ranks)
-            wh, wl = _split16(dtw_t)
+            wh, wl = _split16(dt_w.transpose(1, 2).contiguous())                            # (K, R, D)
             g_dtw = hip.wgrad_grouped_cl(gh, rh) + hip.wgrad_grouped_cl(gh, rl) + hip.wgrad_grouped_cl(gl, rh)
             tmp = torch.empty_like(g_seq)
             hip.rows_gemm_cl(gh.view(b * k, l, d), wh, g_seq.view(b * k, l, rg), r)
             for ga_, wa_ in ((gh, wl), (gl, wh)):
                 hip.rows_gemm_cl(ga_.view(b * k, l, d), wa_, tmp.view(b * k, l, rg), r)
                 g_seq[..., :r] += tmp[..., :r]
-        g_dtw = g_dtw[..., :r]
-        g_seq[..., r8] = g_b
-        g_seq[..., r8 + 1] = g_c
+        if g_dtw.shape[-1] != r:
+            g_dtw = g_dtw[..., :r].contiguous()     # (a view would be cloned by autograd's gradient accumulation anyway)
         g_xd = torch.zeros_like(xdf)
         g_xd.index_add_(1, flat, g_seq.view(b, k * l, rg))
-        gp = hip.slab_sum(gpar)                                                           # (K,3,D)
-        return (gx, g_xd.view(b, l, k * rg), g_dtw, gp[:, 2].reshape(-1), gp[:, 0].reshape(-1), gp[:, 1].reshape(-1),
-                None)
+        gp = hip.slab_sum(gpar)                                                           # (3,K,D): contiguous planes
+        return (gx, g_xd.view(b, l, k * rg), g_dtw, gp[2].reshape(-1), gp[0].reshape(-1), gp[1].reshape(-1), None)
 
 
 class SS2D(nn.Module):
