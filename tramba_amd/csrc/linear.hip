@@ -754,26 +754,39 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
     // lean kernel: whole 64-deep K steps, and a 64-row operand panel within 32-bit byte offsets
     const bool lean_ok = k % 64 == 0 && (double)k * 2.0 * 128.0 < 2147483648.0;
     const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
-    if (!x2 && big >= 2048 && k >= 1024) {
+    // Lean-kernel tile: 64x64 with a 2-stage ring (82 VGPRs, 5-6 resident blocks per CU) on every shape of the model.
+    // Measured back to back in one process at batch 4 and 8 (scripts/bench_gemm_tiles.py) and in-model (scripts/ab_tune.py:
+    // 5.30 -> 5.24 ms per forward): 128x128 tiles (1-2 resident blocks: the load -> LDS -> MFMA chain of a K step lies
+    // open) run 1.3-2x SLOWER, 128x64 0-40 % slower, and the two special cases kept until r02 -- 96x64 tiles where 64x64
+    // lands just above a round of the chip, a 4-stage ring for long K on one block per CU -- lose 0.5-1.5 us each.  The other
+    // forms stay reachable through TRAMBA_TUNE_GEMM_TILE for such measurements.
+    const int tile_tune = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE);
+    if (!CONV && lean_ok && tile_tune == 2) {
         dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
-        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2, CONV>), grid, block, 0, s, (const T *)x,
-                           (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);
-    } else if (!CONV && lean_ok && tile96(m, n, k)) {
+        hipLaunchKernelGGL((linear_lean_kernel<T, TO, 128, 128, 1>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                           (const T *)res, (TO *)y, m, n, k, act, (const T *)x2, k1);
+    } else if (!CONV && lean_ok && tile_tune == 3) {
+        dim3 grid((n + 63) / 64, (unsigned)((m + 127) / 128)), block(256);
+        hipLaunchKernelGGL((linear_lean_kernel<T, TO, 128, 64, 1>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                           (const T *)res, (TO *)y, m, n, k, act, (const T *)x2, k1);
+    } else if (!CONV && lean_ok && tile_tune == 4 && tile96(m, n, k)) {
         // 96x64 tiles, 3 compute waves + 1 loader wave: the tile count drops under one round of the chip
         dim3 grid((n + 63) / 64, (unsigned)((m + 95) / 96)), block(256);
         hipLaunchKernelGGL((linear_lean_kernel<T, TO, 96, 64, 1, false, 3>), grid, block, 0, s, (const T *)x, (const T *)w,
                            bias, (const T *)res, (TO *)y, m, n, k, act, (const T *)x2, k1);
-    } else if (!CONV && lean_ok && !(k >= 1024 && tiles64 <= 320)) {
-        // 2-stage ring, 82 VGPRs: 5-6 resident blocks per CU hide the shallower prefetch (measured on the model's
-        // 18 shapes, scripts/bench_gemm.py: 2.45 -> 2.20 ms per forward against the generic kernel)
-        dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
-        hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 1>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
-                           (const T *)res, (TO *)y, m, n, k, act, (const T *)x2, k1);
-    } else if (!CONV && lean_ok) {
-        // long K on a grid of about one block per CU: nothing else hides the load latency, so 4 stages (168 VGPRs)
+    } else if (!CONV && lean_ok && tile_tune == 5) {
+        // 4 stages (168 VGPRs): long K on a grid of about one block per CU
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
         hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 3>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
                            (const T *)res, (TO *)y, m, n, k, act, (const T *)x2, k1);
+    } else if (!CONV && lean_ok) {
+        dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
+        hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 1>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                           (const T *)res, (TO *)y, m, n, k, act, (const T *)x2, k1);
+    } else if (!x2 && big >= 2048 && k >= 1024) {
+        dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
+        hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 128, 128, 2, CONV>), grid, block, 0, s, (const T *)x,
+                           (const T *)w, bias, (const T *)res, (TO *)y, m, n, k, act, cg);
     } else if (k <= 128) {  // 1-2 K steps: a 2-stage ring, no padded dummy steps
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
         hipLaunchKernelGGL((linear_tiled_kernel<T, TO, 64, 64, 1, CONV>), grid, block, 0, s, (const T *)x,
@@ -904,7 +917,7 @@ extern "C" int tramba_linear_ln_cl(const void *x, const void *w_folded, const fl
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(TRAMBA_PROF_GEMM, s, 2.0 * (double)m * n * k);
     const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
-    const bool deep = k >= 1024 && tiles64 <= 320;       // the ring depth rule of launch_tiled
+    const bool deep = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE) == 5;   // 4-stage ring: measurement only (see launch_tiled)
     dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
     const LnIn li{colsum, eps};
 #define LNIN_(T, TO)                                                                                                     \

@@ -223,18 +223,19 @@ static int launch_layernorm(const void *x, const float *w, const float *b, void 
 //   xh = (x - mean) * rstd,  g = dy * gamma
 //   dx = rstd * (g - mean_C(g) - xh * mean_C(g * xh)),   dgamma += dy * xh,   dbeta += dy
 // mean / rstd are recomputed from x (cheaper than storing them); dgamma / dbeta accumulate over the wave's rows
-// in registers and leave as ONE partial row per wave, part[wave][0 = dgamma, 1 = dbeta][C]; the caller sums the
-// partial rows (fp32 atomics from ~4096 waves onto C addresses serialised in L2: 500 us per call, 10x the rest).
+// in registers, the four waves of a workgroup are folded in LDS and leave as ONE partial row per workgroup,
+// part[block][0 = dgamma, 1 = dbeta][C]; the caller sums the partial rows (fp32 atomics from ~4096 waves onto C addresses serialised in L2: 500 us per call, 10x the rest).
 template <typename T, int V>
 __global__ __launch_bounds__(256) void layernorm_bwd_cl_kernel(const T *__restrict__ x, const T *__restrict__ dy,
                                                               const float *__restrict__ w, T *__restrict__ dx,
                                                               float *__restrict__ part, long rows, int C, float eps,
                                                               int rpw)
 {
+    extern __shared__ float ln_red[];          // [4 waves][2 C]: the waves' (dgamma, dbeta) rows, folded before they leave
     const int lane = threadIdx.x & (kWave - 1);
-    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long r0 = wave * rpw;
-    if (r0 >= rows) return;   // wave-uniform, no barriers
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wv;
+    const long r0 = wave * rpw;                // a wave past the end runs no row and contributes zeros
     const int nit = (C + kWave * V - 1) / (kWave * V);
     float gam[kNormMaxIt][V], gw[kNormMaxIt][V], gb[kNormMaxIt][V];
 #pragma unroll
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cl_kernel(const T *__restri
                 }
             }
     }
-    float *pw = part + wave * 2 * C;
+    float *mine = ln_red + (long)wv * 2 * C;
 #pragma unroll
     for (int it = 0; it < kNormMaxIt; ++it)
         if (it < nit)
@@ -300,16 +301,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cl_kernel(const T *__restri
             for (int v = 0; v < V; ++v) {
                 const int c = (it * kWave + lane) * V + v;
                 if (c < C) {
-                    pw[c] = gw[it][v];
-                    pw[C + c] = gb[it][v];
+                    mine[c] = gw[it][v];
+                    mine[C + c] = gb[it][v];
                 }
             }
+    __syncthreads();
+    // ONE partial row per block, waves added in a fixed order
+    float *pw = part + (long)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256)
+        pw[i] = (ln_red[i] + ln_red[2 * C + i]) + (ln_red[4 * C + i] + ln_red[6 * C + i]);
 }
 
 // Short rows (C <= 64 * V, a multiple of V): LPR lanes per row, 64 / LPR rows of a wave in flight at once, 16-byte
 // accesses -- the one-row-per-wave form above is latency-bound there (rows of 128 channels keep half a wave idle and
 // every row waits for four dependent wave reductions): 1.27 ms for the 384x384 map of the last decoder stage at batch 8.
-// Same contract: the wave owns rows [wave * rpw, +rpw) and leaves ONE partial (dgamma, dbeta) row.
+// Same contract: the wave owns rows [wave * rpw, +rpw); the workgroup leaves ONE partial (dgamma, dbeta) row.
 template <typename T, int V, int LPR>
 __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const T *__restrict__ x, const T *__restrict__ dy,
                                                                 const float *__restrict__ w, T *__restrict__ dx,
@@ -831,13 +837,16 @@ extern "C" int tramba_layernorm_cl(const void *x, const float *w, const float *b
     return TRAMBA_OK;
 }
 
-static long ln_bwd_rows_per_wave(long rows)
+static long ln_bwd_rows_per_wave(long rows, bool rows_form)
 {
-    // ~4096 waves on the large maps; never fewer than 8 rows per wave: every wave leaves a (2, C) partial row that the
-    // caller sums, and at one row per wave (24x24 maps) writing and summing the partials moved 2.7x the bytes of the
-    // backward itself
+    // ~4096 waves on the large maps.  The partial (dgamma, dbeta) rows leave per WORKGROUP (four waves folded in LDS), and
+    // the caller sums them: at one row per wave and one partial per wave (24x24 maps) writing and summing the partials moved
+    // 2.7x the bytes of the backward itself.  Short rows: >= 8 rows per wave (several rows of a wave are in flight at once).
+    // Long rows (one row of a wave at a time, every row a chain of three wave reductions): >= 2, i.e. 4x the waves of the
+    // 8-row rule -- the 24x24 / 12x12 maps otherwise run half a wave per SIMD (43.6 us per call at 4608 x 1024).
     long rpw = rows / 4096;
-    return rpw < 8 ? 8 : (rpw > 128 ? 128 : rpw);
+    const long lo = rows_form ? 8 : 2;
+    return rpw < lo ? lo : (rpw > 128 ? 128 : rpw);
 }
 
 // rows of at most 64 lanes x 16 bytes: several rows per wave (layernorm_bwd_rows_kernel), one partial row per BLOCK
@@ -850,9 +859,9 @@ static bool ln_bwd_rows_form(int c, int dtype)
 extern "C" int64_t tramba_layernorm_bwd_parts(int64_t rows, int c, int dtype)
 {
     if (rows <= 0 || c <= 0) return 0;
-    const long rpw = ln_bwd_rows_per_wave(rows);
+    const long rpw = ln_bwd_rows_per_wave(rows, ln_bwd_rows_form(c, dtype));
     const long waves = (rows + rpw - 1) / rpw;
-    return ln_bwd_rows_form(c, dtype) ? (waves + 3) / 4 : waves;
+    return (waves + 3) / 4;
 }
 
 extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const float *w, void *dx, float *part,
@@ -864,7 +873,7 @@ extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const floa
     const int v = (c % 4 == 0) ? 4 : ((c % 2 == 0) ? 2 : 1);
     TRAMBA_CHECK((c + kWave * v - 1) / (kWave * v) <= kNormMaxIt, "layernorm_bwd_cl: C=%d too large", c);
     hipStream_t s = (hipStream_t)stream;
-    const long rpw = ln_bwd_rows_per_wave(rows);
+    const long rpw = ln_bwd_rows_per_wave(rows, ln_bwd_rows_form(c, dtype));
     const long waves = (rows + rpw - 1) / rpw;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     // short rows: several rows per wave, 16-byte accesses; longer rows: one row per wave
@@ -894,9 +903,10 @@ extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const floa
         return TRAMBA_OK;
     }
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
-        if (v == 4) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 4>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
-        else if (v == 2) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 2>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
-        else hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 1>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
+        const size_t lds = (size_t)8 * c * sizeof(float);
+        if (v == 4) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 4>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
+        else if (v == 2) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 2>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
+        else hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 1>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
     });
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;

@@ -208,7 +208,7 @@ def scan_order(family: str, h: int, w: int, device, param: int = 0) -> ScanOrder
 
 
 # ----------------------------------------------------------------------------- profiling / tuning
-TUNE_MERGE_FORM, TUNE_SCAN_FORM, TUNE_SCAN_W = 0, 1, 2
+TUNE_MERGE_FORM, TUNE_SCAN_FORM, TUNE_SCAN_W, TUNE_GEMM_TILE = 0, 1, 2, 3
 
 
 def tune_set(knob: int, value: int):
