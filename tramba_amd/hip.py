@@ -129,7 +129,15 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """the current HIP stream of the current device as an integer handle.  torch.cuda.current_stream() builds a Stream
+    object per call (~9 us): with ~850 library launches per training step that alone was 7 ms of the launch threads' time."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

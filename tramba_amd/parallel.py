@@ -40,6 +40,7 @@ class GradBucketReducer:
         self._armed = False
         self._hooks = []
         self._sig = None
+        self._params = None
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._native_avg = backend == "nccl"          # RCCL: ncclAvg; gloo has SUM only
         # no process group at all and full-precision buckets: nothing to exchange, nothing to round -- the gradients stay
@@ -49,13 +50,17 @@ class GradBucketReducer:
 
     # ------------------------------------------------------------------ bucket layout
     def _signature(self):
-        return tuple(p.requires_grad for p in self.model.parameters())
+        # (the parameter OBJECTS of a model do not change; walking the module tree for them every step cost 4 ms of host time)
+        if self._params is None:
+            self._params = list(self.model.parameters())
+        return tuple(p.requires_grad for p in self._params)
 
     def _build(self):
         self.remove_hooks()
         self._sig = self._signature()
         # backward produces gradients roughly in reverse parameter order: bucket in that order
-        params = [p for p in self.model.parameters() if p.requires_grad][::-1]
+        self._params = list(self.model.parameters())
+        params = [p for p in self._params if p.requires_grad][::-1]
         cap = int(self.bucket_mb * 1024 * 1024)
         self.buckets, cur, cur_bytes = [], [], 0
         for p in params:
@@ -113,7 +118,7 @@ class GradBucketReducer:
             self._pending[bi] = len(bucket)
             for p in bucket:
                 p.grad = None
-        for p in self.model.parameters():
+        for p in self._params:
             if not p.requires_grad:
                 p.grad = None
         self._armed = self.enabled
