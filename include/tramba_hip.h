@@ -84,8 +84,10 @@ int tramba_tune_get(int knob);
 #define TRAMBA_TUNE_MERGE_FORM 0
 #define TRAMBA_TUNE_SCAN_FORM 1      /* 1 = chained (register ring), 2 = wave-segment, 3 = chained on LDS-DMA staged operands */
 #define TRAMBA_TUNE_SCAN_W 2         /* waves per sequence of the register-ring chained scan (capped by the library's own choice) */
-#define TRAMBA_TUNE_GEMM_TILE 3      /* plain GEMMs with K % 64 == 0: 1 = 64x64 (the default), 2 = 128x128, 3 = 128x64, 4 = 96x64
-                                        where it saves a round of the chip, 5 = 64x64 on a 4-stage ring */
+#define TRAMBA_TUNE_GEMM_TILE 3      /* plain GEMMs with K % 64 == 0: 0 = 64x64 staged by LDS-DMA, 3 or 4 stages by shape (the default), 6 / 7 = 3 / 4 stages;
+                                        register-staged
+                                        forms: 1 = 64x64, 2 = 128x128, 3 = 128x64, 4 = 96x64 where it saves a round of the chip,
+                                        5 = 64x64 on a 4-stage ring */
 #define TRAMBA_TUNE_COUNT 4
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1

@@ -32,7 +32,7 @@ def timeit(fn, reps=20):
 
 def main():
     dev = torch.device("cuda")
-    names = {0: "auto", 1: "64x64", 2: "128x128", 3: "128x64"}
+    names = {0: "auto", 1: "reg64", 6: "dma3", 7: "dma4"}
     for batch in (4, 8):
         tot = {t: 0.0 for t in names}
         best_tot = 0.0

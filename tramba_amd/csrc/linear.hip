@@ -731,6 +731,216 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Plain GEMM with the operand tiles staged by LDS-DMA (buffer_load ... lds): 64x64 block tile, K step 64, 2 x 2 waves.
+// In the register-staged kernel above the K step's largest single cost is the VGPR -> LDS write of the staged tiles
+// (ablation on the model's shapes, r02: dropping the ds_write_b128s takes 15-32 % off the whole launch, more than dropping
+// the global loads or three quarters of the fragment reads; a ds_write_b128 occupies the LDS path for 13 cycles per KB).
+// Here a tile travels L2 -> LDS without touching a VGPR:
+//   * NSTG LDS stages (3, or 4 for long K on a one-block-per-CU grid) of (A 64 x 64, B 64 x 64) 16-bit = 16 KB; waves 0-1 fetch A, waves 2-3 fetch B, four 1 KB pieces per
+//     wave and K step.  A piece is 8 rows x 128 B; lane i lands at piece + 16 i, so the XOR chunk swizzle of the fragment
+//     reads is applied on the GLOBAL side: lane i fetches chunk (i & 7) ^ ((row >> 1) & 7) of row piece*8 + (i >> 3)
+//     (the 8 lanes of a row still cover one 128-byte line);
+//   * step kt:  s_waitcnt vmcnt(4)  my pieces of tile kt have landed (only the four pieces of each later tile already
+//                                   requested may be outstanding: 4 (NSTG - 2), less on the last steps -- no tile past the
+//                                   end of K is ever fetched)
+//               s_barrier           everyone's have; everyone has read tile kt-1 out of the stage about to be refilled
+//               DMA tile kt + NSTG - 1 -> the stage tile kt - 1 was read out of
+//               8 ds_read_b128 (hand-written: hipcc orders an LDS read it can see behind EVERY pending LDS-DMA, i.e.
+//               vmcnt(0) per step), counted lgkmcnt waits, 4 MFMAs
+//   * ~70 VGPRs, no staging registers; rows past M / N read as zero through the descriptor's range check.
+// Same epilogue (tile_epilogue) as the other forms.
+#define TRAMBA_DSR128_(OUT, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(OUT) : "v"(ADDR) : "memory")
+
+template <typename T, typename TO, int NSTG, bool LNIN = false>
+__global__ __launch_bounds__(256) void linear_dma_kernel(const T *__restrict__ x, const T *__restrict__ w,
+                                                        const float *__restrict__ bias, const T *__restrict__ res,
+                                                        TO *__restrict__ y, long M, int N, int K, int act,
+                                                        LnIn li = LnIn{nullptr, 0.f})
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // (vector-register asm in a kernel template: see ss2d_scan_dma_kernel)
+    constexpr int BM = 64, BN = 64;
+    constexpr int TILE_BYTES = (BM + BN) * kBK * 2;          // 16 KB
+    constexpr int EPI_BYTES = BM * (BN + 4) * 4;
+    constexpr int LDS_BYTES = NSTG * TILE_BYTES > EPI_BYTES ? NSTG * TILE_BYTES : EPI_BYTES;
+    static_assert(NSTG == 3 || NSTG == 4, "stage index = kt % NSTG with the loop unrolled by NSTG (up to 8 stages are coded)");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES + (LNIN ? BM * 8 : 0)];
+    typedef __attribute__((address_space(3))) void lds_void;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hi = lane >> 5;
+    long m0;
+    int n0;
+    {   // XCD-aware tile order (see linear_tiled_kernel)
+        const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned q = nblk >> 3, r = nblk & 7, xcd = lin & 7, slot = lin >> 3;
+        const unsigned t = xcd * q + (xcd < r ? xcd : r) + slot;
+        m0 = (long)(t / gridDim.x) * BM;
+        n0 = (int)(t % gridDim.x) * BN;
+    }
+    const int nk = K / kBK;
+    const unsigned rowb = (unsigned)K * 2u;
+    const long mrows = M - m0 < BM ? M - m0 : BM;
+    const int nrows = N - n0 < BN ? N - n0 : BN;
+    // waves 0-1 stage A (rows of x), waves 2-3 stage B (rows of w): one descriptor per wave, wave-uniform
+    const bool stage_b = wave >= 2;
+    const __amdgpu_buffer_rsrc_t rs = stage_b ? make_rsrc(w + (long)n0 * K, (unsigned)nrows * rowb)
+                                              : make_rsrc(x + m0 * K, (unsigned)mrows * rowb);
+    unsigned voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = ((wave & 1) * 4 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        voff[j] = (unsigned)row * rowb + (unsigned)c * 16u;
+    }
+    unsigned char *mine = lds + (stage_b ? BM * kBK * 2 : 0) + (wave & 1) * 4096;   // my four pieces inside a stage
+    auto issue = [&](int kt, int stg) {
+        const unsigned so = (unsigned)kt * (kBK * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(mine + stg * TILE_BYTES + j * 1024), 16, voff[j], so, 0,
+                                                     0);
+    };
+    // fragment read addresses (absolute LDS bytes) of the four 16-deep slices: chunk (2 kk + hi) ^ ((row >> 1) & 7)
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    unsigned aad[4], bad[4];
+    {
+        const int ra_ = wm * 32 + r32, rb_ = wn * 32 + r32;
+        const unsigned a0 = lbase + (unsigned)(ra_ * 128 + ((hi ^ ((ra_ >> 1) & 7)) * 16));
+        const unsigned b0 = lbase + (unsigned)(BM * kBK * 2 + rb_ * 128 + ((hi ^ ((rb_ >> 1) & 7)) * 16));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            aad[kk] = a0 ^ (unsigned)(kk * 32);      // (lds is 1 KB aligned: the XOR stays inside the row)
+            bad[kk] = b0 ^ (unsigned)(kk * 32);
+        }
+    }
+    acc16_t acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    // LNIN (LayerNorm of the input rows folded in, see LnIn): sum and sum of squares of the A rows, read back from the
+    // staged tile -- thread t adds the 16-byte pieces at chunk POSITION t & 7 of rows t >> 3 and (t >> 3) + 32 at every K
+    // step (whatever chunk the swizzle put there: a row's statistics run over all of its chunks), two more ds_read_b128
+    // beside the eight fragment reads
+    float rs1[2] = {0.f, 0.f}, rs2[2] = {0.f, 0.f};
+    const unsigned sad = lbase + (unsigned)((tid >> 3) * 128 + (tid & 7) * 16);
+
+    constexpr int DEPTH = NSTG - 1;                  // tiles in flight ahead of the one being multiplied
+#pragma unroll
+    for (int t = 0; t < DEPTH; ++t)
+        if (t < nk) issue(t, t);
+    // stages 4..7 lie past the 16-bit offset field of ds_read: a second set of addresses, 64 KB up
+    unsigned aad_hi[4], bad_hi[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        aad_hi[kk] = aad[kk] + 65536u;
+        bad_hi[kk] = bad[kk] + 65536u;
+    }
+    const unsigned sad_hi = sad + 65536u;
+    auto kstep = [&](int kt, auto stg_c) {
+        constexpr int STG = decltype(stg_c)::value;
+        // my pieces of tile kt have landed: only the four pieces of each LATER tile already requested may be in flight
+        const int later = nk - 1 - kt;
+        if (later >= DEPTH - 1) {
+            if constexpr (DEPTH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (DEPTH == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        } else {
+            switch (later) {   // (block-uniform) the last DEPTH - 1 steps
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + DEPTH < nk) issue(kt + DEPTH, (STG + DEPTH) % NSTG);
+        frag8_t a[4], b[4];
+        v4u_t sv[2];
+        const unsigned *aa = STG < 4 ? aad : aad_hi, *ba = STG < 4 ? bad : bad_hi;
+        const unsigned sa = STG < 4 ? sad : sad_hi;
+#define TRAMBA_RD_STG_(S, S2)                                                                       \
+    if constexpr (LNIN) { TRAMBA_DSR128_(sv[0], sa, S); TRAMBA_DSR128_(sv[1], sa, S2); }             \
+    TRAMBA_DSR128_(a[0], aa[0], S); TRAMBA_DSR128_(b[0], ba[0], S); TRAMBA_DSR128_(a[1], aa[1], S);  \
+    TRAMBA_DSR128_(b[1], ba[1], S); TRAMBA_DSR128_(a[2], aa[2], S); TRAMBA_DSR128_(b[2], ba[2], S);  \
+    TRAMBA_DSR128_(a[3], aa[3], S); TRAMBA_DSR128_(b[3], ba[3], S)
+        if constexpr ((STG & 3) == 0) { TRAMBA_RD_STG_(0, 4096); }
+        else if constexpr ((STG & 3) == 1) { TRAMBA_RD_STG_(16384, 20480); }
+        else if constexpr ((STG & 3) == 2) { TRAMBA_RD_STG_(32768, 36864); }
+        else { TRAMBA_RD_STG_(49152, 53248); }
+#undef TRAMBA_RD_STG_
+        if constexpr (LNIN) {   // (the two statistics reads were issued first: they are done once eight reads remain)
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(sv[0]), "+v"(sv[1]) : : "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rs1[i] = dot2_ones<T>(sv[i][e], rs1[i]);
+                    rs2[i] = dot2_self<T>(sv[i][e], rs2[i]);
+                }
+        }
+        // counted waits: slice kk needs the first 2 (kk + 1) reads; every destination is named so that no MFMA moves above
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0]), "+v"(b[0]) : : "memory");
+        acc[0][0] = Mfma<T>::run(b[0], a[0], acc[0][0]);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[1]), "+v"(b[1]) : : "memory");
+        acc[0][0] = Mfma<T>::run(b[1], a[1], acc[0][0]);
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[2]), "+v"(b[2]) : : "memory");
+        acc[0][0] = Mfma<T>::run(b[2], a[2], acc[0][0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[3]), "+v"(b[3]) : : "memory");
+        acc[0][0] = Mfma<T>::run(b[3], a[3], acc[0][0]);
+    };
+    int kt0 = 0;
+    for (; kt0 + NSTG <= nk; kt0 += NSTG) {
+        kstep(kt0, std::integral_constant<int, 0>{});
+        kstep(kt0 + 1, std::integral_constant<int, 1>{});
+        kstep(kt0 + 2, std::integral_constant<int, 2>{});
+        if constexpr (NSTG > 3) kstep(kt0 + 3, std::integral_constant<int, 3>{});
+        if constexpr (NSTG > 4) {
+            kstep(kt0 + 4, std::integral_constant<int, 4>{});
+            kstep(kt0 + 5, std::integral_constant<int, 5>{});
+            kstep(kt0 + 6, std::integral_constant<int, 6>{});
+            kstep(kt0 + 7, std::integral_constant<int, 7>{});
+        }
+    }
+    if (kt0 < nk) kstep(kt0, std::integral_constant<int, 0>{});
+    if (kt0 + 1 < nk) kstep(kt0 + 1, std::integral_constant<int, 1>{});
+    if constexpr (NSTG > 3) {
+        if (kt0 + 2 < nk) kstep(kt0 + 2, std::integral_constant<int, 2>{});
+    }
+    if constexpr (NSTG > 4) {
+        if (kt0 + 3 < nk) kstep(kt0 + 3, std::integral_constant<int, 3>{});
+        if (kt0 + 4 < nk) kstep(kt0 + 4, std::integral_constant<int, 4>{});
+        if (kt0 + 5 < nk) kstep(kt0 + 5, std::integral_constant<int, 5>{});
+        if (kt0 + 6 < nk) kstep(kt0 + 6, std::integral_constant<int, 6>{});
+    }
+    __syncthreads();                                       // every wave has read the last tile: the epilogue reuses the LDS
+    if constexpr (LNIN) {
+        float2 *rowstat = reinterpret_cast<float2 *>(lds + LDS_BYTES);   // read by the epilogue behind its own barrier
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float s1 = rs1[i], s2 = rs2[i];
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {      // the 8 lanes that cover one row
+                s1 += __shfl_xor(s1, m, 64);
+                s2 += __shfl_xor(s2, m, 64);
+            }
+            const float mean = s1 / (float)K;
+            const float var = fmaxf(s2 / (float)K - mean * mean, 0.f);
+            if ((tid & 7) == 0) rowstat[(tid >> 3) + 32 * i] = make_float2(mean, rsqrtf(var + li.eps));
+        }
+        tile_epilogue<T, TO, BM, BN, 2>(acc, lds, bias, res, y, M, N, act, m0, n0, li.colsum,
+                                        reinterpret_cast<const float2 *>(lds + LDS_BYTES));
+    } else {
+        tile_epilogue<T, TO, BM, BN, 2>(acc, lds, bias, res, y, M, N, act, m0, n0);
+    }
+#endif
+}
+#undef TRAMBA_DSR128_
+
 // Tile choice: 64x64 (3 K-tiles in flight) wins on every GEMM of this model (M = 576..36864, N <= 4096,
 // K <= 4096: short-M or short-K, measured in scripts/bench_gemm.py); 128x128 only pays once both the tile
 // count and K are large.  TRAMBA_GEMM_TILE=128x128 forces it (tuning aid).
@@ -754,14 +964,26 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
     // lean kernel: whole 64-deep K steps, and a 64-row operand panel within 32-bit byte offsets
     const bool lean_ok = k % 64 == 0 && (double)k * 2.0 * 128.0 < 2147483648.0;
     const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
-    // Lean-kernel tile: 64x64 with a 2-stage ring (82 VGPRs, 5-6 resident blocks per CU) on every shape of the model.
-    // Measured back to back in one process at batch 4 and 8 (scripts/bench_gemm_tiles.py) and in-model (scripts/ab_tune.py:
-    // 5.30 -> 5.24 ms per forward): 128x128 tiles (1-2 resident blocks: the load -> LDS -> MFMA chain of a K step lies
-    // open) run 1.3-2x SLOWER, 128x64 0-40 % slower, and the two special cases kept until r02 -- 96x64 tiles where 64x64
-    // lands just above a round of the chip, a 4-stage ring for long K on one block per CU -- lose 0.5-1.5 us each.  The other
-    // forms stay reachable through TRAMBA_TUNE_GEMM_TILE for such measurements.
+    // Plain GEMMs with K % 64 == 0 (every 1x1 convolution of the model): the LDS-DMA staged 64x64 kernel.  Measured back to
+    // back in one process on the model's shapes at batch 4 and 8 (scripts/bench_gemm_tiles.py): 14 % / 9 % less time per
+    // pass than the register-staged 64x64 kernel (2-stage ring, 82 VGPRs), faster on every shape (19.4 -> 13.0 us at
+    // M = 2304, N = 512, K = 2048).  Register-staged forms for comparison, through TRAMBA_TUNE_GEMM_TILE: 1 = 64x64 (the
+    // default until r02; still used for the two-source A operand), 2 = 128x128 (1-2 resident blocks: 1.3-2x slower),
+    // 3 = 128x64, 4 = 96x64 where it saves a round of the chip, 5 = 64x64 on a 4-stage ring.
     const int tile_tune = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE);
-    if (!CONV && lean_ok && tile_tune == 2) {
+    // (4 stages = 3 tiles in flight where at most one block lands on a CU and K is long: nothing else hides the load latency
+    //  there -- M = 576, N = 1024, K = 4096: 27 -> 22 us with operands that are not cache-resident; 8 stages = one block per
+    //  CU by LDS, was measured slower on every shape and is not built)
+    const bool dma_deep = tile_tune == 7 || (tile_tune == 0 && tiles64 <= 256 && k >= 1024);
+    if (!CONV && lean_ok && !x2 && (tile_tune == 0 || tile_tune == 6 || tile_tune == 7)) {
+        dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
+        if (dma_deep)
+            hipLaunchKernelGGL((linear_dma_kernel<T, TO, 4>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                               (const T *)res, (TO *)y, m, n, k, act);
+        else
+            hipLaunchKernelGGL((linear_dma_kernel<T, TO, 3>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                               (const T *)res, (TO *)y, m, n, k, act);
+    } else if (!CONV && lean_ok && tile_tune == 2) {
         dim3 grid((n + 127) / 128, (unsigned)((m + 127) / 128)), block(256);
         hipLaunchKernelGGL((linear_lean_kernel<T, TO, 128, 128, 1>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
                            (const T *)res, (TO *)y, m, n, k, act, (const T *)x2, k1);
@@ -917,11 +1139,16 @@ extern "C" int tramba_linear_ln_cl(const void *x, const void *w_folded, const fl
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(TRAMBA_PROF_GEMM, s, 2.0 * (double)m * n * k);
     const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
-    const bool deep = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE) == 5;   // 4-stage ring: measurement only (see launch_tiled)
+    const int tile_tune = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE);
+    const bool deep = tile_tune == 5;                    // 4-stage register ring: measurement only (see launch_tiled)
+    const bool dma = tile_tune == 0 || tile_tune == 6;   // the LDS-DMA staged kernel (default)
     dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
     const LnIn li{colsum, eps};
 #define LNIN_(T, TO)                                                                                                     \
-    if (deep)                                                                                                            \
+    if (dma)                                                                                                             \
+        hipLaunchKernelGGL((linear_dma_kernel<T, TO, 3, true>), grid, block, 0, s, (const T *)x, (const T *)w_folded, bias, \
+                           (const T *)residual, (TO *)y, m, n, k, act, li);                                              \
+    else if (deep)                                                                                                            \
         hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 3, false, 2, true>), grid, block, 0, s, (const T *)x,       \
                            (const T *)w_folded, bias, (const T *)residual, (TO *)y, m, n, k, act, (const T *)nullptr, 0,  \
                            LnHead{}, li);                                                                                \
