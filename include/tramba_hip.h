@@ -205,10 +205,10 @@ int tramba_dw_pack(const float *w, const float *bias, const float *w3, const flo
 int tramba_dwconv_cl(const void *x, const float *wt, const float *bt, void *y, int batch, int h,
                      int wd, int c, int ks, int act, int dtype, void *stream);
 /* Training: gradients of the same stencil w.r.t. its tap-major weights and bias (what autograd computes for
- * nn.Conv2d(groups=C), vmamba.py:301, 595-603).  part (P, ks*ks + 1, C) f32, P = tramba_dwconv_wgrad_parts(batch, h):
- * one partial row per wave slot, planes 0..ks*ks-1 = taps, last plane = bias; the caller sums over P (fixed
- * order).  The input gradient is tramba_dwconv_cl(gy, flipped taps, zero bias). */
-int64_t tramba_dwconv_wgrad_parts(int batch, int h);
+ * nn.Conv2d(groups=C), vmamba.py:301, 595-603).  part (P, ks*ks + 1, C) f32, P = tramba_dwconv_wgrad_parts(batch, h, wd,
+ * ks): one partial row per workgroup (image, row band, column range), planes 0..ks*ks-1 = taps, last plane = bias; the
+ * caller sums over P (tramba_slab_sum: fixed order).  The input gradient is tramba_dwconv_cl(gy, flipped taps, zero bias). */
+int64_t tramba_dwconv_wgrad_parts(int batch, int h, int wd, int ks);
 int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *part, int batch, int h, int wd, int c, int ks,
                            int dtype, void *stream);
 /* x: (B, n, n, C).  Y = Wy X Wx^T per channel; low = Y[:n/2,:n/2], high = Y[n/2:,n/2:],

@@ -686,18 +686,32 @@ __device__ __forceinline__ dw_v2f dw_load2(__amdgpu_buffer_rsrc_t r, unsigned vo
     }
 }
 
+// waves per workgroup of the depth-wise weight-gradient kernel: 16 for the 3x3 stencil, 8 for the wider ones (their ks*ks
+// accumulator pairs need more than the 128 registers a 1024-thread workgroup leaves a lane)
+constexpr int dwg_waves(int ks) { return ks <= 3 ? 16 : 8; }
+
 template <typename T, int KS>
-__global__ __launch_bounds__(256) void dwconv_wgrad_cl_kernel(const T *__restrict__ x, const T *__restrict__ gy,
-                                                             float *__restrict__ part, int H, int W, int C, int RPW)
+__global__ __launch_bounds__(dwg_waves(KS) * kWave) void dwconv_wgrad_cl_kernel(const T *__restrict__ x,
+                                                                          const T *__restrict__ gy,
+                                                                          float *__restrict__ part, int H, int W, int C,
+                                                                          int RPW, int CS)
 {
-    constexpr int V = 2, R = KS / 2, TW = 4, NI = TW + KS - 1;
+    // A workgroup of NW (16 or 8) waves owns one image, one 128-channel tile, a band of NW * RPW rows and one of CS column
+    // ranges; wave w walks rows [band + w RPW, +RPW).  The waves' accumulators are folded through LDS in wave order (fixed
+    // -> reproducible) and leave as ONE partial row per workgroup: several times the waves of the 4-wave form for the same
+    // number of partial rows (r02: 384 waves for a 96x96 map at batch 8 ran 179 us for the 7x7 stencil).
+    constexpr int V = 2, R = KS / 2, TW = 4, NI = TW + KS - 1, kDwgWaves = dwg_waves(KS);
+    __shared__ float red[KS * KS + 1][2 * kWave];
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = (blockIdx.x * kWave + lane) * V;
     const bool cok = c0 + V <= C;
-    const int row0 = (blockIdx.y * 4 + wv) * RPW;       // first image row of this wave
+    const int band = blockIdx.y / CS, cs = blockIdx.y % CS;
+    const int row0 = (band * kDwgWaves + wv) * RPW;     // first image row of this wave
+    const int wseg = ((W + CS - 1) / CS + TW - 1) / TW * TW;   // columns per range, whole groups of TW
+    const int wlo = cs * wseg, whi = wlo + wseg < W ? wlo + wseg : W;
     const int b = blockIdx.z;
-    // (waves past the last row still run: their slot must hold zeros, not stale memory)
+    // (waves past the last row still run: they contribute zeros)
     const unsigned colb = (unsigned)C * (unsigned)sizeof(T), rowb = (unsigned)W * colb;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * H * W * C, (unsigned)H * rowb);
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(gy + (long)b * H * W * C, (unsigned)H * rowb);
@@ -714,7 +728,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_cl_kernel(const T *__restric
         // small stencil: every tap row unrolled -- all KS * NI loads of a column group are in flight together (one memory
         // latency per group instead of one per tap row) and acc[][] is indexed statically
         for (int h = row0; h < rend; ++h) {
-            for (int w0 = 0; w0 < W; w0 += TW) {
+            for (int w0 = wlo; w0 < whi; w0 += TW) {
                 dw_v2f g[TW];
 #pragma unroll
                 for (int t = 0; t < TW; ++t) {
@@ -754,7 +768,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_cl_kernel(const T *__restric
                 const int hy = h + dy - R;
                 if (hy < 0 || hy >= H) continue;   // (dy == R is never skipped: the bias sum below sees every row)
 #pragma unroll 2
-                for (int w0 = 0; w0 < W; w0 += TW) {
+                for (int w0 = wlo; w0 < whi; w0 += TW) {
                     dw_v2f g[TW], xin[NI];
 #pragma unroll
                     for (int t = 0; t < TW; ++t) {
@@ -779,18 +793,30 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_cl_kernel(const T *__restric
             }
         }
     }
-    if (!cok) return;
-    // slot = (image, row group, wave): gridDim.y * 4 row slots per image
-    float *p = part + (((long)b * gridDim.y + blockIdx.y) * 4 + wv) * (long)(KS * KS + 1) * C + c0;
+    // ordered fold of the 16 waves: wave 0 stores, waves 1..15 add in turn
+    for (int q = 0; q < kDwgWaves; ++q) {
+        if (wv == q) {
 #pragma unroll
-    for (int dy = 0; dy < KS; ++dy)
+            for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < KS; ++dx) {
-            p[(long)(dy * KS + dx) * C] = acc[dy][dx].x;
-            p[(long)(dy * KS + dx) * C + 1] = acc[dy][dx].y;
+                for (int dx = 0; dx < KS; ++dx) {
+                    float2 *r = reinterpret_cast<float2 *>(&red[dy * KS + dx][2 * lane]);
+                    const float2 o = q == 0 ? make_float2(0.f, 0.f) : *r;
+                    *r = make_float2(o.x + acc[dy][dx].x, o.y + acc[dy][dx].y);
+                }
+            float2 *r = reinterpret_cast<float2 *>(&red[KS * KS][2 * lane]);
+            const float2 o = q == 0 ? make_float2(0.f, 0.f) : *r;
+            *r = make_float2(o.x + accb.x, o.y + accb.y);
         }
-    p[(long)(KS * KS) * C] = accb.x;
-    p[(long)(KS * KS) * C + 1] = accb.y;
+        __syncthreads();
+    }
+    // slot = (image, band, column range)
+    float *p = part + ((long)b * gridDim.y + blockIdx.y) * (long)(KS * KS + 1) * C + (long)blockIdx.x * 2 * kWave;
+    const int cleft = C - blockIdx.x * 2 * kWave;      // channels of this tile that exist
+    for (int i = threadIdx.x; i < (KS * KS + 1) * 2 * kWave; i += kDwgWaves * kWave) {
+        const int t = i / (2 * kWave), c = i % (2 * kWave);
+        if (c < cleft) p[(long)t * C + c] = red[t][c];
+    }
 }
 
 template <typename T, int KS>
@@ -962,13 +988,15 @@ extern "C" int tramba_dw_pack(const float *w, const float *bias, const float *w3
     return TRAMBA_OK;
 }
 
-static int dw_wgrad_rpw(int h) { return h >= 48 ? 4 : 1; }
+// rows per wave / column ranges of the depth-wise weight gradient: bands of 16 (8) waves; maps of >= 48 columns are cut in two
+static int dw_wgrad_rpw(int h) { return h > 96 ? 2 : 1; }
+static int dw_wgrad_cs(int wd) { return wd >= 48 ? 2 : 1; }
 
-extern "C" int64_t tramba_dwconv_wgrad_parts(int batch, int h)
+extern "C" int64_t tramba_dwconv_wgrad_parts(int batch, int h, int wd, int ks)
 {
-    if (batch <= 0 || h <= 0) return 0;
-    const int rpw = dw_wgrad_rpw(h);
-    return (int64_t)batch * ((h + 4 * rpw - 1) / (4 * rpw)) * 4;
+    if (batch <= 0 || h <= 0 || wd <= 0 || ks <= 0) return 0;
+    const int rpw = dw_wgrad_rpw(h), nw = dwg_waves(ks);
+    return (int64_t)batch * ((h + nw * rpw - 1) / (nw * rpw)) * dw_wgrad_cs(wd);
 }
 
 extern "C" int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *part, int batch, int h, int wd, int c,
@@ -980,12 +1008,13 @@ extern "C" int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *part
     TRAMBA_CHECK(c % 2 == 0, "dwconv_wgrad_cl: C=%d must be even", c);
     TRAMBA_CHECK(batch <= 65535 && (double)h * wd * c * 4.0 < 2147483648.0, "dwconv_wgrad_cl: shape exceeds this build's limits");
     hipStream_t s = (hipStream_t)stream;
-    const int rpw = dw_wgrad_rpw(h);
-    dim3 grid((unsigned)((c / 2 + kWave - 1) / kWave), (unsigned)((h + 4 * rpw - 1) / (4 * rpw)), (unsigned)batch), block(256);
+    const int rpw = dw_wgrad_rpw(h), cs = dw_wgrad_cs(wd), nw = dwg_waves(ks);
+    dim3 grid((unsigned)((c / 2 + kWave - 1) / kWave), (unsigned)(((h + nw * rpw - 1) / (nw * rpw)) * cs), (unsigned)batch),
+        block(nw * kWave);
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
-        if (ks == 3) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 3>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw);
-        else if (ks == 5) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 5>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw);
-        else hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 7>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw);
+        if (ks == 3) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 3>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw, cs);
+        else if (ks == 5) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 5>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw, cs);
+        else hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 7>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw, cs);
     });
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;

@@ -59,7 +59,7 @@ SIGNATURES = {
     "tramba_saliency_stats": (c_int, [c_vp] * 4 + [c_int] * 3 + [c_vp]),
     "tramba_dw_pack": (c_int, [c_vp] * 8 + [c_int] * 2 + [c_vp]),
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
-    "tramba_dwconv_wgrad_parts": (c_i64, [c_int, c_int]),
+    "tramba_dwconv_wgrad_parts": (c_i64, [c_int, c_int, c_int, c_int]),
     "tramba_dwconv_wgrad_cl": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
@@ -525,7 +525,7 @@ def dwconv_wgrad_cl(x, gy, ks):
     bb, h, wd, c = x.shape
     if gy.shape != x.shape or gy.dtype != x.dtype:
         raise TrambaHipError("dwconv_wgrad_cl: x / gy mismatch")
-    part = torch.empty((lib().tramba_dwconv_wgrad_parts(bb, h), ks * ks + 1, c), dtype=torch.float32, device=x.device)
+    part = torch.empty((lib().tramba_dwconv_wgrad_parts(bb, h, wd, ks), ks * ks + 1, c), dtype=torch.float32, device=x.device)
     _check(lib().tramba_dwconv_wgrad_cl(_ptr(x), _ptr(gy), _ptr(part), bb, h, wd, c, ks, dt(x), _stream()),
            "dwconv_wgrad_cl")
     s = slab_sum(part)
