@@ -881,9 +881,10 @@ class _SS2DCoreCL(torch.autograd.Function):
         gym = gym.contiguous()
         if gym.dtype not in (torch.float32, x.dtype):
             gym = gym.float()
-        # gradients of the x_dbl rows in sequence order: the kernel accumulates dB / dC straight into their columns
-        g_seq = torch.zeros((b, k, l, rg), dtype=torch.float32, device=x.device)
-        gu, graw, _, _, gpar = hip.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, gym, g_seq)
+        # (dB / dC stay packed (B,K,L) arrays: accumulating them straight into the RG-strided columns of g_seq -- the
+        # kernel can, `bc_stride` -- put every atomic on a cache line of its own and cost the scan backward 30 %)
+        gu, graw, g_b, g_c, gpar = hip.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, gym)
+        g_seq = torch.zeros((b, k, l, rg), dtype=torch.float32, device=x.device)   # x_dbl-row gradients, sequence order
         gx = hip.ss2d_merge_sum_cl(gu, order, x.dtype)
         # row (l, k) of xdbl viewed as (B, L*K, RG) that sequence position (k, i) reads: table[k][i] * K + k.  One gather
         # and one index_add_ over all K directions instead of 4 launches per direction (660 small kernels per step)
@@ -915,6 +916,8 @@ class _SS2DCoreCL(torch.autograd.Function):
                 g_seq[..., :r] += tmp[..., :r]
         if g_dtw.shape[-1] != r:
             g_dtw = g_dtw[..., :r].contiguous()     # (a view would be cloned by autograd's gradient accumulation anyway)
+        g_seq[..., r8] = g_b
+        g_seq[..., r8 + 1] = g_c
         g_xd = torch.zeros_like(xdf)
         g_xd.index_add_(1, flat, g_seq.view(b, k * l, rg))
         gp = hip.slab_sum(gpar)                                                           # (3,K,D): contiguous planes
