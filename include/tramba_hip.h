@@ -147,25 +147,29 @@ int tramba_cross_merge(const void *ys, const int32_t *inv_ptr, const int32_t *in
 int tramba_ss2d_group_stride(int r);
 /* workspace (device memory, 16-byte aligned, >= tramba_ss2d_scan_workspace() bytes) selects the
  * wave-segment form: segment reduce -> carry scan -> segment replay, every wave independent.  With
- * workspace == NULL the chained single-pass kernel (one workgroup per sequence) runs instead. */
+ * workspace == NULL the chained single-pass kernel (one workgroup per sequence) runs instead.
+ * states (training; NULL otherwise, requires ys_dtype == dtype): tramba_ss2d_scan_bwd_workspace() bytes that receive the
+ * recurrence state entering every 32-position tile, (B, K, ceil(L/32) + 8, D) f32 -- handed to tramba_ss2d_scan_bwd_cl as
+ * its workspace with have_states = 1, the backward skips the sweep that would recompute them. */
 size_t tramba_ss2d_scan_workspace(int batch, int l, int d, int k);
 int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
                         const float *dt_bias, const float *A, const float *Ds, void *ys, void *workspace,
                         size_t workspace_bytes, int batch, int l, int d, int k, int r, int dtype,
-                        int ys_dtype, void *stream);
+                        int ys_dtype, float *states, void *stream);
 /* Training: backward of tramba_ss2d_scan_cl + the merge that follows it.  gym (B, L, D), f32 or dtype (gym_dtype), is the
  * gradient of the MERGED map (CrossMerge output, before out_norm); the kernel gathers it through `table`.  Outputs, in SEQUENCE
  * order like ys: gu (B,K,L,D) dtype = dL/d(gathered x) -- merge it with tramba_ss2d_merge_norm_cl(eps < 0) to get
  * dL/dx; graw (B,K,L,D) dtype = dL/d(x_proj ranks . dt_w) before bias and softplus; gB, gC (B,K,L) f32 ACCUMULATED
  * (zero them first), element (b,k,l) at gB[((b*K + k)*L + l) * bc_stride] -- bc_stride = 1 for packed arrays, or the row
  * stride of a (B,K,L,RG) x_dbl-gradient table whose B / C columns the two pointers address; gpar (B,3,K,D) f32 = per-channel dA, dD, d(dt_bias) planes (sum over B for the parameters).
- * workspace: tramba_ss2d_scan_bwd_workspace() bytes of device scratch. */
+ * workspace: tramba_ss2d_scan_bwd_workspace() bytes of device scratch -- or, with have_states = 1, the `states` buffer the
+ * forward launch filled. */
 size_t tramba_ss2d_scan_bwd_workspace(int batch, int l, int d, int k);
 int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
                             const float *dt_bias, const float *A, const float *Ds, const void *gym, void *gu,
                             void *graw, float *gB, float *gC, int bc_stride, float *gpar, void *workspace,
-                            size_t workspace_bytes, int batch, int l, int d, int k, int r, int dtype, int gym_dtype,
-                            void *stream);
+                            size_t workspace_bytes, int have_states, int batch, int l, int d, int k, int r, int dtype,
+                            int gym_dtype, void *stream);
 /* y[b,p,:] = act(LayerNorm_D(sum_{e in inv[p]} ys[b, e/L, e%L, :]));  y: (B, L, D) dtype.
  * eps < 0: the plain sum (CrossMerge alone), ln_w / ln_b / act ignored. */
 int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr, const int32_t *inv_idx,

@@ -503,6 +503,47 @@ def _ref_core_fp64(x, xdbl, table, dt_w, dt_bias, a_neg, ds, r):
     return ym
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("fam,h,d,r,b", [("raster", 24, 64, 32, 2), ("helix", 96, 256, 8, 1), ("raster", 96, 256, 8, 2),
+                                         ("helix", 48, 512, 16, 1), ("window", 24, 40, 3, 1), ("raster", 12, 2048, 64, 1),
+                                         ("dilation", 13, 96, 5, 1)])
+def test_ss2d_saved_states_equal_the_recomputed_ones(dtype, fam, h, d, r, b):
+    """Training: the forward launch saves the state entering every tile (ss2d_scan_cl(states=...), register-ring and LDS-DMA
+    forms, ragged sequence ends) and the backward launch skips the sweep that recomputes them: same ys as the plain forward,
+    and every output of the backward bit-identical to the run that recomputes."""
+    H = hip()
+    dev = torch.device(DEV)
+    if dtype == torch.float32 and h >= 48:
+        pytest.skip("fp32 at the large maps: covered at the small ones")
+    order = H.scan_order(fam, h, h, dev)
+    k, l = order.k, h * h
+    rg = H.ss2d_group_stride(r)
+    g = torch.Generator().manual_seed(h + d + r)
+    x = torch.randn(b, l, d, generator=g).to(dtype).to(dev)
+    xdbl = torch.zeros(b, l, k, rg)
+    xdbl[..., :r] = 0.5 * torch.randn(b, l, k, r, generator=g)
+    xdbl[..., rg - 4:rg - 2] = torch.randn(b, l, k, 2, generator=g)
+    xdbl = xdbl.view(b, l, k * rg).to(dev)
+    dt_w = (torch.randn(k, d, r, generator=g) * r ** -0.5).to(dev)
+    dt_b = (torch.randn(k * d, generator=g) * 0.5 - 1.0).to(dev)
+    a_neg = (-(torch.rand(k * d, generator=g) * 0.8 + 0.2)).to(dev)
+    ds = (1 + 0.1 * torch.randn(k * d, generator=g)).to(dev)
+    gym = torch.randn(b, l, d, generator=g).to(dtype).to(dev)
+    states = H.ss2d_scan_states(x, order)
+    states.fill_(0xFF)                                           # NaN patterns: an unwritten state would poison the result
+    ys_s = H.ss2d_scan_cl(x, xdbl, order, dt_w, dt_b, a_neg, ds, dtype, states=states)
+    ys_p = H.ss2d_scan_cl(x, xdbl, order, dt_w, dt_b, a_neg, ds, dtype, segmented=False)
+    assert torch.equal(ys_s, ys_p)
+    with_states = H.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_b, a_neg, ds, gym, states=states)
+    recomputed = H.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_b, a_neg, ds, gym)
+    for name, u, v in zip(("gu", "graw", "gB", "gC", "gpar"), with_states, recomputed):
+        assert torch.isfinite(u.float()).all(), name
+        if name in ("gB", "gC"):                                 # accumulated by float atomics over the channel tiles
+            np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(v.abs().max()), err_msg=name)
+        else:
+            assert torch.equal(u, v), name
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("fam,h,d,r,b", [("raster", 12, 64, 4, 2), ("helix", 12, 32, 8, 1), ("window", 24, 40, 3, 1),
                                          ("dilation", 16, 96, 16, 2), ("raster", 24, 64, 40, 1)])

@@ -374,11 +374,13 @@ struct ScanWave {
 // the x_proj rows 8 times.  Channel tile fastest inside an XCD's run: the tiles sharing lines run side by side on one
 // XCD and the second reader hits in its L2.
 
-template <typename T, typename TY, int NK, bool SPLIT>
+// SAVE (training): the state entering every tile also goes to hst (B, K, NTA, D) f32, NTA = ceil(L / 32) + kMaxW -- the
+// backward kernel then skips its first sweep, which recomputes exactly these values.
+template <typename T, typename TY, int NK, bool SPLIT, bool SAVE = false>
 __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
-    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W)
+    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W, float *__restrict__ hst = nullptr)
 {
     __shared__ float agg[2][kMaxW][2][kTP];
     __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];
@@ -479,6 +481,10 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
             h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
         }
         carry = h;
+        if constexpr (SAVE) {
+            const long nta = (L + kTP - 1) / kTP + kMaxW;
+            if (hi == 0 && cok && l0 < L) hst[(((long)b * K + k) * nta + (s * W + wv)) * D + c] = hin;
+        }
         const unsigned yv = (unsigned)((l0 + 4 * hi) * D + cc_) * (unsigned)sizeof(TY);
         if (cfull && l0 + kTP <= L) {  // wave-uniform: ragged only at the sequence / channel edge
             w.template replay<TY, false>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, true, kTP);
@@ -520,11 +526,11 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
 // a store round trip every step (first version: 83-90 us on the Helix launch, SQ_WAIT_ANY 49 % of wave-cycles; now 77-82).
 #define TRAMBA_LDS_RD_(INSTR, OUT, ADDR, OFF) asm volatile(INSTR " %0, %1 offset:" #OFF : "=v"(OUT) : "v"(ADDR) : "memory")
 
-template <typename T, typename TY, int NK, int R8, int W>
+template <typename T, typename TY, int NK, int R8, int W, bool SAVE = false>
 __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
-    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R)
+    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, float *__restrict__ hst = nullptr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass needs this kernel's launch stub, not its body, and hipcc
                                       // silently drops the stub of a kernel template whose body holds vector-register asm
@@ -675,9 +681,17 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dma(1);                                                    // tile 0 -> my slot, index vector of tile 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (no stores outstanding yet: a counted wait would not wait)
+    // SAVE: the state entering every tile -> hst (see ss2d_scan_cl_kernel); one more store per tile behind the DMAs, issued
+    // for every tile (an out-of-range offset past the sequence end) so that the counted wait stays a constant
+    const long nta = (L + kTP - 1) / kTP + kMaxW;
+    const __amdgpu_buffer_rsrc_t rh =
+        make_rsrc(SAVE ? hst + ((long)b * K + k) * nta * D : nullptr, SAVE ? (unsigned)(nta * D) * 4u : 0u);
     float carry = 0.f;
     for (int s = 0; s < nsuper; ++s) {
-        if (s > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (s > 0) {
+            if constexpr (SAVE) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        }
         TileOps<T, NK> cur;
         float uf[16];
         from_lds(cur, uf);
@@ -704,6 +718,10 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
             h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
         }
         carry = h;
+        if constexpr (SAVE) {
+            const unsigned ho = (hi == 0 && l0 < L) ? (unsigned)((s * W + wv) * D + c) * 4u : kOutOfRange;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hin), rh, ho, 0, 0);
+        }
         w.read_stage4(2, Cp);                                  // C of my 16 positions, read where it is used
         const unsigned yv = (unsigned)((l0 + 4 * hi) * D + c) * (unsigned)sizeof(TY);
         if (l0 + kTP <= L) {  // wave-uniform: ragged only at the sequence end
@@ -735,7 +753,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
     const float *__restrict__ Ds, const TG *__restrict__ gym, T *__restrict__ gu, T *__restrict__ graw,
     float *__restrict__ gB, float *__restrict__ gC, float *__restrict__ gpar, float *__restrict__ hst, int L, int D,
-    int K, int R, int W, int bcs)
+    int K, int R, int W, int bcs, int have_states)
 {
     constexpr int kTS = 36;   // LDS row stride (floats) of the position-sum transposes: 16-byte aligned rows
     __shared__ float agg[2][kMaxW][2][kTP];
@@ -768,7 +786,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
 
     const int span = W * kTP;
     const int nsuper = (L + span - 1) / span;
-    float *hs = hst + ((long)b * K + k) * (long)(nsuper * W) * D;
+    float *hs = hst + ((long)b * K + k) * (long)((L + kTP - 1) / kTP + kMaxW) * D;   // (B, K, NTA, D), tile = position / 32
 
     for (int i = threadIdx.x; i < 2 * kMaxW * kTP; i += blockDim.x) {   // rows of absent waves: identity
         const int bq = i / kTP;
@@ -784,8 +802,8 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
         return tk[l < L ? l : L - 1];
     };
 
-    // ---- sweep 1: the state entering every tile
-    {
+    // ---- sweep 1: the state entering every tile (skipped when the forward launch has saved them, block-uniform)
+    if (!have_states) {
         float carry = 0.f;
         int idx_cur = load_idx(0);
         for (int s = 0; s < nsuper; ++s) {
@@ -845,7 +863,8 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
         w.stage_bc(cur, Bp, Cp, true);
         w.terms(cur, Bp, nvalid, a, bb, uf, tl);
         w.prefix(a, bb, preA, preH, tA, tH);
-        const float hin = hs[(long)(s * W + wv) * D + cc_];
+        // (a tile past the sequence end is all identity elements; its entering state is not among the saved ones)
+        const float hin = l0 < L ? hs[(long)(s * W + wv) * D + cc_] : 0.f;
         // forward replay: h after / before every element
         float hh[16], hp[16];
 #pragma unroll
@@ -1554,13 +1573,48 @@ extern "C" size_t tramba_ss2d_scan_workspace(int batch, int l, int d, int k)
     return (size_t)batch * k * p.nseg * d * (sizeof(float2) + sizeof(float));
 }
 
+// the chained forms, with or without the per-tile states of the training path (saved only where ys is in the input dtype:
+// the discarded branch keeps the other combinations from being instantiated)
+template <typename T, typename TY, int NK, int R8, int W>
+static void launch_scan_dma(dim3 grid, dim3 block, hipStream_t s, const void *x, const float *xdbl, const int32_t *table,
+                            const float *dt_w, const float *dt_bias, const float *A, const float *Ds, void *ys, int l, int d,
+                            int k, int r, float *states)
+{
+    if constexpr (std::is_same<T, TY>::value) {
+        if (states) {
+            hipLaunchKernelGGL((ss2d_scan_dma_kernel<T, TY, NK, R8, W, true>), grid, block, 0, s, (const T *)x, xdbl, table,
+                               dt_w, dt_bias, A, Ds, (TY *)ys, l, d, k, r, states);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((ss2d_scan_dma_kernel<T, TY, NK, R8, W>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, dt_bias, A,
+                       Ds, (TY *)ys, l, d, k, r, (float *)nullptr);
+}
+
+template <typename T, typename TY, int NK, bool SP>
+static void launch_scan_ring(dim3 grid, dim3 block, hipStream_t s, const void *x, const float *xdbl, const int32_t *table,
+                             const float *dt_w, const float *dt_bias, const float *A, const float *Ds, void *ys, int l, int d,
+                             int k, int r, int W, float *states)
+{
+    if constexpr (std::is_same<T, TY>::value) {
+        if (states) {
+            hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK, SP, true>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w,
+                               dt_bias, A, Ds, (TY *)ys, l, d, k, r, W, states);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK, SP>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, dt_bias, A, Ds,
+                       (TY *)ys, l, d, k, r, W, (float *)nullptr);
+}
+
 extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32_t *table,
                                    const float *dt_w, const float *dt_bias, const float *A,
                                    const float *Ds, void *ys, void *workspace, size_t workspace_bytes,
                                    int batch, int l, int d, int k, int r, int dtype, int ys_dtype,
-                                   void *stream)
+                                   float *states, void *stream)
 {
     TRAMBA_CHECK(x && xdbl && table && dt_w && dt_bias && A && Ds && ys, "ss2d_scan_cl: null tensor");
+    TRAMBA_CHECK(!states || ys_dtype == dtype, "ss2d_scan_cl: states are saved by the forms whose ys is in the input dtype");
     TRAMBA_CHECK(batch > 0 && l > 0 && d > 0 && k > 0 && r > 0, "ss2d_scan_cl: empty shape");
     TRAMBA_CHECK(batch <= 65535 && k <= 65535, "ss2d_scan_cl: B or K exceeds grid limits");
     TRAMBA_CHECK(r <= 64, "ss2d_scan_cl: dt_rank %d > 64 unsupported", r);
@@ -1605,8 +1659,9 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     // (A caller that passes no workspace gets the chained form.)
     const bool seg_wins = p.nseg == 1 || ((long)batch * k * ct <= 128 && p.ntiles >= 64);
     const int form_tune = tramba_tune_get(TRAMBA_TUNE_SCAN_FORM);      // 1 = chained, 2 = wave-segment, 3 = chained on LDS-DMA
-    const bool use_seg = workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) &&
-                         (form_tune == 2 || (form_tune == 0 && seg_wins));   // (the LDS-DMA form below is tried first)
+    const bool use_seg = !states && workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) &&
+                         (form_tune == 2 || (form_tune == 0 && seg_wins));   // (the LDS-DMA form below is tried first;
+                                                                             //  the chained forms are the ones that save states)
     // ---- chained form on LDS-DMA staged operands (4 waves per SIMD): 16-bit maps with dt_rank <= 32 whose sequences fill
     //      the chip at 16 or at 8 waves each
     {
@@ -1623,8 +1678,7 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
         if (dma_ok && (scan_tune == 3 || (scan_tune == 0 && seqs * wdma >= 2048 && p.ntiles >= 4 * wdma))) {
             dim3 grid(ct, k, batch), block(wdma * kWave);
 #define DMA_(T, TY, NK_, R8_, W_) \
-    hipLaunchKernelGGL((ss2d_scan_dma_kernel<T, TY, NK_, R8_, W_>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, dt_bias, \
-                       A, Ds, (TY *)ys, l, d, k, r)
+    launch_scan_dma<T, TY, NK_, R8_, W_>(grid, block, s, x, xdbl, table, dt_w, dt_bias, A, Ds, ys, l, d, k, r, states)
 #define DMA_W_(T, TY, NK_, R8_) \
     if (wdma == 16) { DMA_(T, TY, NK_, R8_, 16); } else { DMA_(T, TY, NK_, R8_, 8); }
 #define DMA_R_(T, TY) \
@@ -1676,9 +1730,8 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
         if (W > (l + kTP - 1) / kTP) W = (l + kTP - 1) / kTP;
     }
     dim3 grid(ct, k, batch), block(W * kWave);
-#define GO_(T, TY, NK_, SP_)                                                                               \
-    hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK_, SP_>), grid, block, 0, s, (const T *)x, xdbl, table, \
-                       dt_w, dt_bias, A, Ds, (TY *)ys, l, d, k, r, W)
+#define GO_(T, TY, NK_, SP_) \
+    launch_scan_ring<T, TY, NK_, SP_>(grid, block, s, x, xdbl, table, dt_w, dt_bias, A, Ds, ys, l, d, k, r, W, states)
     BY_DTYPE_(GO_)
 #undef GO_
 #undef BY_DTYPE_
@@ -1697,8 +1750,8 @@ extern "C" size_t tramba_ss2d_scan_bwd_workspace(int batch, int l, int d, int k)
 extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
                                        const float *dt_bias, const float *A, const float *Ds, const void *gym,
                                        void *gu, void *graw, float *gB, float *gC, int bc_stride, float *gpar,
-                                       void *workspace, size_t workspace_bytes, int batch, int l, int d, int k, int r,
-                                       int dtype, int gym_dtype, void *stream)
+                                       void *workspace, size_t workspace_bytes, int have_states, int batch, int l, int d,
+                                       int k, int r, int dtype, int gym_dtype, void *stream)
 {
     TRAMBA_CHECK(bc_stride >= 1, "ss2d_scan_bwd_cl: bc_stride must be >= 1");
     TRAMBA_CHECK(x && xdbl && table && dt_w && dt_bias && A && Ds && gym && gu && graw && gB && gC && gpar && workspace,
@@ -1719,7 +1772,8 @@ extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const i
     dim3 grid(ct, k, batch), block(W * kWave);
 #define BWD_G_(T, NK_, SP_, TG)                                                                                     \
     hipLaunchKernelGGL((ss2d_scan_bwd_cl_kernel<T, NK_, SP_, TG>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, \
-                       dt_bias, A, Ds, (const TG *)gym, (T *)gu, (T *)graw, gB, gC, gpar, (float *)workspace, l, d, k, r, W, bc_stride)
+                       dt_bias, A, Ds, (const TG *)gym, (T *)gu, (T *)graw, gB, gC, gpar, (float *)workspace, l, d, k, r, W, bc_stride, \
+                       have_states)
 #define BWD_(T, NK_, SP_)                                                          \
     if (gym_dtype == TRAMBA_F32) { BWD_G_(T, NK_, SP_, float); } else { BWD_G_(T, NK_, SP_, T); }
 #define BWD_NK_(T, SP_)                \

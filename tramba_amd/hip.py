@@ -46,9 +46,9 @@ SIGNATURES = {
     "tramba_cross_merge": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_ss2d_group_stride": (c_int, [c_int]),
     "tramba_ss2d_scan_workspace": (ctypes.c_size_t, [c_int] * 4),
-    "tramba_ss2d_scan_cl": (c_int, [c_vp] * 9 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
+    "tramba_ss2d_scan_cl": (c_int, [c_vp] * 9 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp, c_vp]),
     "tramba_ss2d_scan_bwd_workspace": (ctypes.c_size_t, [c_int] * 4),
-    "tramba_ss2d_scan_bwd_cl": (c_int, [c_vp] * 12 + [c_int, c_vp, c_vp, ctypes.c_size_t] + [c_int] * 7 + [c_vp]),
+    "tramba_ss2d_scan_bwd_cl": (c_int, [c_vp] * 12 + [c_int, c_vp, c_vp, ctypes.c_size_t] + [c_int] * 8 + [c_vp]),
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_layernorm_bwd_parts": (c_i64, [c_i64, c_int, c_int]),
@@ -339,9 +339,18 @@ def _scan_workspace(device, nbytes):
     return ws
 
 
-def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch.float32, segmented=True):
+def ss2d_scan_states(x, order: ScanOrder):
+    """the buffer ss2d_scan_cl(states=...) fills for ss2d_scan_bwd_cl(states=...): the recurrence state entering every
+    32-position tile, (B, K, ceil(L/32) + 8, D) f32"""
+    b, l, d = x.shape
+    return torch.empty(lib().tramba_ss2d_scan_bwd_workspace(b, l, d, order.k), dtype=torch.uint8, device=x.device)
+
+
+def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch.float32, segmented=True, states=None):
     """x: (B, L, D); xdbl: (B, L, K*RG) f32 -> ys (B, K, L, D).  With `segmented` a workspace is passed and
-    the library picks the wave-segment or the chained form per shape (TRAMBA_SCAN_FORM forces one)."""
+    the library picks the wave-segment or the chained form per shape (TRAMBA_SCAN_FORM forces one).
+    states (training): a buffer from ss2d_scan_states(); the launch saves the per-tile entering states in it (chained forms
+    only, ys in the input dtype), and the backward launch given the same buffer skips its first sweep."""
     _dev(x, xdbl, dt_w, dt_bias, A, Ds)
     b, l, d = x.shape
     k, r = order.k, dt_w.shape[-1]
@@ -355,8 +364,8 @@ def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch
         ws_bytes = lib().tramba_ss2d_scan_workspace(b, l, d, k)
         ws = _scan_workspace(x.device, ws_bytes)
     _check(lib().tramba_ss2d_scan_cl(_ptr(x), _ptr(xdbl), _ptr(order.table), _ptr(dt_w), _ptr(dt_bias), _ptr(A),
-                                     _ptr(Ds), _ptr(ys), _ptr(ws), ws_bytes, b, l, d, k, r, dt(x), dt(ys), _stream()),
-           "ss2d_scan_cl")
+                                     _ptr(Ds), _ptr(ys), _ptr(ws), ws_bytes, b, l, d, k, r, dt(x), dt(ys), _ptr(states),
+                                     _stream()), "ss2d_scan_cl")
     return ys
 
 
@@ -370,11 +379,12 @@ def ss2d_merge_sum_cl(ys, order: ScanOrder, out_dtype):
     return y
 
 
-def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym, g_seq=None):
+def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym, g_seq=None, states=None):
     """Backward of ss2d_scan_cl + merge.  gym (B, L, D) f32 = gradient of the merged map.
     Returns gu, graw (B,K,L,D) x.dtype, gB, gC (B,K,L) f32, gpar (B,3,K,D) f32 (dA, dD, dbias planes).
     g_seq: a ZEROED (B,K,L,RG) f32 x_dbl-gradient table in sequence order -- gB / gC are then accumulated straight into its
-    B / C columns (RG - 4, RG - 3) and returned as views of it."""
+    B / C columns (RG - 4, RG - 3) and returned as views of it.
+    states: the buffer the forward launch filled (ss2d_scan_cl(states=...)): the sweep that recomputes them is skipped."""
     _dev(x, xdbl, dt_w, dt_bias, A, Ds, gym, g_seq)
     b, l, d = x.shape
     k, r = order.k, dt_w.shape[-1]
@@ -393,10 +403,17 @@ def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym, g_seq
         gB, gC, bcs = g_seq[..., rg - 4], g_seq[..., rg - 3], rg
     gpar = torch.empty((b, 3, k, d), dtype=torch.float32, device=x.device)
     ws_bytes = lib().tramba_ss2d_scan_bwd_workspace(b, l, d, k)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    if states is not None:
+        _dev(states)
+        if states.numel() * states.element_size() < ws_bytes:
+            raise TrambaHipError("ss2d_scan_bwd_cl: the states buffer is smaller than ss2d_scan_states() makes it")
+        ws = states
+    else:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     _check(lib().tramba_ss2d_scan_bwd_cl(_ptr(x), _ptr(xdbl), _ptr(order.table), _ptr(dt_w), _ptr(dt_bias), _ptr(A),
                                          _ptr(Ds), _ptr(gym), _ptr(gu), _ptr(graw), _ptr(gB), _ptr(gC), bcs, _ptr(gpar),
-                                         _ptr(ws), ws_bytes, b, l, d, k, r, dt(x), dt(gym), _stream()), "ss2d_scan_bwd_cl")
+                                         _ptr(ws), ws_bytes, 0 if states is None else 1, b, l, d, k, r, dt(x), dt(gym),
+                                         _stream()), "ss2d_scan_bwd_cl")
     return gu, graw, gB, gC, gpar
 
 

@@ -865,14 +865,17 @@ class _SS2DCoreCL(torch.autograd.Function):
         dt_w, dt_bias, a_neg, ds = (t.detach().float().contiguous() for t in (dt_w, dt_bias, a_neg, ds))
         # per-direction outputs and the merged map travel in the activation dtype, as in inference (fp32 in the fp32
         # validation mode): half the bytes of the K-fold intermediate, and out_norm / GELU / their backward run on 2-byte maps
-        ys = hip.ss2d_scan_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, x.dtype)
-        ctx.save_for_backward(x, xdbl, dt_w, dt_bias, a_neg, ds)
+        # the forward launch also writes the state entering every tile: the backward kernel would recompute them in a sweep of
+        # its own (a quarter of its time)
+        states = hip.ss2d_scan_states(x, order)
+        ys = hip.ss2d_scan_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, x.dtype, states=states)
+        ctx.save_for_backward(x, xdbl, dt_w, dt_bias, a_neg, ds, states)
         ctx.order = order
         return hip.ss2d_merge_sum_cl(ys, order, x.dtype)
 
     @staticmethod
     def backward(ctx, gym):
-        x, xdbl, dt_w, dt_bias, a_neg, ds = ctx.saved_tensors
+        x, xdbl, dt_w, dt_bias, a_neg, ds, states = ctx.saved_tensors
         order = ctx.order
         b, l, d = x.shape
         k, r = order.k, dt_w.shape[-1]
@@ -883,7 +886,7 @@ class _SS2DCoreCL(torch.autograd.Function):
             gym = gym.float()
         # (dB / dC stay packed (B,K,L) arrays: accumulating them straight into the RG-strided columns of g_seq -- the
         # kernel can, `bc_stride` -- put every atomic on a cache line of its own and cost the scan backward 30 %)
-        gu, graw, g_b, g_c, gpar = hip.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, gym)
+        gu, graw, g_b, g_c, gpar = hip.ss2d_scan_bwd_cl(x, xdbl, order, dt_w, dt_bias, a_neg, ds, gym, states=states)
         g_seq = torch.zeros((b, k, l, rg), dtype=torch.float32, device=x.device)   # x_dbl-row gradients, sequence order
         gx = hip.ss2d_merge_sum_cl(gu, order, x.dtype)
         # row (l, k) of xdbl viewed as (B, L*K, RG) that sequence position (k, i) reads: table[k][i] * K + k.  One gather
