@@ -257,8 +257,11 @@ int tramba_rows_gemm_cl(const void *x, const void *w, float *y, int nz, int64_t 
 /* The 16-bit copies of a model's fp32 master weights that the next training step reads (the reference keeps fp32 weights
  * and lets autocast cast per call, Trambav6.py:151-154 / train.py:74-89): for every table entry t,
  *   dst[t] (rows, cols) = (dtype) src[t],   dst_t[t] (cols, rows) = its transpose      (either pointer may be 0: skipped)
- * table: DEVICE array of ntensors x 6 int64 {src, dst, dst_t, rows, cols, first_tile}; a tensor owns
- * ceil(rows/64)*ceil(cols/64) consecutive tiles starting at first_tile (ascending), total_tiles = their sum. */
+ * table: DEVICE array of ntensors x 8 int64 {src, dst, dst_t, rows, cols, first_tile, dst_ld, dst_t_ld}; src is a dense
+ * (rows, cols) matrix, the rows of dst / dst_t are dst_ld / dst_t_ld elements apart (= cols / rows for dense outputs;
+ * larger when the matrix is a block of a padded layout, e.g. one direction of the x_proj weight); a tensor owns
+ * ceil(rows/64)*ceil(cols/64) consecutive tiles starting at first_tile (ascending), total_tiles = their sum.  8-byte
+ * alignment of every dst / dst_t row start when the leading dimensions are multiples of 4. */
 int tramba_shadow_cast_multi(const void *table, int ntensors, int64_t total_tiles, int dtype, void *stream);
 /* out[i] = sum over s < nslab of part[s*n + i], i < n, summed in slab order (deterministic): the per-workgroup partial sums
  * of the LayerNorm / depth-wise / scan parameter gradients.  n % 4 == 0, 16-byte aligned. */

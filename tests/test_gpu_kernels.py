@@ -666,13 +666,27 @@ def test_shadow_cast_multi_matches_cast_and_transpose():
         rows, first = [], 0
         for i, (a, b, c) in enumerate(zip(src, dst, dst_t)):
             r, cc = a.shape
-            rows.append([a.data_ptr(), 0 if i == 3 else b.data_ptr(), 0 if i == 4 else c.data_ptr(), r, cc, first])
+            rows.append([a.data_ptr(), 0 if i == 3 else b.data_ptr(), 0 if i == 4 else c.data_ptr(), r, cc, first, cc, r])
             first += ((r + 63) // 64) * ((cc + 63) // 64)
         table = torch.tensor(rows, dtype=torch.int64).to(DEV)
         H.shadow_cast_multi(table, len(rows), first, dtype)
         for i, (a, b, c) in enumerate(zip(src, dst, dst_t)):
             assert torch.equal(b, torch.full_like(b, 7.0) if i == 3 else a.to(dtype)), (i, dtype)
             assert torch.equal(c, torch.full_like(c, 7.0) if i == 4 else a.to(dtype).t()), (i, dtype)
+        # blocks of a padded layout: two (R, D) matrices into rows 0.. and 12.. of a (24, D) buffer, transposes into columns
+        # 0.. and 12.. of a (D, 24) buffer (the x_proj weight of the fused scan)
+        for r_, d_ in ((8, 256), (3, 40)):
+            blocks = [torch.randn(r_, d_, generator=g).to(DEV) for _ in range(2)]
+            pad = torch.zeros(24, d_, dtype=dtype, device=DEV)
+            pad_t = torch.zeros(d_, 24, dtype=dtype, device=DEV)
+            es = pad.element_size()
+            rows2 = [[blk.data_ptr(), pad.data_ptr() + 12 * j * d_ * es, pad_t.data_ptr() + 12 * j * es, r_, d_, j * ((d_ + 63) // 64),
+                      d_, 24] for j, blk in enumerate(blocks)]
+            H.shadow_cast_multi(torch.tensor(rows2, dtype=torch.int64).to(DEV), 2, 2 * ((d_ + 63) // 64), dtype)
+            want = torch.zeros(24, d_, dtype=dtype, device=DEV)
+            for j, blk in enumerate(blocks):
+                want[12 * j:12 * j + r_] = blk.to(dtype)
+            assert torch.equal(pad, want) and torch.equal(pad_t, want.t()), (r_, d_, dtype)
 
 
 # ----------------------------------------------------------------------------- training-path GEMMs (train_gemm.hip)

@@ -488,6 +488,15 @@ def test_training_weight_shadows_follow_the_optimizer():
             assert wt is not None and wt.shape == (w16.shape[1], w16.shape[0]) and torch.equal(wt, w16.t())
             nlin += 1
     assert nlin > 100
+    # every fused SS2D core: the padded (K*RG, D) x_proj weight the scan kernels read, and its transpose
+    nss = 0
+    for mod in m.modules():
+        if isinstance(mod, ta.SS2D):
+            ent = M._lowp_shadow[id(mod.x_proj_weight)]
+            want = ta.hip.pad_x_proj_weight(mod.x_proj_weight.detach().to(torch.bfloat16)).contiguous()
+            assert ent[1] == mod.x_proj_weight._version and torch.equal(ent[0], want) and torch.equal(ent[3], want.t())
+            nss += 1
+    assert nss > 20
     with torch.no_grad():
         lin.weight.mul_(0.5)                                                        # out-of-band update: version moves on
     fresh = M._lowp(lin.weight, torch.bfloat16)

@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ 
     }
 }
 
-// ---- multi-tensor cast (+ transpose) of fp32 matrices: table[t] = {src, dst, dst_t, rows, cols, first_tile} (int64 each)
+// ---- multi-tensor cast (+ transpose) of fp32 matrices: table[t] = {src, dst, dst_t, rows, cols, first_tile, dst_ld,
+//      dst_t_ld} (int64 each); src is dense (rows, cols), dst rows are dst_ld apart, dst_t rows dst_t_ld apart
 constexpr int kShadowTile = 64;
 
 template <typename T>
@@ -324,18 +325,19 @@ __global__ __launch_bounds__(256) void shadow_cast_multi_kernel(const long *__re
     int lo = 0, hi = ntensors - 1;                  // last tensor whose first tile is <= tileid
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (table[(long)mid * 6 + 5] <= tileid) lo = mid; else hi = mid - 1;
+        if (table[(long)mid * 8 + 5] <= tileid) lo = mid; else hi = mid - 1;
     }
-    const long *e = table + (long)lo * 6;
+    const long *e = table + (long)lo * 8;
     const float *src = reinterpret_cast<const float *>(e[0]);
     T *dst = reinterpret_cast<T *>(e[1]);
     T *dst_t = reinterpret_cast<T *>(e[2]);
-    const long rows = e[3], cols = e[4];
+    const long rows = e[3], cols = e[4], ld = e[6], ld_t = e[7];
     const long local = tileid - e[5];
     const long tiles_c = (cols + kShadowTile - 1) / kShadowTile;
     const long r0 = (local / tiles_c) * kShadowTile, c0 = (local % tiles_c) * kShadowTile;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const bool vec = (cols & 3) == 0;               // 16-byte loads / 8-byte stores of whole quads
+    const bool vec = (cols & 3) == 0;               // 16-byte loads of whole quads
+    const bool vec_d = vec && (ld & 3) == 0;        // 8-byte stores
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long r = r0 + ty + 16 * i, c = c0 + 4 * tx;
@@ -357,18 +359,18 @@ __global__ __launch_bounds__(256) void shadow_cast_multi_kernel(const long *__re
             tile[ty + 16 * i][4 * tx + j] = o[j];
         }
         if (dst && r < rows) {
-            if (vec && c + 4 <= cols) {
-                *reinterpret_cast<uint2 *>(dst + r * cols + c) = *reinterpret_cast<const uint2 *>(o);
+            if (vec_d && c + 4 <= cols) {
+                *reinterpret_cast<uint2 *>(dst + r * ld + c) = *reinterpret_cast<const uint2 *>(o);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (c + j < cols) dst[r * cols + c + j] = o[j];
+                    if (c + j < cols) dst[r * ld + c + j] = o[j];
             }
         }
     }
     if (!dst_t) return;                              // (uniform over the block)
     __syncthreads();
-    const bool vec_t = (rows & 3) == 0;
+    const bool vec_t = (rows & 3) == 0 && (ld_t & 3) == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long c = c0 + ty + 16 * i, r = r0 + 4 * tx;   // output row = source column
@@ -377,11 +379,11 @@ __global__ __launch_bounds__(256) void shadow_cast_multi_kernel(const long *__re
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = tile[4 * tx + j][ty + 16 * i];
         if (vec_t && r + 4 <= rows) {
-            *reinterpret_cast<uint2 *>(dst_t + c * rows + r) = *reinterpret_cast<const uint2 *>(o);
+            *reinterpret_cast<uint2 *>(dst_t + c * ld_t + r) = *reinterpret_cast<const uint2 *>(o);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (r + j < rows) dst_t[c * rows + r + j] = o[j];
+                if (r + j < rows) dst_t[c * ld_t + r + j] = o[j];
         }
     }
 }

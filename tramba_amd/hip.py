@@ -697,11 +697,12 @@ def slab_sum(part):
 
 
 def shadow_cast_multi(table, ntensors, total_tiles, dtype):
-    """One launch over a device-resident table (ntensors, 6) int64 {src f32, dst, dst_t, rows, cols, first_tile}: every
-    dst = src cast to `dtype`, every dst_t = its transpose (tramba_amd.modules.refresh_lowp_shadows builds the table)."""
+    """One launch over a device-resident table (ntensors, 8) int64 {src f32, dst, dst_t, rows, cols, first_tile, dst_ld,
+    dst_t_ld}: every dst = src cast to `dtype`, every dst_t = its transpose, with leading dimensions (blocks of padded
+    layouts); tramba_amd.modules.refresh_lowp_shadows builds the table."""
     _dev(table)
-    if table.dtype != torch.int64 or table.shape != (ntensors, 6) or not table.is_contiguous():
-        raise TrambaHipError("shadow_cast_multi: table must be a contiguous (ntensors, 6) int64 tensor")
+    if table.dtype != torch.int64 or table.shape != (ntensors, 8) or not table.is_contiguous():
+        raise TrambaHipError("shadow_cast_multi: table must be a contiguous (ntensors, 8) int64 tensor")
     _check(lib().tramba_shadow_cast_multi(_ptr(table), ntensors, total_tiles, _DT[dtype], _stream()), "shadow_cast_multi")
 
 

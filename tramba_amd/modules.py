@@ -310,8 +310,16 @@ _lowp_shadow = {}        # id(p) -> [shadow, version, weakref(p), shadow_t or No
 
 
 def _shadow_params(model):
-    return [p for m in model.modules() if isinstance(m, Linear2d) for p in (m.weight,)
-            if p is not None and p.is_cuda and p.dtype == torch.float32 and p.dim() == 2]
+    """[(parameter, dt_rank or None)]: the Linear2d weights, and the x_proj weights of the SS2D cores that can take the fused
+    training path (their shadow is the padded (K*RG, D) layout the kernels read, see _XProjCL)"""
+    out = [(m.weight, None) for m in model.modules() if isinstance(m, Linear2d)
+           if m.weight is not None and m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.dim() == 2]
+    for m in model.modules():
+        if isinstance(m, SS2D):
+            p = m.x_proj_weight
+            if p.is_cuda and p.dtype == torch.float32 and p.dim() == 3 and p.shape[1] == m.dt_rank + 2:
+                out.append((p, m.dt_rank))
+    return out
 
 
 @torch.no_grad()
@@ -323,28 +331,49 @@ def refresh_lowp_shadows(model, dtype):
     params = plan[5] if plan is not None else _shadow_params(model)
     if not params:
         return 0
-    sig = (dtype,) + tuple((p.data_ptr(), tuple(p.shape)) for p in params)
+    sig = (dtype,) + tuple((p.data_ptr(), tuple(p.shape)) for p, _ in params)
     if plan is None or plan[0] != sig:
         params = _shadow_params(model)
-        sig = (dtype,) + tuple((p.data_ptr(), tuple(p.shape)) for p in params)
+        sig = (dtype,) + tuple((p.data_ptr(), tuple(p.shape)) for p, _ in params)
         for key in [k for k, ent in _lowp_shadow.items() if ent[2]() is None]:   # parameters of models that no longer exist
             del _lowp_shadow[key]
         rows, first = [], 0
-        for p in params:
-            ent = _lowp_shadow.get(id(p))
-            if (ent is None or ent[0].dtype != dtype or ent[0].shape != p.shape or ent[0].device != p.device
-                    or ent[2]() is not p or ent[3] is None):
-                ent = [torch.empty_like(p, dtype=dtype), -1, weakref.ref(p),
-                       torch.empty((p.shape[1], p.shape[0]), dtype=dtype, device=p.device)]
-                _lowp_shadow[id(p)] = ent
-            n, k = p.shape
-            rows.append([p.data_ptr(), ent[0].data_ptr(), ent[3].data_ptr(), n, k, first])
+        es = torch.empty((), dtype=dtype).element_size()
+
+        def entry(src, dst, dst_t, n, k, ld, ld_t):
+            nonlocal first
+            rows.append([src, dst, dst_t, n, k, first, ld, ld_t])
             first += ((n + 63) // 64) * ((k + 63) // 64)
-        table = torch.tensor(rows, dtype=torch.int64).to(params[0].device)
+
+        for p, r in params:
+            ent = _lowp_shadow.get(id(p))
+            if r is None:      # Linear2d weight (N, K): W and W^T
+                n, k = p.shape
+                if (ent is None or ent[0].dtype != dtype or ent[0].shape != p.shape or ent[0].device != p.device
+                        or ent[2]() is not p or ent[3] is None):
+                    ent = [torch.empty_like(p, dtype=dtype), -1, weakref.ref(p),
+                           torch.empty((k, n), dtype=dtype, device=p.device)]
+                    _lowp_shadow[id(p)] = ent
+                entry(p.data_ptr(), ent[0].data_ptr(), ent[3].data_ptr(), n, k, k, n)
+            else:              # x_proj weight (K, R + 2, D) -> padded (K*RG, D) [R ranks, 0-pad, B, C, 2 pad] and its transpose
+                kk, _, d = p.shape
+                rg = hip.ss2d_group_stride(r)
+                r8 = rg - 4
+                if (ent is None or ent[0].dtype != dtype or ent[0].shape != (kk * rg, d) or ent[0].device != p.device
+                        or ent[2]() is not p or ent[3] is None):
+                    ent = [torch.zeros((kk * rg, d), dtype=dtype, device=p.device), -1, weakref.ref(p),
+                           torch.zeros((d, kk * rg), dtype=dtype, device=p.device)]      # the pad rows stay zero for good
+                    _lowp_shadow[id(p)] = ent
+                for g in range(kk):
+                    src = p.data_ptr() + g * (r + 2) * d * 4
+                    entry(src, ent[0].data_ptr() + g * rg * d * es, ent[3].data_ptr() + g * rg * es, r, d, d, kk * rg)
+                    entry(src + r * d * 4, ent[0].data_ptr() + (g * rg + r8) * d * es, ent[3].data_ptr() + (g * rg + r8) * es,
+                          2, d, d, kk * rg)
+        table = torch.tensor(rows, dtype=torch.int64).to(params[0][0].device)
         plan = (sig, table, len(rows), first, dtype, params)
         model.__dict__["_tramba_shadow_plan"] = plan
     hip.shadow_cast_multi(plan[1], plan[2], plan[3], dtype)
-    for p in params:
+    for p, _ in params:
         _lowp_shadow[id(p)][1] = p._version
     return len(params)
 
@@ -353,10 +382,11 @@ def restamp_lowp_shadows(model):
     """Declare the shadows of `model`'s parameters current (after a hipGraph replay that refreshed them itself and a
     version bump of the parameters: tramba_amd.graph.GraphedTrainStep)."""
     for m in model.modules():
-        if isinstance(m, Linear2d):
-            ent = _lowp_shadow.get(id(m.weight))
-            if ent is not None and ent[2]() is m.weight:
-                ent[1] = m.weight._version
+        p = m.weight if isinstance(m, Linear2d) else (m.x_proj_weight if isinstance(m, SS2D) else None)
+        if p is not None:
+            ent = _lowp_shadow.get(id(p))
+            if ent is not None and ent[2]() is p:
+                ent[1] = p._version
 
 
 def _lowp(p, dtype):
@@ -828,12 +858,17 @@ class _XProjCL(torch.autograd.Function):
         k, r2, d = w.shape
         r = r2 - 2
         rg = hip.ss2d_group_stride(r)
-        wl = w.detach().to(x.dtype)
-        parts = [wl[:, :r]]
-        if rg - 4 - r:
-            parts.append(_zeros_const((k, rg - 4 - r, d), x.dtype, x.device))
-        parts += [wl[:, r:], _zeros_const((k, 2, d), x.dtype, x.device)]
-        wa = torch.cat(parts, dim=1).view(k * rg, d)
+        ent = _lowp_shadow.get(id(w))
+        if (ent is not None and ent[1] == w._version and ent[0].dtype == x.dtype and ent[2]() is w
+                and ent[0].shape == (k * rg, d)):
+            wa, ctx.wa_t = ent[0], ent[3]       # padded weight and its transpose, written after the optimizer step
+        else:
+            wl = w.detach().to(x.dtype)
+            parts = [wl[:, :r]]
+            if rg - 4 - r:
+                parts.append(_zeros_const((k, rg - 4 - r, d), x.dtype, x.device))
+            parts += [wl[:, r:], _zeros_const((k, 2, d), x.dtype, x.device)]
+            wa, ctx.wa_t = torch.cat(parts, dim=1).view(k * rg, d), None
         ctx.save_for_backward(x, wa)
         ctx.meta = (w.dtype, k, r, rg)
         return hip.linear_cl(x.contiguous(), wa, out_dtype=torch.float32)
@@ -843,7 +878,7 @@ class _XProjCL(torch.autograd.Function):
         x, wa = ctx.saved_tensors
         wdtype, k, r, rg = ctx.meta
         ga = g.to(x.dtype).reshape(-1, g.shape[-1]).contiguous()
-        gx = _dgrad(ga, wa).view(x.shape) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(ga, wa, ctx.wa_t).view(x.shape) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
             gp = _wgrad(ga, x.reshape(-1, x.shape[-1]))[0].view(k, rg, -1)
