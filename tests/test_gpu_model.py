@@ -462,6 +462,59 @@ def test_tramba_v_768_fp16_long_sequence_against_oracle():
     assert abs(mae(got16) - mae(want)) < 5e-4
 
 
+def test_tramba_v_train_step_at_the_baseline_batch():
+    """BASELINE config 3 at ITS batch size (8 per GPU, bf16): the loss and the gradients of the batch equal the mean of its
+    two halves run on their own (images are independent; the scan kernels pick other schedules at batch 8 than at 4), and
+    the full optimisation step runs."""
+    import tramba_amd as ta
+    from tramba_amd import train
+    torch.manual_seed(0)
+    m = ta.bulid_model(use_pretrain=False, img_size=384).to(DEV).train()
+    for mod in m.modules():
+        if isinstance(mod, ta.DropPath):
+            mod.drop_prob = 0.0
+    m.compute_dtype = torch.bfloat16
+    x = torch.randn(8, 3, 384, 384, generator=torch.Generator().manual_seed(0)).to(DEV)
+    y = (torch.rand(8, 1, 384, 384, generator=torch.Generator().manual_seed(1)) > 0.7).float().to(DEV)
+    probes = [p for n, p in m.named_parameters() if p.numel() >= 65536][::12] + [p for n, p in m.named_parameters() if "A_logs" in n][:3]
+
+    def run(xs, ys):
+        for p in m.parameters():
+            p.grad = None
+        loss = train.tramba_loss(m(xs), ys)
+        loss.backward()
+        return float(loss.detach()), [p.grad.detach().double().clone() for p in probes]
+
+    l8, g8 = run(x, y)
+    la, ga = run(x[:4], y[:4])
+    lb, gb = run(x[4:], y[4:])
+    assert abs(l8 - 0.5 * (la + lb)) <= 2e-3 * abs(l8), (l8, la, lb)
+    for g, a, b in zip(g8, ga, gb):
+        want = 0.5 * (a + b)
+        cos = float((g * want).sum() / (g.norm() * want.norm() + 1e-30))
+        assert cos > 0.995 and 0.97 < float(g.norm() / want.norm()) < 1.03, (cos, float(g.norm() / want.norm()))
+    opt = train.get_opt(1e-4, m)
+    losses = [float(train.train_step(m, opt, x, y)) for _ in range(2)]
+    assert np.isfinite(losses).all()       # (Adam's first steps on random-init weights need not lower the loss)
+
+
+def test_tramba_v_768_fp16_at_the_baseline_batch():
+    """BASELINE config 5 at ITS batch size (2): every image of the fp16 768x768 batch equals the same image run alone, to
+    fp16 rounding (the kernels may pick another schedule for the larger launch)."""
+    import tramba_amd as ta
+    m = ta.prepare_inference(_load_synth(ta.bulid_model(deep_supervision=True, use_pretrain=False, img_size=768)), torch.float16)
+    x = torch.cat([synth.synth_input("c5", (1, 3, 768, 768)), synth.synth_input("c5b", (1, 3, 768, 768))]).to(DEV)
+    with torch.no_grad():
+        both = m(x)
+        alone = [m(x[i:i + 1]) for i in range(2)]
+    for j, o in enumerate(both):
+        for i in range(2):
+            ref = alone[i][j][0].float()
+            scale = float(ref.abs().max())
+            assert float((o[i].float() - ref).abs().max()) <= 2e-2 * scale + 1e-3, (j, i)
+            assert float(((o[i] > 0) != (alone[i][j][0] > 0)).float().mean()) < 2e-3   # saliency decisions
+
+
 def test_training_weight_shadows_follow_the_optimizer():
     """train_step refreshes the bf16 shadows of the fp32 Linear2d weights with one fused cast; a shadow is used only while
     its parameter is unchanged (version counter), so an out-of-band update falls back to a fresh cast."""
