@@ -941,11 +941,9 @@ __global__ __launch_bounds__(256) void linear_dma_kernel(const T *__restrict__ x
 }
 #undef TRAMBA_DSR128_
 
-// Tile choice: 64x64 (3 K-tiles in flight) wins on every GEMM of this model (M = 576..36864, N <= 4096,
-// K <= 4096: short-M or short-K, measured in scripts/bench_gemm.py); 128x128 only pays once both the tile
-// count and K are large.  TRAMBA_GEMM_TILE=128x128 forces it (tuning aid).
-// 96x64 tiles where 64x64 tiles land just above a whole number of rounds of the 256 CUs and 96-row tiles land at or under
-// it (M = 2304, N = 512: 288 -> 192 workgroups).  TRAMBA_GEMM_TILE=96x64 forces it for every eligible shape, =64x64 forbids.
+// Tile / staging choice: see launch_tiled.  tile96(): where a 96x64 tile (3 compute waves + 1 loader wave) lands at or
+// under a whole number of rounds of the 256 CUs and 64x64 tiles land just above it (M = 2304, N = 512: 288 -> 192
+// workgroups); a measurement form since r02 (tramba_tune_set(TRAMBA_TUNE_GEMM_TILE, 4)).
 static bool tile96(long m, int n, int k)
 {
     if (m < 96) return false;

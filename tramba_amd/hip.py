@@ -348,7 +348,7 @@ def ss2d_scan_states(x, order: ScanOrder):
 
 def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch.float32, segmented=True, states=None):
     """x: (B, L, D); xdbl: (B, L, K*RG) f32 -> ys (B, K, L, D).  With `segmented` a workspace is passed and
-    the library picks the wave-segment or the chained form per shape (TRAMBA_SCAN_FORM forces one).
+    the library picks the wave-segment or a chained form per shape (tune_set(TUNE_SCAN_FORM, ...) forces one).
     states (training): a buffer from ss2d_scan_states(); the launch saves the per-tile entering states in it (chained forms
     only, ys in the input dtype), and the backward launch given the same buffer skips its first sweep."""
     _dev(x, xdbl, dt_w, dt_bias, A, Ds)
