@@ -121,7 +121,8 @@ int tramba_selective_scan_fwd(const void *u, const void *delta, const float *A, 
                               int out_dtype, int delta_softplus, void *stream);
 /* du, ddelta: (B, KD, L) io_dtype; dA (KD,N), dD, ddelta_bias (KD): f32, ACCUMULATED into
  * (caller zeroes);  dB, dC: (ncopy, B, K, N, L) f32, accumulated into (caller zeroes) -- the rows of a
- * direction group spread their atomic adds over `ncopy` private copies which the caller sums. */
+ * direction group spread their atomic adds over `ncopy` private copies which the caller sums.
+ * Both directions: d_state N = 1 (everything Tramba builds), 2 and 4. */
 int tramba_selective_scan_bwd(const void *u, const void *delta, const float *A, const void *Bm,
                               const void *Cm, const float *D, const float *delta_bias,
                               const float *dout, const float *ckpt, void *du, void *ddelta,

@@ -58,10 +58,13 @@ def test_selective_scan_fwd(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 4, 8, 144), (1, 4, 6, 576), (1, 2, 3, 1000), (1, 8, 2, 2304), (1, 1, 5, 37)])
+@pytest.mark.parametrize("shape", [(2, 4, 8, 1, 144), (1, 4, 6, 1, 576), (1, 2, 3, 1, 1000), (1, 8, 2, 1, 2304), (1, 1, 5, 1, 37),
+                                   (2, 2, 3, 2, 200), (1, 2, 2, 4, 64), (1, 4, 4, 4, 1153), (2, 1, 8, 2, 2304)])
 def test_selective_scan_bwd(dtype, shape):
-    nb, k, dper, l = shape
-    a = _scan_inputs(nb, k, dper, 1, l, dtype, seed=3)
+    """every gradient of selective_scan_cuda_oflex.bwd (csms6s.py:920-922) against the fp64 oracle, d_state 1, 2 and 4
+    (dA (KD, N), dB / dC (B, K, N, L)), ragged and unaligned lengths"""
+    nb, k, dper, n, l = shape
+    a = _scan_inputs(nb, k, dper, n, l, dtype, seed=3)
     dout = torch.randn(nb, k * dper, l, generator=torch.Generator().manual_seed(9))
     f = lambda t: t.float()
     want = oss.selective_scan_bwd(f(a["u"]), f(a["delta"]), a["A"], f(a["B"]), f(a["C"]), a["D"], a["delta_bias"], dout, True)

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_fwd_ker
 }
 
 // ------------------------------------------------------------------------------------ backward
-// Adjoint of the recurrence (N = 1).  With g_l = dLoss/dh_l:
+// Adjoint of the recurrence, per state component n (N = 1, 2, 4 instantiated).  With g_l = dLoss/dh_l:
 //     g_l      = C_l dout_l + a_{l+1} g_{l+1}                      (right-to-left scan)
 //     d dt_l   = g_l (h_{l-1} a_l A + B_l u_l)        d u_l = dout_l D + g_l dt_l B_l
 //     dB_l    += g_l dt_l u_l   dC_l += dout_l h_l    dA += g_l h_{l-1} a_l dt_l   dD += dout_l u_l
@@ -269,7 +269,7 @@ __device__ __forceinline__ float row_sum(float v)
     return v;
 }
 
-template <typename T, int LPR>
+template <typename T, int LPR, int N>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_kernel(
     const T *__restrict__ u, const T *__restrict__ delta, const float *__restrict__ A,
     const T *__restrict__ Bm, const T *__restrict__ Cm, const float *__restrict__ Dskip,
@@ -278,6 +278,8 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_ker
     float *__restrict__ dC, float *__restrict__ dD, float *__restrict__ ddbias, int rows_total, int kd,
     int K, int L, int nchunk, int softplus, int vec_ok, int ncopy, long copy_stride)
 {
+    // N state components per row (d_state): the recurrences are independent, the gradients of u and delta sum over them;
+    // B, C (B, K, N, L), A (KD, N), the forward's checkpoints (rows, nchunk, N).
     constexpr int RPW = kWave / LPR;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -291,13 +293,15 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_ker
     const T *ur = u + rrow * L;
     const T *dr = delta + rrow * L;
     const float *gr = dout + rrow * L;
-    const long bc = ((long)b * K + k) * L;
+    const long bc = ((long)b * K + k) * N * L;
     const T *Br = Bm + bc;
     const T *Cr = Cm + bc;
     // dB/dC are shared by the KD/K rows of a group: spread the adds over `ncopy` private copies
     // (summed by the caller) so that KD/K/ncopy, not KD/K, rows contend for one address
     const long pc = (long)(d % ncopy) * copy_stride;
-    const float An = A[d];
+    float An[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) An[n] = A[(long)d * N + n];
     const float bias = dbias ? dbias[d] : 0.f;
     const float skip = Dskip ? Dskip[d] : 0.f;
 
@@ -307,18 +311,21 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_ker
     __shared__ float tr[kWavesPerBlock][2][kWave * kE];
     float *trB = tr[threadIdx.x >> 6][0], *trC = tr[threadIdx.x >> 6][1];
 
-    float g_carry = 0.f;   // g of the first element of the chunk to the right
-    float a_carry = 1.f;   // a of that element
-    float accA = 0.f, accD = 0.f, accBias = 0.f;
+    float g_carry[N], a_carry[N], accA[N];   // g / a of the first element of the chunk to the right, per component
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        g_carry[n] = 0.f;
+        a_carry[n] = 1.f;
+        accA[n] = 0.f;
+    }
+    float accD = 0.f, accBias = 0.f;
 
     for (int chunk = nchunk - 1; chunk >= 0; --chunk) {
         const int l0 = chunk * (LPR * kE) + sub * kE;
-        float cu[kE], cd[kE], cB[kE], cC[kE], go[kE];
+        float cu[kE], cd[kE], go[kE];
         if (vec_ok && l0 + kE <= L) {
             load_pack<T, kE>(ur + l0, cu);
             load_pack<T, kE>(dr + l0, cd);
-            load_pack<T, kE>(Br + l0, cB);
-            load_pack<T, kE>(Cr + l0, cC);
             load_pack<float, kE>(gr + l0, go);
         } else {
 #pragma unroll
@@ -326,92 +333,114 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_ker
                 const bool ok = l0 + j < L;
                 cu[j] = ok ? Cvt<T>::to_f(ur[l0 + j]) : 0.f;
                 cd[j] = ok ? Cvt<T>::to_f(dr[l0 + j]) : 0.f;
-                cB[j] = ok ? Cvt<T>::to_f(Br[l0 + j]) : 0.f;
-                cC[j] = ok ? Cvt<T>::to_f(Cr[l0 + j]) : 0.f;
                 go[j] = ok ? gr[l0 + j] : 0.f;
             }
         }
-        float dt[kE], raw[kE], a[kE], bb[kE];
-        float pa = 1.f, ph = 0.f;
+        float dt[kE], raw[kE], odu[kE], ddt[kE];
 #pragma unroll
         for (int j = 0; j < kE; ++j) {
             raw[j] = cd[j] + bias;
             dt[j] = softplus ? softplus20(raw[j]) : raw[j];
             if (l0 + j >= L) dt[j] = 0.f;
-            a[j] = __expf(dt[j] * An);
-            bb[j] = dt[j] * cB[j] * cu[j];
-            ph = fmaf(a[j], ph, bb[j]);
-            pa *= a[j];
-        }
-        // forward replay from the checkpoint: state entering this lane
-        row_scan<LPR>(pa, ph, sub);
-        float ea = __shfl_up(pa, 1, LPR), eh = __shfl_up(ph, 1, LPR);
-        if (sub == 0) { ea = 1.f; eh = 0.f; }
-        const float hstart = chunk > 0 ? ckpt[rrow * nchunk + chunk - 1] : 0.f;
-        float h = fmaf(ea, hstart, eh);
-        float hprev[kE], hcur[kE];
-#pragma unroll
-        for (int j = 0; j < kE; ++j) {
-            hprev[j] = h;
-            h = fmaf(a[j], h, bb[j]);
-            hcur[j] = h;
-        }
-        // adjoint scan: element j carries (a_{j+1}, C_j dout_j)
-        float a_right = __shfl_down(a[0], 1, LPR);          // first a of the lane to the right
-        if (sub == LPR - 1) a_right = a_carry;
-        float an[kE], cg[kE];
-#pragma unroll
-        for (int j = 0; j < kE; ++j) {
-            an[j] = j + 1 < kE ? a[j + 1] : a_right;
-            cg[j] = cC[j] * go[j];
-        }
-        float qa = 1.f, qg = 0.f;
-#pragma unroll
-        for (int j = kE - 1; j >= 0; --j) {
-            qg = fmaf(an[j], qg, cg[j]);
-            qa *= an[j];
-        }
-        row_scan_rev<LPR>(qa, qg, sub);
-        float xa = __shfl_down(qa, 1, LPR), xg = __shfl_down(qg, 1, LPR);   // exclusive suffix
-        if (sub == LPR - 1) { xa = 1.f; xg = 0.f; }
-        float g = fmaf(xa, g_carry, xg);
-        // carries for the chunk to the left: full-row suffix applied to the old carry
-        const float fa = __shfl(qa, 0, LPR), fg = __shfl(qg, 0, LPR);
-        g_carry = fmaf(fa, g_carry, fg);
-        a_carry = __shfl(a[0], 0, LPR);
-
-        float odu[kE], odd[kE];
-#pragma unroll
-        for (int j = kE - 1; j >= 0; --j) {
-            g = fmaf(an[j], g, cg[j]);                       // g_j
-            const bool ok = l0 + j < L;
-            const float ddt = g * fmaf(hprev[j] * a[j], An, cB[j] * cu[j]);
-            odu[j] = fmaf(go[j], skip, g * dt[j] * cB[j]);
-            float dr_ = ddt;
-            if (softplus && raw[j] <= 20.f) dr_ = ddt * sigmoidf_(raw[j]);
-            odd[j] = ok ? dr_ : 0.f;
-            accA = fmaf(g * hprev[j], a[j] * dt[j], accA);
+            odu[j] = go[j] * skip;
+            ddt[j] = 0.f;
             accD = fmaf(go[j], cu[j], accD);
-            accBias += odd[j];
-            trB[lane * kE + j] = ok ? g * dt[j] * cu[j] : 0.f;
-            trC[lane * kE + j] = ok ? go[j] * hcur[j] : 0.f;
         }
-        __builtin_amdgcn_wave_barrier();
-        if (row_ok) {
-            // lane i, step j -> element (lane/LPR)*LPR*kE + j*LPR + sub of the wave's staging area, i.e.
-            // position chunk*LPR*kE + j*LPR + sub of the row: consecutive lanes, consecutive addresses
-            const int rbase = (lane / LPR) * (LPR * kE);
 #pragma unroll
-            for (int j = 0; j < kE; ++j) {
-                const int e = j * LPR + sub;
-                const int l = chunk * (LPR * kE) + e;
-                if (l < L) {
-                    atomicAdd(dB + pc + bc + l, trB[rbase + e]);
-                    atomicAdd(dC + pc + bc + l, trC[rbase + e]);
+        for (int n = 0; n < N; ++n) {
+            float cB[kE], cC[kE];
+            if (vec_ok && l0 + kE <= L) {
+                load_pack<T, kE>(Br + (long)n * L + l0, cB);
+                load_pack<T, kE>(Cr + (long)n * L + l0, cC);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kE; ++j) {
+                    const bool ok = l0 + j < L;
+                    cB[j] = ok ? Cvt<T>::to_f(Br[(long)n * L + l0 + j]) : 0.f;
+                    cC[j] = ok ? Cvt<T>::to_f(Cr[(long)n * L + l0 + j]) : 0.f;
                 }
             }
+            float a[kE], bb[kE];
+            float pa = 1.f, ph = 0.f;
+#pragma unroll
+            for (int j = 0; j < kE; ++j) {
+                a[j] = __expf(dt[j] * An[n]);
+                bb[j] = dt[j] * cB[j] * cu[j];
+                ph = fmaf(a[j], ph, bb[j]);
+                pa *= a[j];
+            }
+            // forward replay from the checkpoint: state entering this lane
+            row_scan<LPR>(pa, ph, sub);
+            float ea = __shfl_up(pa, 1, LPR), eh = __shfl_up(ph, 1, LPR);
+            if (sub == 0) { ea = 1.f; eh = 0.f; }
+            const float hstart = chunk > 0 ? ckpt[(rrow * nchunk + chunk - 1) * N + n] : 0.f;
+            float h = fmaf(ea, hstart, eh);
+            float hprev[kE], hcur[kE];
+#pragma unroll
+            for (int j = 0; j < kE; ++j) {
+                hprev[j] = h;
+                h = fmaf(a[j], h, bb[j]);
+                hcur[j] = h;
+            }
+            // adjoint scan: element j carries (a_{j+1}, C_j dout_j)
+            float a_right = __shfl_down(a[0], 1, LPR);          // first a of the lane to the right
+            if (sub == LPR - 1) a_right = a_carry[n];
+            float an[kE], cg[kE];
+#pragma unroll
+            for (int j = 0; j < kE; ++j) {
+                an[j] = j + 1 < kE ? a[j + 1] : a_right;
+                cg[j] = cC[j] * go[j];
+            }
+            float qa = 1.f, qg = 0.f;
+#pragma unroll
+            for (int j = kE - 1; j >= 0; --j) {
+                qg = fmaf(an[j], qg, cg[j]);
+                qa *= an[j];
+            }
+            row_scan_rev<LPR>(qa, qg, sub);
+            float xa = __shfl_down(qa, 1, LPR), xg = __shfl_down(qg, 1, LPR);   // exclusive suffix
+            if (sub == LPR - 1) { xa = 1.f; xg = 0.f; }
+            float g = fmaf(xa, g_carry[n], xg);
+            // carries for the chunk to the left: full-row suffix applied to the old carry
+            const float fa = __shfl(qa, 0, LPR), fg = __shfl(qg, 0, LPR);
+            g_carry[n] = fmaf(fa, g_carry[n], fg);
+            a_carry[n] = __shfl(a[0], 0, LPR);
+
+#pragma unroll
+            for (int j = kE - 1; j >= 0; --j) {
+                g = fmaf(an[j], g, cg[j]);                       // g_j
+                const bool ok = l0 + j < L;
+                ddt[j] = fmaf(g, fmaf(hprev[j] * a[j], An[n], cB[j] * cu[j]), ddt[j]);
+                odu[j] = fmaf(g * dt[j], cB[j], odu[j]);
+                accA[n] = fmaf(g * hprev[j], a[j] * dt[j], accA[n]);
+                trB[lane * kE + j] = ok ? g * dt[j] * cu[j] : 0.f;
+                trC[lane * kE + j] = ok ? go[j] * hcur[j] : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (row_ok) {
+                // lane i, step j -> element (lane/LPR)*LPR*kE + j*LPR + sub of the wave's staging area, i.e.
+                // position chunk*LPR*kE + j*LPR + sub of the row: consecutive lanes, consecutive addresses
+                const int rbase = (lane / LPR) * (LPR * kE);
+#pragma unroll
+                for (int j = 0; j < kE; ++j) {
+                    const int e = j * LPR + sub;
+                    const int l = chunk * (LPR * kE) + e;
+                    if (l < L) {
+                        atomicAdd(dB + pc + bc + (long)n * L + l, trB[rbase + e]);
+                        atomicAdd(dC + pc + bc + (long)n * L + l, trC[rbase + e]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+        float odd[kE];
+#pragma unroll
+        for (int j = 0; j < kE; ++j) {
+            float dr_ = ddt[j];
+            if (softplus && raw[j] <= 20.f) dr_ = ddt[j] * sigmoidf_(raw[j]);
+            odd[j] = l0 + j < L ? dr_ : 0.f;
+            accBias += odd[j];
+        }
         if (row_ok) {
             if (vec_ok && l0 + kE <= L) {
                 store_pack<T, kE>(du + rrow * L + l0, odu);
@@ -426,11 +455,14 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void selective_scan_bwd_ker
             }
         }
     }
-    accA = row_sum<LPR>(accA);
     accD = row_sum<LPR>(accD);
     accBias = row_sum<LPR>(accBias);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const float sA = row_sum<LPR>(accA[n]);
+        if (row_ok && sub == 0) atomicAdd(dA + (long)d * N + n, sA);
+    }
     if (row_ok && sub == 0) {
-        atomicAdd(dA + d, accA);
         if (dD) atomicAdd(dD + d, accD);
         if (ddbias) atomicAdd(ddbias + d, accBias);
     }
@@ -527,8 +559,8 @@ extern "C" int tramba_selective_scan_bwd(const void *u, const void *delta, const
     TRAMBA_CHECK(batch > 0 && kd > 0 && k > 0 && l > 0, "selective_scan_bwd: empty shape");
     TRAMBA_CHECK(kd % k == 0, "selective_scan_bwd: KD=%d is not a multiple of K=%d", kd, k);
     TRAMBA_CHECK(ncopy >= 1, "selective_scan_bwd: ncopy must be >= 1");
-    if (n != 1) {
-        set_error("selective_scan_bwd: d_state=%d unsupported (Tramba uses 1)", n);
+    if (n != 1 && n != 2 && n != 4) {
+        set_error("selective_scan_bwd: d_state=%d not instantiated (1,2,4)", n);
         return TRAMBA_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -541,17 +573,22 @@ extern "C" int tramba_selective_scan_bwd(const void *u, const void *delta, const
     const int vec_ok = (l % kE == 0) && aligned16(u) && aligned16(delta) && aligned16(Bm) && aligned16(Cm) &&
                        aligned16(dout) && aligned16(du) && aligned16(ddelta);
     dim3 grid((unsigned)blocks), block(kWavesPerBlock * kWave);
-#define LAUNCH_(T, LPR_)                                                                                    \
-    hipLaunchKernelGGL((selective_scan_bwd_kernel<T, LPR_>), grid, block, 0, s, (const T *)u, (const T *)delta, \
-                       A, (const T *)Bm, (const T *)Cm, D, delta_bias, dout, ckpt, (T *)du, (T *)ddelta, dA, dB, \
-                       dC, dD, ddelta_bias, (int)rows, kd, k, l, nchunk, delta_softplus, vec_ok, ncopy,          \
+#define LAUNCH_N_(T, LPR_, N_)                                                                                    \
+    hipLaunchKernelGGL((selective_scan_bwd_kernel<T, LPR_, N_>), grid, block, 0, s, (const T *)u, (const T *)delta, \
+                       A, (const T *)Bm, (const T *)Cm, D, delta_bias, dout, ckpt, (T *)du, (T *)ddelta, dA, dB,    \
+                       dC, dD, ddelta_bias, (int)rows, kd, k, l, nchunk, delta_softplus, vec_ok, ncopy,             \
                        (long)batch * k * n * l)
+#define LAUNCH_(T, LPR_)                                        \
+    if (n == 1) { LAUNCH_N_(T, LPR_, 1); }                      \
+    else if (n == 2) { LAUNCH_N_(T, LPR_, 2); }                 \
+    else { LAUNCH_N_(T, LPR_, 4); }
     TRAMBA_DISPATCH_DTYPE(io_dtype, T, {
-        if (lpr == 16) LAUNCH_(T, 16);
-        else if (lpr == 32) LAUNCH_(T, 32);
-        else LAUNCH_(T, 64);
+        if (lpr == 16) { LAUNCH_(T, 16) }
+        else if (lpr == 32) { LAUNCH_(T, 32) }
+        else { LAUNCH_(T, 64) }
     });
 #undef LAUNCH_
+#undef LAUNCH_N_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
