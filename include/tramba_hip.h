@@ -206,6 +206,15 @@ int tramba_rowdot_cl(const void *x, const float *w, float bias, float *y, int64_
  * into one 7x7 (and b3 + b5 + b7), so y = GELU(h + dw3(h) + dw5(h) + dw7(h)) is ONE dwconv pass. */
 int tramba_dw_pack(const float *w, const float *bias, const float *w3, const float *b3, const float *w5,
                    const float *b5, float *wt, float *bt, int c, int ks, void *stream);
+/* Training path of the dense 3x3 convolutions of the VMamba stem / downsample layers (vmamba.py:454,481,486; the reference
+ * gets their autograd from cuDNN through nn.Conv2d): the data movement around the library's GEMMs.
+ *   im2col: x (B,H,W,C) dtype -> cols (B*Ho*Wo, CKp) dtype, column (ky*3 + kx)*C + ci (the k-major order of
+ *           tramba_conv3x3s2_cl's weight), zeros in the padding taps and in columns 9C..CKp;  Ho = (H + 2 pad - 3)/stride + 1
+ *   col2im: gcols (B*Ho*Wo, CKp) -> gx (B,H,W,C) = the adjoint gather (fp32 sums, fixed order, no atomics). */
+int tramba_im2col3x3_cl(const void *x, void *cols, int batch, int h, int wd, int c, int stride, int pad, int ckp,
+                        int dtype, void *stream);
+int tramba_col2im3x3_cl(const void *gcols, void *gx, int batch, int h, int wd, int c, int stride, int pad, int ckp,
+                        int dtype, void *stream);
 /* depth-wise ks x ks, stride 1, "same" padding, y = act(conv(x) + bt). */
 int tramba_dwconv_cl(const void *x, const float *wt, const float *bt, void *y, int batch, int h,
                      int wd, int c, int ks, int act, int dtype, void *stream);

@@ -1020,6 +1020,137 @@ extern "C" int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *part
     return TRAMBA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// im2col / col2im of a dense 3x3 convolution on a channels-last map (training path of the four stride-2 convs of the VMamba
+// stem and downsample layers, vmamba.py:454,481,486): the GEMMs around them are the library's own, these two kernels are
+// the data movement.  cols (B*Ho*Wo, CKp): row = output pixel, column (ky*3 + kx)*C + ci -- the k-major order of
+// tramba_conv3x3s2_cl's weight -- zero in the padding taps and in the CKp - 9C alignment columns.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void im2col3x3_cl_kernel(const T *__restrict__ x, T *__restrict__ cols, int H, int W,
+                                                          int C, int Ho, int Wo, int stride, int pad, int CKp, long total)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per V consecutive columns of a row
+    if (i >= total) return;
+    const int cpr = CKp / V;
+    const long row = i / cpr;
+    const int col = (int)(i % cpr) * V;
+    const int wo = (int)(row % Wo);
+    const long t = row / Wo;
+    const int ho = (int)(t % Ho), b = (int)(t / Ho);
+    float v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = 0.f;
+    const int tap = col / C, ci = col - tap * C;    // (V > 1 only with C % V == 0: the V columns share a tap)
+    if (tap < 9) {
+        const int hi = ho * stride + tap / 3 - pad, wi = wo * stride + tap % 3 - pad;
+        if (hi >= 0 && hi < H && wi >= 0 && wi < W) load_pack<T, V>(x + (((long)b * H + hi) * W + wi) * C + ci, v);
+    }
+    store_pack<T, V>(cols + row * CKp + col, v);
+}
+
+// gx[b,hi,wi,ci] = sum over the taps (ky,kx) and output pixels (ho,wo) with ho*stride + ky - pad = hi, wo*stride + kx - pad
+// = wi of gcols[(b,ho,wo)][(ky*3 + kx)*C + ci]: a gather per input pixel (at most 4 terms at stride 2), fp32 sums, no atomics
+template <typename T, int V>
+__global__ __launch_bounds__(256) void col2im3x3_cl_kernel(const T *__restrict__ gcols, T *__restrict__ gx, int H, int W,
+                                                          int C, int Ho, int Wo, int stride, int pad, int CKp, long total)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per V channels of an input pixel
+    if (i >= total) return;
+    const int cpp = C / V;
+    const long pix = i / cpp;
+    const int ci = (int)(i % cpp) * V;
+    const int wi = (int)(pix % W);
+    const long t = pix / W;
+    const int hi = (int)(t % H), b = (int)(t / H);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int hn = hi + pad - ky;
+        if (hn < 0 || hn % stride) continue;
+        const int ho = hn / stride;
+        if (ho >= Ho) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int wn = wi + pad - kx;
+            if (wn < 0 || wn % stride) continue;
+            const int wo = wn / stride;
+            if (wo >= Wo) continue;
+            float v[V];
+            load_pack<T, V>(gcols + (((long)b * Ho + ho) * Wo + wo) * CKp + (ky * 3 + kx) * C + ci, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += v[e];
+        }
+    }
+    store_pack<T, V>(gx + pix * C + ci, acc);
+}
+
+static int conv3_geom(int h, int wd, int stride, int pad, int &ho, int &wo)
+{
+    ho = (h + 2 * pad - 3) / stride + 1;
+    wo = (wd + 2 * pad - 3) / stride + 1;
+    return ho > 0 && wo > 0;
+}
+
+extern "C" int tramba_im2col3x3_cl(const void *x, void *cols, int batch, int h, int wd, int c, int stride, int pad,
+                                   int ckp, int dtype, void *stream)
+{
+    TRAMBA_CHECK(x && cols, "im2col3x3_cl: null tensor");
+    TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0 && stride >= 1 && pad >= 0, "im2col3x3_cl: empty shape");
+    TRAMBA_CHECK(ckp >= 9 * c, "im2col3x3_cl: CKp=%d < 9*C", ckp);
+    int ho, wo;
+    TRAMBA_CHECK(conv3_geom(h, wd, stride, pad, ho, wo), "im2col3x3_cl: the map is smaller than the stencil");
+    const int esz = dtype == TRAMBA_F32 ? 4 : 2;
+    const int vmax = 16 / esz;
+    const bool vec = c % vmax == 0 && ckp % vmax == 0 && aligned16(x) && aligned16(cols);
+    const long rows = (long)batch * ho * wo;
+    hipStream_t s = (hipStream_t)stream;
+    TRAMBA_DISPATCH_DTYPE(dtype, T, {
+        constexpr int VM = 16 / (int)sizeof(T);
+        if (vec) {
+            const long total = rows * (ckp / VM);
+            hipLaunchKernelGGL((im2col3x3_cl_kernel<T, VM>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T *)x,
+                               (T *)cols, h, wd, c, ho, wo, stride, pad, ckp, total);
+        } else {
+            const long total = rows * ckp;
+            hipLaunchKernelGGL((im2col3x3_cl_kernel<T, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T *)x,
+                               (T *)cols, h, wd, c, ho, wo, stride, pad, ckp, total);
+        }
+    });
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_col2im3x3_cl(const void *gcols, void *gx, int batch, int h, int wd, int c, int stride, int pad,
+                                   int ckp, int dtype, void *stream)
+{
+    TRAMBA_CHECK(gcols && gx, "col2im3x3_cl: null tensor");
+    TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0 && stride >= 1 && pad >= 0, "col2im3x3_cl: empty shape");
+    TRAMBA_CHECK(ckp >= 9 * c, "col2im3x3_cl: CKp=%d < 9*C", ckp);
+    int ho, wo;
+    TRAMBA_CHECK(conv3_geom(h, wd, stride, pad, ho, wo), "col2im3x3_cl: the map is smaller than the stencil");
+    const int esz = dtype == TRAMBA_F32 ? 4 : 2;
+    const int vmax = 16 / esz;
+    const bool vec = c % vmax == 0 && ckp % vmax == 0 && aligned16(gcols) && aligned16(gx);
+    const long pixels = (long)batch * h * wd;
+    hipStream_t s = (hipStream_t)stream;
+    TRAMBA_DISPATCH_DTYPE(dtype, T, {
+        constexpr int VM = 16 / (int)sizeof(T);
+        if (vec) {
+            const long total = pixels * (c / VM);
+            hipLaunchKernelGGL((col2im3x3_cl_kernel<T, VM>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                               (const T *)gcols, (T *)gx, h, wd, c, ho, wo, stride, pad, ckp, total);
+        } else {
+            const long total = pixels * c;
+            hipLaunchKernelGGL((col2im3x3_cl_kernel<T, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                               (const T *)gcols, (T *)gx, h, wd, c, ho, wo, stride, pad, ckp, total);
+        }
+    });
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
 extern "C" int tramba_dwconv_cl(const void *x, const float *wt, const float *bt, void *y, int batch, int h,
                                 int wd, int c, int ks, int act, int dtype, void *stream)
 {

@@ -59,6 +59,8 @@ SIGNATURES = {
     "tramba_saliency_stats": (c_int, [c_vp] * 4 + [c_int] * 3 + [c_vp]),
     "tramba_dw_pack": (c_int, [c_vp] * 8 + [c_int] * 2 + [c_vp]),
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
+    "tramba_im2col3x3_cl": (c_int, [c_vp] * 2 + [c_int] * 8 + [c_vp]),
+    "tramba_col2im3x3_cl": (c_int, [c_vp] * 2 + [c_int] * 8 + [c_vp]),
     "tramba_dwconv_wgrad_parts": (c_i64, [c_int, c_int, c_int, c_int]),
     "tramba_dwconv_wgrad_cl": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
@@ -534,6 +536,26 @@ def dwconv_cl(x, wt, bt, act=ACT_NONE):
     _check(lib().tramba_dwconv_cl(_ptr(x), _ptr(wt), _ptr(bt), _ptr(y), bb, h, wd, c, ks, act, dt(x), _stream()),
            "dwconv_cl")
     return y
+
+
+def im2col3x3_cl(x, stride, pad, ckp):
+    """x (B,H,W,C) -> cols (B*Ho*Wo, ckp), column (ky*3 + kx)*C + ci, zeros for padding taps / alignment columns."""
+    _dev(x)
+    bb, h, wd, c = x.shape
+    ho, wo = (h + 2 * pad - 3) // stride + 1, (wd + 2 * pad - 3) // stride + 1
+    cols = torch.empty((bb * ho * wo, ckp), dtype=x.dtype, device=x.device)
+    _check(lib().tramba_im2col3x3_cl(_ptr(x), _ptr(cols), bb, h, wd, c, stride, pad, ckp, dt(x), _stream()), "im2col3x3_cl")
+    return cols
+
+
+def col2im3x3_cl(gcols, shape, stride, pad):
+    """gcols (B*Ho*Wo, CKp) -> gx of `shape` = (B,H,W,C): the adjoint of im2col3x3_cl."""
+    _dev(gcols)
+    bb, h, wd, c = shape
+    gx = torch.empty(shape, dtype=gcols.dtype, device=gcols.device)
+    _check(lib().tramba_col2im3x3_cl(_ptr(gcols), _ptr(gx), bb, h, wd, c, stride, pad, gcols.shape[1], dt(gcols), _stream()),
+           "col2im3x3_cl")
+    return gx
 
 
 def dwconv_wgrad_cl(x, gy, ks):

@@ -125,43 +125,42 @@ def _dgrad(gy2, wa, wa_t=None):
 
 
 class _ConvIm2colCL(torch.autograd.Function):
-    """A dense convolution of the TRAINING path on a channels-last map with autograd (the four 3x3 / stride-2 convs of
-    the VMamba stem and downsample layers, vmamba.py:454,481,486): im2col (torch's native unfold / fold kernels, pure
-    data movement) around the library's own GEMMs -- forward and input gradient on tramba_linear_cl, weight / bias
-    gradient on tramba_wgrad_cl.  x (B,H,W,Cin), w (Cout,Cin,kh,kw), b (Cout) or None -> (B,Ho,Wo,Cout)."""
+    """A dense convolution of the TRAINING path on a channels-last map with autograd (the 3x3 / stride-2 convs of the
+    VMamba stem and downsample layers, vmamba.py:454,481,486), all on the library: im2col / col2im
+    (tramba_im2col3x3_cl / tramba_col2im3x3_cl: one pass each over the column matrix, in the k-major column order
+    (ky, kx, ci), no transposed or padded copies) around the GEMMs -- forward and input gradient on tramba_linear_cl, weight /
+    bias gradient on tramba_wgrad_cl.  x (B,H,W,Cin), w (Cout,Cin,3,3), b (Cout) or None -> (B,Ho,Wo,Cout)."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, padding):
         bsz, h, wd, cin = x.shape
         cout, _, kh, kw = w.shape
-        cols = F.unfold(x.permute(0, 3, 1, 2), (kh, kw), padding=padding, stride=stride)      # (B, Cin*kh*kw, L)
-        ck = cin * kh * kw
+        if (kh, kw) != (3, 3) or stride[0] != stride[1] or padding[0] != padding[1]:
+            raise NotImplementedError("the training path of a dense convolution is built for 3x3 kernels with one stride / padding")
+        st, pd = int(stride[0]), int(padding[0])
+        ck = cin * 9
         ckp = (ck + 7) // 8 * 8                                                                # 16-byte rows for the kernels
-        ct = cols.transpose(1, 2)
-        ct = F.pad(ct, (0, ckp - ck)) if ckp != ck else ct.contiguous()                        # (B, L, CKp)
-        w2 = w.detach().reshape(cout, ck).to(x.dtype)
+        ct = hip.im2col3x3_cl(x.contiguous(), st, pd, ckp)                                     # (B*L, CKp), columns (ky, kx, ci)
+        w2 = w.detach().permute(0, 2, 3, 1).reshape(cout, ck).to(x.dtype)                      # the same column order
         if ckp != ck:
             w2 = F.pad(w2, (0, ckp - ck))
-        ho = (h + 2 * padding[0] - kh) // stride[0] + 1
-        wo = (wd + 2 * padding[1] - kw) // stride[1] + 1
-        y = hip.linear_cl(ct.view(-1, ckp), w2.contiguous(), None if b is None else b.detach().float().contiguous())
+        ho, wo = (h + 2 * pd - 3) // st + 1, (wd + 2 * pd - 3) // st + 1
+        y = hip.linear_cl(ct, w2.contiguous(), None if b is None else b.detach().float().contiguous())
         ctx.save_for_backward(ct, w2)
-        ctx.cfg = (tuple(stride), tuple(padding), (kh, kw), (h, wd), cin, ck, b is not None, w.dtype, w.shape)
+        ctx.cfg = (st, pd, tuple(x.shape), cin, ck, b is not None, w.dtype)
         return y.view(bsz, ho, wo, cout)
 
     @staticmethod
     def backward(ctx, gy):
         ct, w2 = ctx.saved_tensors
-        stride, padding, ks, hw, cin, ck, has_bias, wdtype, wshape = ctx.cfg
-        bsz = gy.shape[0]
+        st, pd, xshape, cin, ck, has_bias, wdtype = ctx.cfg
         gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gct = _dgrad(gy2, w2)[:, :ck].reshape(bsz, -1, ck).transpose(1, 2)                 # (B, Cin*kh*kw, L)
-            gx = F.fold(gct, hw, ks, padding=padding, stride=stride).permute(0, 2, 3, 1).contiguous()
+            gx = hip.col2im3x3_cl(_dgrad(gy2, w2), xshape, st, pd)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _wgrad(gy2, ct.view(gy2.shape[0], -1), has_bias)
-            gw = gw[:, :ck].reshape(wshape).to(wdtype)
+            gw, gb = _wgrad(gy2, ct, has_bias)
+            gw = gw[:, :ck].reshape(-1, 3, 3, cin).permute(0, 3, 1, 2).contiguous().to(wdtype)   # back to (Cout, Cin, 3, 3)
         return gx, gw, gb, None, None
 
 
@@ -1319,7 +1318,9 @@ def _conv_cl(conv: nn.Conv2d, x_cl):
                               lambda: conv.weight.detach().permute(0, 2, 3, 1).reshape(conv.out_channels, -1)
                               .to(x_cl.dtype).contiguous())
         return hip.conv3x3s2_cl(x_cl, wk, _f32(conv.bias))
-    if torch.is_grad_enabled() and (x_cl.requires_grad or conv.weight.requires_grad):
+    if (torch.is_grad_enabled() and (x_cl.requires_grad or conv.weight.requires_grad) and conv.kernel_size == (3, 3)
+            and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1] and conv.groups == 1
+            and conv.dilation == (1, 1)):
         return _ConvIm2colCL.apply(x_cl, conv.weight, conv.bias, conv.stride, conv.padding)
     x = from_cl(x_cl)
     b = None if conv.bias is None else conv.bias.to(x.dtype)
