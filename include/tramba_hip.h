@@ -215,6 +215,10 @@ int tramba_im2col3x3_cl(const void *x, void *cols, int batch, int h, int wd, int
                         int dtype, void *stream);
 int tramba_col2im3x3_cl(const void *gcols, void *gx, int batch, int h, int wd, int c, int stride, int pad, int ckp,
                         int dtype, void *stream);
+/* Backward of F.interpolate(mode="bilinear", align_corners=False) from (planes, h, w) to (planes, hout, wout), fp32 -- the
+ * resize of the deep-supervision outputs in the loss (train.py:76-85): gin = the adjoint, gathered per input pixel. */
+int tramba_upsample_bilinear_bwd(const float *gout, float *gin, int planes, int h, int w, int hout, int wout,
+                                 void *stream);
 /* depth-wise ks x ks, stride 1, "same" padding, y = act(conv(x) + bt). */
 int tramba_dwconv_cl(const void *x, const float *wt, const float *bt, void *y, int batch, int h,
                      int wd, int c, int ks, int act, int dtype, void *stream);

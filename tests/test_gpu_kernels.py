@@ -656,6 +656,24 @@ def test_slab_sum_fixed_order(shape):
     assert torch.equal(got, H.slab_sum(part))
 
 
+@pytest.mark.parametrize("cfg", [(8, 48, 384), (8, 96, 384), (2, 192, 384), (3, 13, 37), (1, 7, 7), (2, 24, 25)])
+def test_upsample_bilinear_backward_is_the_adjoint(cfg):
+    """tramba_upsample_bilinear_bwd (the resize of the deep-supervision outputs in the loss, train.py:76-85) == autograd of
+    F.interpolate(mode="bilinear"): every input pixel gathers its weights (borders, non-integer scales included)."""
+    from tramba_amd import train
+    b, n, m = cfg
+    g = torch.Generator().manual_seed(n * m)
+    x = torch.randn(b, 1, n, n, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(b, 1, m, m, generator=g).to(DEV)
+    F.interpolate(x, (m, m), mode="bilinear").backward(gy)
+    want = x.grad.clone()
+    x.grad = None
+    y = train._resize_bilinear(x, (m, m))
+    assert torch.equal(y, F.interpolate(x.detach(), (m, m), mode="bilinear"))
+    y.backward(gy)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+
+
 def test_shadow_cast_multi_matches_cast_and_transpose():
     """tramba_shadow_cast_multi: one launch writes the 16-bit copy and the 16-bit transpose of every matrix in a device
     table (ragged shapes, shapes below one tile, a skipped destination) == .to(dtype) / .t() bit for bit."""

@@ -60,6 +60,7 @@ SIGNATURES = {
     "tramba_dw_pack": (c_int, [c_vp] * 8 + [c_int] * 2 + [c_vp]),
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
     "tramba_im2col3x3_cl": (c_int, [c_vp] * 2 + [c_int] * 8 + [c_vp]),
+    "tramba_upsample_bilinear_bwd": (c_int, [c_vp] * 2 + [c_int] * 5 + [c_vp]),
     "tramba_col2im3x3_cl": (c_int, [c_vp] * 2 + [c_int] * 8 + [c_vp]),
     "tramba_dwconv_wgrad_parts": (c_i64, [c_int, c_int, c_int, c_int]),
     "tramba_dwconv_wgrad_cl": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp]),
@@ -536,6 +537,19 @@ def dwconv_cl(x, wt, bt, act=ACT_NONE):
     _check(lib().tramba_dwconv_cl(_ptr(x), _ptr(wt), _ptr(bt), _ptr(y), bb, h, wd, c, ks, act, dt(x), _stream()),
            "dwconv_cl")
     return y
+
+
+def upsample_bilinear_bwd(gout, h, w):
+    """gout (..., H, W) f32 = gradient of F.interpolate(x (..., h, w), (H, W), mode="bilinear") -> gradient of x."""
+    _dev(gout)
+    gout = gout.contiguous()
+    hh, ww = gout.shape[-2:]
+    planes = gout.numel() // (hh * ww)
+    gin = torch.empty(gout.shape[:-2] + (h, w), dtype=torch.float32, device=gout.device)
+    if gout.dtype != torch.float32:
+        raise TrambaHipError("upsample_bilinear_bwd: fp32 gradients only")
+    _check(lib().tramba_upsample_bilinear_bwd(_ptr(gout), _ptr(gin), planes, h, w, hh, ww, _stream()), "upsample_bilinear_bwd")
+    return gin
 
 
 def im2col3x3_cl(x, stride, pad, ckp):

@@ -1105,12 +1105,27 @@ class SS2D(nn.Module):
         return from_cl(self._forward_cl(to_cl(x)))
 
 
+class _AddMasked(torch.autograd.Function):
+    """x + y * mask (stochastic depth on the residual branch, mask = keep / keep_prob per sample): one launch forward, one
+    backward (gy = g * mask; gx is g itself) -- autograd's own graph for addcmul issues three small launches per block."""
+
+    @staticmethod
+    def forward(ctx, x, y, mask):
+        ctx.save_for_backward(mask)
+        return torch.addcmul(x, y, mask)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return (g if ctx.needs_input_grad[0] else None), (g * mask if ctx.needs_input_grad[1] else None), None
+
+
 class _ResidualBlock(nn.Module):
     def _residual(self, x, branch, drop_path):
         """x + drop_path(branch(x_normed)); the add is fused into the branch's last GEMM when possible."""
         if isinstance(drop_path, DropPath) and drop_path.training and drop_path.drop_prob > 0.0:
             y = branch(None)
-            return torch.addcmul(x, y, drop_path.mask_for(y))      # x + y * mask / keep in one launch
+            return _AddMasked.apply(x, y, drop_path.mask_for(y))   # x + y * mask / keep in one launch
         return branch(x)
 
 
