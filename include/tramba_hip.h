@@ -251,6 +251,11 @@ int tramba_linear_ln_cl(const void *x, const void *w_folded, const float *colsum
 int tramba_linear2_cl(const void *x1, const void *x2, int k1, const void *w, const float *bias, const void *residual,
                       void *y, int64_t m, int n, int k, int act, int dtype, int out_dtype, void *stream);
 
+/* y_pre = x @ w^T + bias and y_act = act(y_pre) from ONE launch (act = GELU or SiLU): the forward of `act(Linear(x))` on the
+ * training path, whose backward needs the pre-activation (Models/modules.py:134-153 under autograd).  16-bit dtypes,
+ * K % 64 == 0, N % 8 == 0; both outputs (M, N) in dtype. */
+int tramba_linear_dual_cl(const void *x, const void *w, const float *bias, void *y_pre, void *y_act, int64_t m, int n,
+                          int k, int act, int dtype, void *stream);
 /* Weight (and bias) gradient of a 1x1 convolution under autograd -- what `loss.backward()` computes for every
  * Linear2d (Models/modules.py:10-19; the reference gets it from cuDNN/cuBLAS through F.conv2d's autograd):
  *   out[g][n*K + k]  = sum over batches b and tokens t of gy[g][b][t][n] * x[g][b][t][k]       (N x K, fp32)

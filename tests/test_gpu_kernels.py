@@ -674,6 +674,23 @@ def test_upsample_bilinear_backward_is_the_adjoint(cfg):
     np.testing.assert_allclose(x.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mnk", [(4608, 2048, 512), (576, 4096, 1024), (1000, 72, 128), (73, 8, 64)])
+def test_linear_dual_output(dtype, mnk):
+    """tramba_linear_dual_cl: the pre-activation and its GELU from one launch == the two single-output launches bit for bit
+    (same kernel, same accumulation order), ragged M / N included."""
+    m, n, k = mnk
+    H = hip()
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dtype).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    pre, act = H.linear_dual_cl(x, w, bias, H.ACT_GELU)
+    assert torch.equal(pre, H.linear_cl(x, w, bias)) and torch.equal(act, H.linear_cl(x, w, bias, None, H.ACT_GELU))
+    pre, act = H.linear_dual_cl(x, w, None, H.ACT_SILU)
+    assert torch.equal(pre, H.linear_cl(x, w)) and torch.equal(act, H.linear_cl(x, w, None, None, H.ACT_SILU))
+
+
 def test_shadow_cast_multi_matches_cast_and_transpose():
     """tramba_shadow_cast_multi: one launch writes the 16-bit copy and the 16-bit transpose of every matrix in a device
     table (ragged shapes, shapes below one tile, a skipped destination) == .to(dtype) / .t() bit for bit."""

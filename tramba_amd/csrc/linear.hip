@@ -180,8 +180,11 @@ __device__ __forceinline__ void tile_epilogue(ACC &acc, unsigned char *lds,
                                               const float *__restrict__ bias, const T *__restrict__ res,
                                               TO *__restrict__ y, long M, int N, int act, long m0, int n0,
                                               const float *__restrict__ colsum = nullptr,
-                                              const float2 *__restrict__ rowstat = nullptr)
+                                              const float2 *__restrict__ rowstat = nullptr,
+                                              TO *__restrict__ y_pre = nullptr)
 {
+    // y_pre (training, linear_dma_kernel<.., DUAL>): the value BEFORE the activation (acc + bias) also leaves, to a second
+    // tensor -- the pre-activation the backward of a GELU needs, without a separate activation launch re-reading it.
     // colsum / rowstat: LayerNorm of the INPUT rows folded into the GEMM (linear_lean_kernel<.., LNIN>): the accumulator
     // holds x . W' with W' = W * gamma; the normalised product is rstd_m * (acc - mean_m * colsum_n), and beta . W rides
     // in `bias`.  rowstat[row] = (mean, rstd) of the block's rows, in LDS behind the staging tile.
@@ -223,6 +226,7 @@ __device__ __forceinline__ void tile_epilogue(ACC &acc, unsigned char *lds,
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) o[q] += bv[q];
             }
+            if (y_pre) store_pack<TO, CPL>(y_pre + grow * N + gcol, o);
 #pragma unroll
             for (int q = 0; q < CPL; ++q) o[q] = apply_act(o[q], act);
             if (res) {
@@ -237,7 +241,9 @@ __device__ __forceinline__ void tile_epilogue(ACC &acc, unsigned char *lds,
             for (int q = 0; q < CPL; ++q) {
                 if (gcol + q < N) {
                     if (colsum) o[q] = rowstat[row].y * fmaf(-rowstat[row].x, colsum[gcol + q], o[q]);
-                    float t = apply_act(o[q] + (bias ? bias[gcol + q] : 0.f), act);
+                    const float pre = o[q] + (bias ? bias[gcol + q] : 0.f);
+                    if (y_pre) y_pre[grow * N + gcol + q] = Cvt<TO>::from_f(pre);
+                    float t = apply_act(pre, act);
                     if (res) {
                         const float rv = Cvt<T>::to_f(res[grow * N + gcol + q]);
                         t = combine_residual(t, rv, act);
@@ -752,11 +758,11 @@ __global__ __launch_bounds__(256) void linear_lean_kernel(const T *__restrict__ 
 // Same epilogue (tile_epilogue) as the other forms.
 #define TRAMBA_DSR128_(OUT, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(OUT) : "v"(ADDR) : "memory")
 
-template <typename T, typename TO, int NSTG, bool LNIN = false>
+template <typename T, typename TO, int NSTG, bool LNIN = false, bool DUAL = false>
 __global__ __launch_bounds__(256) void linear_dma_kernel(const T *__restrict__ x, const T *__restrict__ w,
                                                         const float *__restrict__ bias, const T *__restrict__ res,
                                                         TO *__restrict__ y, long M, int N, int K, int act,
-                                                        LnIn li = LnIn{nullptr, 0.f})
+                                                        LnIn li = LnIn{nullptr, 0.f}, TO *__restrict__ y_pre = nullptr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // (vector-register asm in a kernel template: see ss2d_scan_dma_kernel)
     constexpr int BM = 64, BN = 64;
@@ -935,7 +941,7 @@ __global__ __launch_bounds__(256) void linear_dma_kernel(const T *__restrict__ x
         tile_epilogue<T, TO, BM, BN, 2>(acc, lds, bias, res, y, M, N, act, m0, n0, li.colsum,
                                         reinterpret_cast<const float2 *>(lds + LDS_BYTES));
     } else {
-        tile_epilogue<T, TO, BM, BN, 2>(acc, lds, bias, res, y, M, N, act, m0, n0);
+        tile_epilogue<T, TO, BM, BN, 2>(acc, lds, bias, res, y, M, N, act, m0, n0, nullptr, nullptr, DUAL ? y_pre : nullptr);
     }
 #endif
 }
@@ -1235,6 +1241,32 @@ extern "C" int tramba_conv3x3s2_cl(const void *x, const void *w, const float *bi
         launch_tiled<__hip_bfloat16, __hip_bfloat16, true>(x, w, bias, nullptr, y, m, cout, 9 * cin, TRAMBA_ACT_NONE, s, cg);
     else
         launch_tiled<__half, __half, true>(x, w, bias, nullptr, y, m, cout, 9 * cin, TRAMBA_ACT_NONE, s, cg);
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_linear_dual_cl(const void *x, const void *w, const float *bias, void *y_pre, void *y_act, int64_t m,
+                                     int n, int k, int act, int dtype, void *stream)
+{
+    TRAMBA_CHECK(x && w && y_pre && y_act, "linear_dual_cl: null tensor");
+    TRAMBA_CHECK(m > 0 && n > 0 && k > 0, "linear_dual_cl: empty shape");
+    TRAMBA_CHECK(dtype == TRAMBA_BF16 || dtype == TRAMBA_F16, "linear_dual_cl: 16-bit activations only");
+    TRAMBA_CHECK(act == TRAMBA_ACT_GELU || act == TRAMBA_ACT_SILU, "linear_dual_cl: act must be GELU or SiLU");
+    TRAMBA_CHECK(k % 64 == 0 && n % 8 == 0 && (double)k * 2.0 * 128.0 < 2147483648.0 && (m + 63) / 64 <= 65535,
+                 "linear_dual_cl: needs K %% 64 == 0, N %% 8 == 0");
+    TRAMBA_CHECK(aligned16(x) && aligned16(w) && aligned16(y_pre) && aligned16(y_act), "linear_dual_cl: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(TRAMBA_PROF_GEMM, s, 2.0 * (double)m * n * k);
+    dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
+    if (dtype == TRAMBA_BF16) {
+        using T = __hip_bfloat16;
+        hipLaunchKernelGGL((linear_dma_kernel<T, T, 3, false, true>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                           (const T *)nullptr, (T *)y_act, m, n, k, act, LnIn{nullptr, 0.f}, (T *)y_pre);
+    } else {
+        using T = __half;
+        hipLaunchKernelGGL((linear_dma_kernel<T, T, 3, false, true>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                           (const T *)nullptr, (T *)y_act, m, n, k, act, LnIn{nullptr, 0.f}, (T *)y_pre);
+    }
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }

@@ -66,6 +66,7 @@ SIGNATURES = {
     "tramba_dwconv_wgrad_cl": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_linear_dual_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_linear_ln_cl": (c_int, [c_vp] * 6 + [c_i64, c_int, c_int, c_f, c_int, c_int, c_int, c_vp]),
     "tramba_linear2_cl": (c_int, [c_vp, c_vp, c_int] + [c_vp] * 4 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_wgrad_workspace": (ctypes.c_size_t, [c_i64, c_int, c_int, c_int, c_int]),
@@ -622,6 +623,27 @@ def linear_cl(x, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
     _check(lib().tramba_linear_cl(_ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), m, n, k, act, dt(x),
                                   dt(y), _stream()), "linear_cl")
     return y
+
+
+def linear_dual_ok(x, w):
+    """can linear_dual_cl take this GEMM? (16-bit operands, whole 64-deep K steps, 16-byte rows)"""
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and x.shape[-1] % 64 == 0
+            and w.shape[0] % 8 == 0 and x.is_contiguous() and w.is_contiguous())
+
+
+def linear_dual_cl(x, w, bias, act):
+    """x: (..., K); w: (N, K) -> (pre, act(pre)), both (..., N) in x's dtype, from one launch."""
+    _dev(x, w, bias)
+    k, n = x.shape[-1], w.shape[0]
+    m = x.numel() // k
+    if not linear_dual_ok(x, w) or w.shape[1] != k:
+        raise TrambaHipError("linear_dual_cl: needs 16-bit contiguous operands with K % 64 == 0 and N % 8 == 0")
+    _check_epilogue("linear_dual_cl", bias, None, x.dtype, m, n)
+    y_pre = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
+    y_act = torch.empty_like(y_pre)
+    _check(lib().tramba_linear_dual_cl(_ptr(x), _ptr(w), _ptr(bias), _ptr(y_pre), _ptr(y_act), m, n, k, act, dt(x), _stream()),
+           "linear_dual_cl")
+    return y_pre, y_act
 
 
 def linear_ln_cl(x, w_folded, colsum, bias, eps, residual=None, act=ACT_NONE, out_dtype=None):

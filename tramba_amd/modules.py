@@ -444,11 +444,12 @@ class _GeluLinearTrainCL(torch.autograd.Function):
     Mlp hidden layer, the SS2D inner width)."""
 
     @staticmethod
-    def forward(ctx, h, w, b):
+    def forward(ctx, h, w, b, a=None):
+        """a: gelu(h) when the producer has already written it (the dual-output GEMM of _LinearGeluPairTrainCL)"""
         wa = _lowp(w, h.dtype).detach().contiguous()
         h2 = h.reshape(-1, h.shape[-1])
         h2 = h2 if h2.is_contiguous() else h2.contiguous()
-        a2 = F.gelu(h2)
+        a2 = F.gelu(h2) if a is None else a.detach().reshape(h2.shape)
         ctx.save_for_backward(h2, a2, wa)
         ctx.wa_t = _lowp_t(w, h.dtype)
         ctx.wdtype, ctx.has_bias, ctx.hshape = w.dtype, b is not None, h.shape
@@ -467,7 +468,38 @@ class _GeluLinearTrainCL(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = _wgrad(gy2, a2, ctx.has_bias)
             gw = gw.to(ctx.wdtype)
-        return gh, gw, gb
+        return gh, gw, gb, None
+
+
+class _LinearGeluPairTrainCL(torch.autograd.Function):
+    """(h, gelu(h)) with h = x @ w^T + b from ONE launch (tramba_linear_dual_cl): the Mlp's fc1 on the training path.  h
+    carries the gradient; gelu(h) is handed to the next Linear (_GeluLinearTrainCL), which owns the activation's backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        wa = _lowp(w, x.dtype).detach().contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        ctx.save_for_backward(x2, wa)
+        ctx.wa_t = _lowp_t(w, x.dtype)
+        ctx.wdtype, ctx.has_bias, ctx.xshape = w.dtype, b is not None, x.shape
+        h, a = hip.linear_dual_cl(x2, wa, None if b is None else b.detach().float().contiguous(), hip.ACT_GELU)
+        ctx.mark_non_differentiable(a)
+        shape = x.shape[:-1] + (wa.shape[0],)
+        return h.view(shape), a.view(shape)
+
+    @staticmethod
+    def backward(ctx, gh, _ga):
+        x2, wa = ctx.saved_tensors
+        gx = gw = gb = None
+        gy2 = gh.reshape(-1, gh.shape[-1])
+        gy2 = gy2 if gy2.is_contiguous() and gy2.dtype == x2.dtype else gy2.to(x2.dtype).contiguous()
+        if ctx.needs_input_grad[0]:
+            gx = _dgrad(gy2, wa, ctx.wa_t).view(ctx.xshape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = _wgrad(gy2, x2, ctx.has_bias)
+            gw = gw.to(ctx.wdtype)
+        return gx, gw, gb
 
 
 class _RowDotCL(torch.autograd.Function):
@@ -501,17 +533,26 @@ class _RowDotCL(torch.autograd.Function):
 class Linear2d(nn.Linear):
     """1x1 convolution stored as an (out,in) matrix (modules.py:10-19)."""
 
-    def _forward_cl(self, x, act=hip.ACT_NONE, residual=None, out_dtype=None, gelu_in=False):
+    def _forward_cl(self, x, act=hip.ACT_NONE, residual=None, out_dtype=None, gelu_in=False, gelu_ready=None):
         """gelu_in: x is a pre-activation whose GELU this layer applies first (training path: the producer leaves the
-        activation to its consumer, see _GeluLinearTrainCL)"""
+        activation to its consumer, see _GeluLinearTrainCL); gelu_ready: that GELU, when the producer wrote it as well"""
         if _infer(x, self.weight):
             w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
             return hip.linear_cl(F.gelu(x) if gelu_in else x, w.detach(), _f32(self.bias), residual, act, out_dtype)
-        fn = _GeluLinearTrainCL if gelu_in else _LinearTrainCL
-        y = _act_torch(fn.apply(x, self.weight, self.bias), act)
+        if gelu_in:
+            y = _act_torch(_GeluLinearTrainCL.apply(x, self.weight, self.bias, gelu_ready), act)
+        else:
+            y = _act_torch(_LinearTrainCL.apply(x, self.weight, self.bias), act)
         if residual is not None:
             y = y + residual
         return y if out_dtype is None else y.to(out_dtype)
+
+    def _forward_gelu_pair_cl(self, x):
+        """training path: (h, gelu(h) or None) with h = self(x) -- both from one launch where the GEMM kernel takes the shape"""
+        if (not _infer(x, self.weight) and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] % 64 == 0
+                and self.weight.shape[0] % 8 == 0):
+            return _LinearGeluPairTrainCL.apply(x, self.weight, self.bias)
+        return self._forward_cl(x), None
 
     def _forward_norm_cl(self, x, norm, act=hip.ACT_NONE, residual=None, out_dtype=None):
         """self(norm(x)) for a LayerNorm2d `norm` over the input channels.  16-bit inference folds the LayerNorm into the
@@ -623,13 +664,16 @@ class Mlp(nn.Module):
         """pre_norm: the LayerNorm2d the caller would apply to x first (folded into fc1 where possible)"""
         # training: the GELU is applied by fc2 (its gradient rides in fc2's input-gradient GEMM)
         defer = (not _infer(x, self.fc1.weight, self.fc2.weight)) and isinstance(self.act, nn.GELU) and self.drop.p == 0.0
-        act = hip.ACT_NONE if defer else hip.ACT_GELU
+        if defer:      # fc1 writes h and gelu(h) in one launch where it can; fc2 multiplies gelu(h) and owns the GELU's gradient
+            xin = x if pre_norm is None else pre_norm._forward_cl(x)
+            h, a = self.fc1._forward_gelu_pair_cl(xin)
+            return self.fc2._forward_cl(h, residual=residual, gelu_in=True, gelu_ready=a)
         if pre_norm is not None:
-            h = self.fc1._forward_norm_cl(x, pre_norm, act=act)
+            h = self.fc1._forward_norm_cl(x, pre_norm, act=hip.ACT_GELU)
         else:
-            h = self.fc1._forward_cl(x, act=act)
+            h = self.fc1._forward_cl(x, act=hip.ACT_GELU)
         h = self.drop(h)
-        return self.drop(self.fc2._forward_cl(h, residual=residual, gelu_in=defer))
+        return self.drop(self.fc2._forward_cl(h, residual=residual))
 
     def forward(self, x):
         _need_device(x)
