@@ -102,7 +102,13 @@ def pmc_traffic(key):
     the gfx950 x2 FETCH_SIZE correction).  None when no summary covers this kernel shape."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    try:   # profiles/LATEST names the tag of the newest set (file names do not sort by time: r02i was collected after r02z)
+        tag = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
+        paths.sort(key=lambda q: os.path.basename(q).startswith(tag + "_"))
+    except OSError:
+        pass
+    for path in paths:
         try:
             d = json.load(open(path)).get(key)
         except Exception:
