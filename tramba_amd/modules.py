@@ -999,8 +999,22 @@ class _SS2DCoreCL(torch.autograd.Function):
             g_dtw = g_dtw[..., :r].contiguous()     # (a view would be cloned by autograd's gradient accumulation anyway)
         g_seq[..., r8] = g_b
         g_seq[..., r8 + 1] = g_c
-        g_xd = torch.zeros_like(xdf)
-        g_xd.index_add_(1, flat, g_seq.view(b, k * l, rg))
+        # back to spatial order.  Where every direction visits every pixel exactly once (raster, window, dilation orders) the
+        # rows are permuted, not accumulated: one gather through the inverse permutation (deterministic, no zero fill);
+        # the Helix lines revisit pixels, there the rows are summed by index_add_
+        inv = getattr(order, "_flat_inverse", None)
+        if inv is None or (torch.is_tensor(inv) and inv.device != x.device):
+            if int(torch.unique(flat).numel()) == flat.numel() == l * k:      # (one host read per scan order, cached)
+                inv = torch.empty_like(flat)
+                inv[flat] = torch.arange(flat.numel(), device=flat.device)
+            else:
+                inv = False
+            order._flat_inverse = inv
+        if inv is not False:
+            g_xd = g_seq.view(b, k * l, rg)[:, inv]
+        else:
+            g_xd = torch.zeros_like(xdf)
+            g_xd.index_add_(1, flat, g_seq.view(b, k * l, rg))
         gp = hip.slab_sum(gpar)                                                           # (3,K,D): contiguous planes
         return (gx, g_xd.view(b, l, k * rg), g_dtw, gp[2].reshape(-1), gp[0].reshape(-1), gp[1].reshape(-1), None)
 
