@@ -316,6 +316,81 @@ def test_reducer_on_a_one_rank_rccl_group():
         dist.destroy_process_group()
 
 
+class _TinyDP(torch.nn.Module):
+    """a VSSBlock behind the interface train.train_step expects (a list of logit maps; the name holds "encoder")"""
+
+    def __init__(self):
+        super().__init__()
+        import tramba_amd as ta
+        torch.manual_seed(11)
+        self.encoder = ta.VSSBlock(hidden_dim=64, drop_path=0.0, channel_first=True)
+        self.compute_dtype = None
+
+    def forward(self, z):
+        return [self.encoder(z).mean(dim=1, keepdim=True)]
+
+
+def _dp_data(n):
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(n, 64, 24, 24, generator=g), (torch.rand(n, 1, 24, 24, generator=g) > 0.5).float()
+
+
+def _dp_gpu_worker(rank, world, port, out_dir, steps):
+    import os
+    import torch.distributed as dist
+    from tramba_amd import parallel, train
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)                       # both ranks share the one card of the test box
+        model = _TinyDP().to("cuda").train()
+        parallel.broadcast_parameters(model, src=0)
+        red = parallel.GradBucketReducer(model, bucket_mb=0.05)
+        opt = train.get_opt(1e-2, model)
+        x, y = _dp_data(4 * world)
+        xs, ys = x[rank::world].to("cuda"), y[rank::world].to("cuda")
+        for _ in range(steps):
+            train.train_step(model, opt, xs, ys, reducer=red)
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "nbuckets": len(red.buckets),
+                        "bytes": red.bytes_per_step()}, os.path.join(out_dir, "r0.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp2_on_the_device_matches_a_single_process(tmp_path):
+    """Two data-parallel ranks with the model ON THE GPU (both on the one card, gloo carrying the buckets): hooks, bucket
+    fill, all-reduce, .grad views and the fused Adam leave the weights a single process gets from the mean of the two
+    shard losses -- the N > 1 code path of bench.py's training leg, with the device kernels in it."""
+    import socket
+    import torch.multiprocessing as mp
+    from tramba_amd import train
+    steps, world = 3, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_gpu_worker, args=(world, port, str(tmp_path), steps), nprocs=world, join=True)
+    got = torch.load(tmp_path / "r0.pt")
+    assert got["nbuckets"] > 1
+    model = _TinyDP().to(DEV).train()
+    opt = train.get_opt(1e-2, model)
+    x, y = _dp_data(4 * world)
+    x, y = x.to(DEV), y.to(DEV)
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        loss = sum(train.tramba_loss(model(x[r::world]), y[r::world]) for r in range(world)) / world
+        loss.backward()
+        opt.step()
+    assert got["bytes"] == sum(p.numel() * 4 for p in model.parameters())
+    moved = 0.0
+    ref0 = _TinyDP().state_dict()
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(got["sd"][k].numpy(), v.cpu().numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
+        moved = max(moved, float((v.cpu() - ref0[k]).abs().max()))
+    assert moved > 1e-3                                   # the steps did move the weights
+
+
 def test_tramba_v_batch4_consistent(tramba_v):
     """images are independent units: a batch of 4 equals four batches of 1."""
     x = torch.randn(4, 3, 384, 384, generator=torch.Generator().manual_seed(0)).to(DEV)
