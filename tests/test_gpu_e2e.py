@@ -182,3 +182,39 @@ def test_inference_after_graphed_steps_sees_the_current_weights():
         want = fresh(xe)
     for g, w in zip(outs[1], want):
         assert torch.equal(g, w)
+
+
+def test_bench_line_survives_a_stuck_training_leg():
+    """bench.py's contract under the driver: ONE JSON line with the forward result.  A training leg that does not finish (a
+    collective that never completes at N > 1) must not cost that line: with the watchdog's deadline set to almost nothing,
+    rank 0 still prints the forward measurement, train = {"error": ...}, and exits 0."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-latency",
+                          "--no-cpu-baseline", "--train-timeout", "0.05"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["metric"].startswith("images/sec fwd") and line["value"] > 30.0 and line["n_gpus"] == 1
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
+    assert "error" in line["train"] and "not finished" in line["train"]["error"]
+
+
+def test_bench_starts_its_own_ranks_and_reports_the_dp_step():
+    """`python bench.py --gpus 2` (the driver's form at N > 1 when it does not bring its own launcher): the parent starts the
+    ranks as a child torch.distributed.run job, every rank runs a replica of the forward and the data-parallel training
+    step, rank 0 prints ONE line with n_gpus = 2 and the gradient bytes of a step.  Two ranks on the one card of the test
+    box, gloo instead of RCCL (one device cannot host two RCCL ranks)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4",
+                          "--warmup", "1", "--no-latency"], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 30.0 and line["config"]["global_batch"] == 8
+    t = line["train"]
+    assert t["global_batch"] == 16 and t["grad_bytes_per_step"] == t["grad_bucket_bytes"] > 4e8
+    assert t["allreduce"]["allreduce_alone_ms"] > 0 and "dp2" in t["parallelism"] and t["value"] > 0
