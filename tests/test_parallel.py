@@ -218,3 +218,19 @@ def test_compat_shims_import():
                     "Models.SS2D.csms6s", "Models.freq_mamba", "Models.DCT_2D", "Models.modules", "Models.mamba_init",
                     "utils", "utils.loss", "utils.lr"):
             sys.modules.pop(mod, None)
+
+
+def test_bf16_buckets_with_a_bucket_nobody_filled():
+    """world size 1, bf16 buckets small enough that the unused head owns a bucket: finish() must leave its gradients None
+    and must not call a multi-tensor copy on empty lists (round-2 advisor finding)."""
+    from tramba_amd import parallel, train
+    model = _WrapSpare()
+    red = parallel.GradBucketReducer(model, bucket_mb=1e-5, bucket_dtype=torch.bfloat16)
+    assert len(red.buckets) > 4
+    opt = train.get_opt(1e-2, model)
+    x, m = _data(4)
+    for _ in range(2):
+        train.train_step(model, opt, x, m, reducer=red)
+    assert model.never.weight.grad is None and model.spare.weight.grad is None
+    g = model.decoder.weight.grad
+    assert g is not None and g.dtype == torch.float32 and torch.isfinite(g).all()

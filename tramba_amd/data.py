@@ -239,8 +239,10 @@ def train_loader(root, img_size=384, batch_size=4, num_workers=8, rank=0, world_
     import functools
     return DataLoader(ds, batch_size=batch_size, shuffle=sampler is None, sampler=sampler, pin_memory=True,
                       num_workers=num_workers, drop_last=world_size > 1,
-                      # workers started after the process has a HIP context must not be forks of it
-                      multiprocessing_context=("spawn" if num_workers > 0 and torch.cuda.is_initialized() else None),
+                      # workers start at iter() time, by then the process usually holds a HIP context and must not be forked:
+                      # on a GPU build they are always spawned, and kept across epochs (a spawn re-imports torch per worker)
+                      multiprocessing_context=("spawn" if num_workers > 0 and torch.cuda.device_count() > 0 else None),
+                      persistent_workers=num_workers > 0 and torch.cuda.device_count() > 0,
                       worker_init_fn=functools.partial(_seed_worker, rank=rank) if (distinct_workers and num_workers > 0) else None)
 
 

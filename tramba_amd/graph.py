@@ -141,21 +141,25 @@ class GraphedTrainStep:
                 train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        from .modules import _mask_pool
-        _mask_pool.forget_draw()                            # the step's one stochastic-depth draw must be IN the graph
+        from .modules import model_mask_pool
+        pool = model_mask_pool(self.model)
+        pool.forget_draw()                                  # the step's one stochastic-depth draw must be IN the graph
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):                       # records, executes nothing
             loss = train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
-        _mask_pool.forget_draw()                            # (the table drawn during capture lives in the graph's pool)
+        keep_alive = (pool.probs, pool.buf)                 # the keep-probabilities the captured bernoulli / divide nodes read
+        pool.forget_draw()                                  # (the table drawn during capture lives in the graph's pool)
         self._restore(saved)
         torch.cuda.set_rng_state(rng, dev)
-        return graph, sx, sy, loss
+        return graph, sx, sy, loss, keep_alive
 
     def __call__(self, images, label):
         if not self.model.training:
             raise RuntimeError("GraphedTrainStep: the model is in eval mode (an evaluation callback must switch it back "
                                "with model.train() before the next step)")
-        lrs = self._lrs()
+        # learning rates AND the set of trainable parameters are baked into a capture (freeze_encoder / unfreeze_encoder
+        # flip requires_grad: the eager step follows them, a stale graph would keep updating frozen weights)
+        lrs = self._lrs() + tuple(p.requires_grad for g in self.opt.param_groups for p in g["params"])
         if lrs != self._lr_key:
             self._graphs.clear()
             self._lr_key = lrs
@@ -163,7 +167,7 @@ class GraphedTrainStep:
         entry = self._graphs.get(key)
         if entry is None:
             entry = self._graphs[key] = self._capture(images, label)
-        graph, sx, sy, loss = entry
+        graph, sx, sy, loss = entry[:4]
         sx.copy_(images, non_blocking=True)
         sy.copy_(label, non_blocking=True)
         graph.replay()

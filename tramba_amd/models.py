@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import hip
 from .modules import (FinalPatchExpand_X4, FreqBlockv6, LayerNorm2d, Linear2d, MultiScaleDecoderBlock, PatchExpand,
-                      VSSMEncoder, _infer, _init_weights, _mask_pool, _need_device, from_cl, load_pretrained_Base,
+                      VSSMEncoder, _infer, _init_weights, model_mask_pool, _need_device, from_cl, load_pretrained_Base,
                       to_cl)
 from .ops import CrossMerge_Line, CrossScan_Line
 
@@ -196,7 +196,7 @@ class BaseUMamba(nn.Module):
     def forward(self, x):
         _need_device(x)
         if self.training:
-            _mask_pool.begin_step()        # one stochastic-depth draw per forward (modules._MaskPool)
+            model_mask_pool(self).begin_step()        # one stochastic-depth draw per forward (modules._MaskPool)
         if self.compute_dtype is not None:
             x = x.to(self.compute_dtype)
         if OVERLAP_BRANCHES and not torch.is_grad_enabled() and type(self.decoder) is VSSMDecoder:
@@ -324,7 +324,7 @@ class BaseUMambaEnc(nn.Module):
     def forward(self, x):
         _need_device(x)
         if self.training:
-            _mask_pool.begin_step()
+            model_mask_pool(self).begin_step()
         if self.compute_dtype is not None:
             x = x.to(self.compute_dtype)
         if self.kind == "R":

@@ -271,7 +271,20 @@ class _MaskPool:
         return self.buf[ent[0]]
 
 
-_mask_pool = _MaskPool()
+_mask_pool = _MaskPool()        # DropPath instances used outside a model that owns a pool (bare blocks in tests / scripts)
+
+
+def model_mask_pool(model):
+    """The stochastic-depth table of ONE model: created at its first training forward and handed to every DropPath below it,
+    so that two training models in a process neither share draws nor reallocate the table a captured hipGraph of the other
+    one reads (GraphedTrainStep keeps the tensors of its capture alive on top of that)."""
+    pool = model.__dict__.get("_tramba_mask_pool")
+    if pool is None:
+        pool = model.__dict__["_tramba_mask_pool"] = _MaskPool()
+        for m in model.modules():
+            if isinstance(m, DropPath):
+                m.__dict__["_pool"] = pool
+    return pool
 
 
 class DropPath(nn.Module):
@@ -286,7 +299,8 @@ class DropPath(nn.Module):
         keep = 1.0 - self.drop_prob
         shape = (x.shape[0],) + (1,) * (x.ndim - 1)
         if x.is_cuda:
-            return _mask_pool.take(self, keep, x.shape[0], x.dtype, x.device).view(shape)
+            pool = self.__dict__.get("_pool") or _mask_pool
+            return pool.take(self, keep, x.shape[0], x.dtype, x.device).view(shape)
         return x.new_empty(shape).bernoulli_(keep).div_(keep)
 
     def forward(self, x):
@@ -484,12 +498,16 @@ class _LinearGeluPairTrainCL(torch.autograd.Function):
         ctx.wa_t = _lowp_t(w, x.dtype)
         ctx.wdtype, ctx.has_bias, ctx.xshape = w.dtype, b is not None, x.shape
         h, a = hip.linear_dual_cl(x2, wa, None if b is None else b.detach().float().contiguous(), hip.ACT_GELU)
-        ctx.mark_non_differentiable(a)
         shape = x.shape[:-1] + (wa.shape[0],)
-        return h.view(shape), a.view(shape)
+        h, a = h.view(shape), a.view(shape)
+        ctx.mark_non_differentiable(a)          # on the tensor that is RETURNED ...
+        ctx.set_materialize_grads(False)        # ... and no (M, 4C) zero gradient is materialised for it in backward
+        return h, a
 
     @staticmethod
     def backward(ctx, gh, _ga):
+        if gh is None:
+            return None, None, None
         x2, wa = ctx.saved_tensors
         gx = gw = gb = None
         gy2 = gh.reshape(-1, gh.shape[-1])

@@ -184,7 +184,9 @@ class GradBucketReducer:
             views = self._views[bi]
             if self._wide is not None:
                 wide = self._wide[bi]
-                torch._foreach_copy_([w for w, h in zip(wide, have) if h], [v for v, h in zip(views, have) if h])
+                dst = [w for w, h in zip(wide, have) if h]
+                if dst:       # (a bucket none of whose parameters produced a gradient: world 1 or find_unused)
+                    torch._foreach_copy_(dst, [v for v, h in zip(views, have) if h])
                 views = wide
             for p, v, h in zip(bucket, views, have):
                 p.grad = v if h else None
