@@ -151,12 +151,14 @@ int tramba_ss2d_group_stride(int r);
  * workspace == NULL the chained single-pass kernel (one workgroup per sequence) runs instead.
  * states (training; NULL otherwise, requires ys_dtype == dtype): tramba_ss2d_scan_bwd_workspace() bytes that receive the
  * recurrence state entering every 32-position tile, (B, K, ceil(L/32) + 8, D) f32 -- handed to tramba_ss2d_scan_bwd_cl as
- * its workspace with have_states = 1, the backward skips the sweep that would recompute them. */
+ * its workspace with have_states = 1, the backward skips the sweep that would recompute them.
+ * a_log (training, chained forms): `A` holds the PARAMETER A_logs (K*D) and the kernel forms A = -exp(A_logs) itself
+ * (vmamba.py:246) -- no exp / negation launch per block and step. */
 size_t tramba_ss2d_scan_workspace(int batch, int l, int d, int k);
 int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32_t *table, const float *dt_w,
                         const float *dt_bias, const float *A, const float *Ds, void *ys, void *workspace,
                         size_t workspace_bytes, int batch, int l, int d, int k, int r, int dtype,
-                        int ys_dtype, float *states, void *stream);
+                        int ys_dtype, float *states, int a_log, void *stream);
 /* Training: backward of tramba_ss2d_scan_cl + the merge that follows it.  gym (B, L, D), f32 or dtype (gym_dtype), is the
  * gradient of the MERGED map (CrossMerge output, before out_norm); the kernel gathers it through `table`.  Outputs, in SEQUENCE
  * order like ys: gu (B,K,L,D) dtype = dL/d(gathered x) -- merge it with tramba_ss2d_merge_norm_cl(eps < 0) to get
@@ -170,11 +172,37 @@ int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const int32_t *tab
                             const float *dt_bias, const float *A, const float *Ds, const void *gym, void *gu,
                             void *graw, float *gB, float *gC, int bc_stride, float *gpar, void *workspace,
                             size_t workspace_bytes, int have_states, int batch, int l, int d, int k, int r, int dtype,
-                            int gym_dtype, void *stream);
+                            int gym_dtype, int flags, void *stream);
+/* flags of tramba_ss2d_scan_bwd_cl:
+ *   1  `A` holds A_logs (as a_log of the forward) and gpar's first plane is dL/dA_logs (= dL/dA * A)
+ *   2  gB / gC are (B, K, ceil(D/32), L) f32 tables of per-channel-tile partial sums, every element written by exactly one
+ *      wave: no zero fill and no atomics (reproducible); tramba_ss2d_bwd_prep_cl adds the partials in a fixed order.
+ *      bc_stride is ignored. */
+#define TRAMBA_SCAN_BWD_A_LOG 1
+#define TRAMBA_SCAN_BWD_BC_PARTIALS 2
+/* Training, after tramba_ss2d_scan_bwd_cl(flags & 2), r = dt_rank, R8 = 8*ceil(r/8), RG = R8 + 4:
+ *   ranks (B, K, L, R8) dtype = xdbl[b, table[k][i], k*RG .. k*RG + R8): the dt-rank rows in SEQUENCE order, the operand of
+ *         the dt_projs_weight gradient (tramba_wgrad_cl with groups = K);
+ *   gseq  (B, K, L, RG) f32: columns R8, R8 + 1 = dL/dB, dL/dC summed over the channel tiles (fixed order), R8 + 2, R8 + 3 = 0;
+ *         the rank columns 0 .. r are written afterwards by tramba_rows_gemm_cl(graw, dt_projs_weight^T, ldy = RG). */
+int tramba_ss2d_bwd_prep_cl(const float *xdbl, const int32_t *table, const float *bpart, const float *cpart, void *ranks,
+                            float *gseq, int batch, int l, int k, int r, int ctiles, int dtype, void *stream);
+/* out (B, L, K*RG) dtype = the x_dbl-row gradients of gseq (B, K, L, RG) f32 brought back from sequence to spatial order:
+ * out[b, p, k*RG + j] = sum over the entries (k, i) of pixel p in the inverse table of gseq[b, k, i, j] for j < r and
+ * j in {R8, R8 + 1}, 0 elsewhere -- a gather-sum in CSR order (deterministic; the Helix lines revisit pixels), the adjoint of
+ * the scan kernels' gather of x_dbl rows, cast to the dtype the x_proj gradient GEMMs read. */
+int tramba_ss2d_bwd_assemble_cl(const float *gseq, const int32_t *inv_ptr, const int32_t *inv_idx, void *out, int batch,
+                                int l, int k, int r, int dtype, void *stream);
 /* y[b,p,:] = act(LayerNorm_D(sum_{e in inv[p]} ys[b, e/L, e%L, :]));  y: (B, L, D) dtype.
  * eps < 0: the plain sum (CrossMerge alone), ln_w / ln_b / act ignored. */
 int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr, const int32_t *inv_idx,
                               const float *ln_w, const float *ln_b, void *y, int batch, int l, int d,
+                              int k, float eps, int act, int ys_dtype, int dtype, void *stream);
+/* The same merge with the epilogue of SS2D's input gradient (training; eps < 0 only): y = (sum + addend) * silu'(zpre),
+ * addend (B, L, D) dtype or NULL = the x_proj branch's gradient, zpre (B, L, D) dtype = the pre-activation of the SiLU in front
+ * of the core (vmamba.py:283-285). */
+int tramba_ss2d_merge_grad_cl(const void *ys, const int32_t *inv_ptr, const int32_t *inv_idx, const float *ln_w,
+                              const float *ln_b, void *y, const void *addend, const void *zpre, int batch, int l, int d,
                               int k, float eps, int act, int ys_dtype, int dtype, void *stream);
 
 /* ------------------------------------------------------------------ element / stencil kernels, channels-last */
@@ -187,6 +215,19 @@ int tramba_layernorm_cl(const void *x, const float *w, const float *b, void *y, 
 int64_t tramba_layernorm_bwd_parts(int64_t rows, int c, int dtype);
 int tramba_layernorm_bwd_cl(const void *x, const void *dy, const float *w, void *dx, float *part, int64_t rows,
                             int c, float eps, int dtype, void *stream);
+/* The same on the residual stream of a block (vmamba.py:384-396 under autograd): dx = LayerNorm-backward + gres (the gradient
+ * that reaches the block input through the skip connection; NULL: none), and dxm (NULL: not wanted) = dx * mask[row /
+ * rows_per_sample] -- the gradient of the PREVIOUS residual branch under stochastic depth (mask (B) f32 = keep / keep_prob
+ * per sample; NULL: 1).  One pass where autograd issued the LayerNorm backward, an add and a multiply. */
+int tramba_layernorm_bwd_res_cl(const void *x, const void *dy, const float *w, void *dx, float *part, const void *gres,
+                                const float *mask, int64_t rows_per_sample, void *dxm, int64_t rows, int c, float eps,
+                                int dtype, void *stream);
+/* Residual add + stochastic depth + LayerNorm of the training path in one pass: xsum = x + y * mask[row / rows_per_sample]
+ * (y NULL: no add, xsum unused), n = LayerNorm_C(xsum), n_act (NULL: not wanted) = act(n) -- the pre-activation / activation
+ * pair a following `Linear(act(.))` needs under autograd.  x, y, xsum, n, n_act: (rows, C) dtype; w, b, mask f32. */
+int tramba_add_layernorm_cl(const void *x, const void *y, const float *mask, int64_t rows_per_sample, const float *w,
+                            const float *b, void *xsum, void *n, void *n_act, int64_t rows, int c, float eps, int act,
+                            int dtype, void *stream);
 /* x: (B, H, W, P*P*C) -> y: (B, H*P, W*P, C) with y[b,hP+p1,wP+p2,:] = LN(x[b,h,w,(p1*P+p2)*C : +C]). */
 int tramba_shuffle_norm_cl(const void *x, const float *w, const float *b, void *y, int batch, int h,
                            int wd, int c, int p, float eps, int dtype, void *stream);
@@ -222,6 +263,17 @@ int tramba_upsample_bilinear_bwd(const float *gout, float *gin, int planes, int 
 /* depth-wise ks x ks, stride 1, "same" padding, y = act(conv(x) + bt). */
 int tramba_dwconv_cl(const void *x, const float *wt, const float *bt, void *y, int batch, int h,
                      int wd, int c, int ks, int act, int dtype, void *stream);
+/* Training forms of the same stencil: y_pre (NULL: not wanted) also receives conv(x) + bt BEFORE the activation (the backward
+ * of SiLU / GELU needs it; y = act of the value as stored); flip_taps = 1 mirrors the taps through the centre -- the input
+ * gradient of the stencil is tramba_dwconv_dual_cl(gy, wt, zero bias, NULL, gx, ..., ACT_NONE, 1). */
+int tramba_dwconv_dual_cl(const void *x, const float *wt, const float *bt, void *y_pre, void *y, int batch, int h, int wd,
+                          int c, int ks, int act, int flip_taps, int dtype, void *stream);
+/* The weight gradient of a stencil in the parameters' own layout: gwt (ks*ks + 1, C) f32 = tap-major taps + bias row (the
+ * summed output of tramba_dwconv_wgrad_cl) -> g7 (C, ks*ks); with g5 / g3 non-NULL (ks = 7) the folded multi-scale stencil's
+ * gradient restricted to the 5x5 / 3x3 parameters' supports (C, 25) / (C, 9) (the adjoint of tramba_dw_pack's fold); gb
+ * (nb, C) or NULL = nb copies of the bias row. */
+int tramba_dw_unpack_grad(const float *gwt, float *g7, float *g5, float *g3, float *gb, int nb, int c, int ks,
+                          void *stream);
 /* Training: gradients of the same stencil w.r.t. its tap-major weights and bias (what autograd computes for
  * nn.Conv2d(groups=C), vmamba.py:301, 595-603).  part (P, ks*ks + 1, C) f32, P = tramba_dwconv_wgrad_parts(batch, h, wd,
  * ks): one partial row per workgroup (image, row band, column range), planes 0..ks*ks-1 = taps, last plane = bias; the

@@ -1,0 +1,171 @@
+"""GPU parity tests of the TRAINING path against autograd through the CPU oracle (oracle/model.py + the fp64 C selective
+scan with its hand-derived backward, oracle/selective_scan.py): what `loss.backward()` computes in the reference
+(train.py:74-89; Models/SS2D/csms6s.py:914-923 for the scan), parameter by parameter and element by element."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import model as om
+from oracle import ops as oo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _oracle_grads(fn, sd, x, gy=None, label=None):
+    """gradients of fn(SD(sd), x) (or of the training loss when `label` is given) w.r.t. x and every floating entry of sd, fp64"""
+    sd64 = {k: (v.detach().cpu().double().requires_grad_(v.is_floating_point()) if v.is_floating_point() else v.cpu())
+            for k, v in sd.items()}
+    x64 = x.detach().cpu().double().requires_grad_()
+    out = fn(sd64, x64)
+    if label is not None:
+        loss = oo.tramba_loss(out, label.cpu().double())
+        loss.backward()
+    else:
+        out.backward(gy.cpu().double())
+    return x64.grad, {k: v.grad for k, v in sd64.items() if torch.is_tensor(v) and v.requires_grad}, out
+
+
+def _rel_l2(got, want):
+    want = want.double()
+    return float((got.double().cpu() - want).norm() / want.norm().clamp_min(1e-30))
+
+
+BLOCK_ORACLES = {
+    "ss2d_raster": lambda sd, x: om.ss2d(om.SD(sd), x, "raster"),
+    "vssblock": lambda sd, x: om.vss_block(om.SD(sd), x),
+    "freqblock": lambda sd, x: om.freq_block(om.SD(sd), x),
+    "helixblock": lambda sd, x: om.multiscale_decoder_block(om.SD(sd), x),
+    "freqblock24": lambda sd, x: om.freq_block(om.SD(sd), x),
+    "helixblock24": lambda sd, x: om.multiscale_decoder_block(om.SD(sd), x),
+    "patchexpand": lambda sd, x: om._expand_shuffle_norm(om.SD(sd), x, 2),
+    "finalexpand": lambda sd, x: om._expand_shuffle_norm(om.SD(sd), x, 4),
+    "freqexpand": lambda sd, x: om._expand_shuffle_norm(om.SD(sd), x, 2),
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag", list(BLOCK_ORACLES))
+def test_block_parameter_gradients_elementwise_against_oracle_autograd(tag, dtype):
+    """every parameter gradient (and the input gradient) of the nine blocks of the reference goldens, element-wise against
+    autograd through the oracle (the goldens themselves hold only two digests per parameter gradient).  fp32: max abs error
+    <= 2e-3 of the tensor's largest entry; bf16 (activations; fp32 master weights): relative L2 error <= 6e-2."""
+    from test_gpu_model import _blocks, _load_synth
+    ctor, shape = _blocks()[tag]
+    m = _load_synth(ctor())
+    x = synth.synth_input("g4_" + tag, shape)
+    gy = None
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    xin = x.to(DEV).to(dtype).requires_grad_()
+    if dtype != torch.float32:
+        # the block in 16-bit activations: weights stay fp32 masters, the training path casts them per call
+        x = xin.detach().float().cpu()
+    y = m(xin)
+    gy = synth.synth_input("g4_gy_" + tag, tuple(y.shape))
+    params = list(m.named_parameters())
+    grads = torch.autograd.grad(y, [xin] + [p for _, p in params], gy.to(DEV).to(y.dtype))
+    gx_ref, gp_ref, y_ref = _oracle_grads(BLOCK_ORACLES[tag], sd, x, gy=gy)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(y.detach().cpu().double().numpy(), y_ref.detach().numpy(), rtol=1e-3, atol=1e-4)
+    worst = {}
+    for name, g, ref in [("input", grads[0], gx_ref)] + [(n, g, gp_ref[n]) for (n, _), g in zip(params, grads[1:])]:
+        assert g.shape == ref.shape, name
+        if dtype == torch.float32:
+            err = float((g.double().cpu() - ref).abs().max())
+            assert err <= 2e-3 * float(ref.abs().max()) + 1e-7, (name, err, float(ref.abs().max()))
+        else:
+            worst[name] = _rel_l2(g, ref)
+    if worst:
+        bad = {n: e for n, e in worst.items() if e > 6e-2}
+        assert not bad, bad
+
+
+@pytest.fixture(scope="module")
+def tramba_v_grad_oracle():
+    """Tramba-V 384x384, batch 1, reference init under seed 0, stochastic depth off: the loss gradient of every parameter
+    by autograd through the fp64 CPU oracle (computed once for the fp32 and the bf16 test)."""
+    import tramba_amd as ta
+    torch.manual_seed(0)
+    m = ta.bulid_model(use_pretrain=False, img_size=384)
+    for mod in m.modules():
+        if isinstance(mod, ta.DropPath):
+            mod.drop_prob = 0.0
+    x = torch.randn(1, 3, 384, 384, generator=torch.Generator().manual_seed(0))
+    label = (torch.rand(1, 1, 384, 384, generator=torch.Generator().manual_seed(1)) > 0.7).float()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    _, gp, outs = _oracle_grads(lambda s, xx: om.tramba_v(s, xx), sd, x, label=label)
+    return m, x, label, gp
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tramba_v_parameter_gradients_against_oracle_autograd(tramba_v_grad_oracle, dtype):
+    """the full training graph (train.py:74-89: forward, deep-supervision loss, backward) on Tramba-V: EVERY parameter's
+    gradient against the oracle's.  fp32: relative L2 error per tensor <= 1e-3.  bf16 activations: cosine >= 0.999 and
+    norm ratio within 2 % per tensor."""
+    from tramba_amd import train
+    m, x, label, gp_ref = tramba_v_grad_oracle
+    m = m.to(DEV).train()
+    m.compute_dtype = None if dtype == torch.float32 else dtype
+    m.zero_grad(set_to_none=True)
+    loss = train.tramba_loss(m(x.to(DEV)), label.to(DEV))
+    loss.backward()
+    bad = {}
+    names = [n for n, _ in m.named_parameters()]
+    assert set(names) == set(gp_ref)
+    for n, p in m.named_parameters():
+        g, ref = p.grad.double().cpu(), gp_ref[n]
+        assert g.shape == ref.shape, n
+        rn = float(ref.norm())
+        if rn == 0.0:
+            assert float(g.norm()) == 0.0, n
+            continue
+        if dtype == torch.float32:
+            e = float((g - ref).norm()) / rn
+            if e > 1e-3:
+                bad[n] = e
+        else:
+            cos = float((g * ref).sum() / (g.norm() * ref.norm()).clamp_min(1e-300))
+            ratio = float(g.norm()) / rn
+            if cos < 0.999 or abs(ratio - 1.0) > 0.02:
+                bad[n] = (round(cos, 5), round(ratio, 4))
+    assert not bad, (len(bad), dict(list(bad.items())[:12]))
+    m.compute_dtype = None
+
+
+def test_helix_scan_at_the_benchmarked_launch():
+    """The launch bench.py's `roofline` object times -- Helix-SS2D at 96x96, K = 8, D = 256, B = 4, bf16 with 2-byte `ys`
+    (BASELINE config 2's decoder stage; vmamba.py:230-257 + csms6s.py:161-216) -- against the fp64 oracle directly: the
+    LDS-DMA form forced (tune knob 3) AND the library's own choice at this shape, which must be bit-identical to it."""
+    from tramba_amd import hip as H
+    b, h, d, r, k, fam = 4, 96, 256, 8, 8, "helix"
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(h * d + k)
+    x = torch.randn(b, d, h, h, generator=g).to(dtype)
+    wx = (torch.randn(k, r + 2, d, generator=g) * d ** -0.5).to(dtype)
+    wdt = torch.randn(k, d, r, generator=g) * r ** -0.5
+    dtb = torch.randn(k, d, generator=g) * 0.5 - 2.0
+    a_logs = torch.log(0.5 + torch.rand(k * d, 1, generator=g))
+    ds = 1 + 0.1 * torch.randn(k * d, generator=g)
+    lw, lb = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    y = oo.ss2d_core(x.double(), wx.double(), wdt.double(), dtb.double(), a_logs.double(), ds.double(), fam)
+    want = torch.nn.functional.gelu(oo.layernorm2d(y, lw.double(), lb.double())).permute(0, 2, 3, 1)
+    dev = torch.device(DEV)
+    order = H.scan_order(fam, h, h, dev)
+    xc = x.permute(0, 2, 3, 1).contiguous().view(b, h * h, d).to(dev)
+    xdbl = H.linear_cl(xc, H.pad_x_proj_weight(wx.to(dev)), out_dtype=torch.float32)
+    args = (xc, xdbl, order, wdt.to(dev), dtb.reshape(-1).to(dev), (-torch.exp(a_logs)).reshape(-1).to(dev), ds.to(dev), dtype)
+    outs = []
+    for form in (3, 0):
+        H.tune_set(H.TUNE_SCAN_FORM, form)
+        try:
+            ys = H.ss2d_scan_cl(*args, segmented=True)
+        finally:
+            H.tune_set(H.TUNE_SCAN_FORM, 0)
+        out = H.ss2d_merge_norm_cl(ys, order, lw.to(dev), lb.to(dev), 1e-5, 2, dtype)
+        np.testing.assert_allclose(out.view(b, h, h, d).cpu().double().numpy(), want.numpy(), rtol=4e-2, atol=4e-2)
+        outs.append(ys)
+    assert torch.equal(outs[0], outs[1])   # the library's choice at the benchmarked shape IS the LDS-DMA form
+    # and the merged, normalised map as a whole: RMS error against fp64 below 1 % of the map's RMS
+    err = (out.view(b, h, h, d).cpu().double() - want)
+    assert float(err.pow(2).mean().sqrt()) <= 1e-2 * float(want.pow(2).mean().sqrt())

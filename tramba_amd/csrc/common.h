@@ -147,6 +147,12 @@ __device__ __forceinline__ float gelu_gradf_(float x)
     const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.5f * x * x * 1.44269504088896f);
     return fmaf(x, pdf, cdf);
 }
+// d/dx of SiLU: s (1 + x (1 - s)), s = sigmoid(x)
+__device__ __forceinline__ float silu_gradf_(float x)
+{
+    const float sg = sigmoidf_(x);
+    return sg * fmaf(x, 1.f - sg, 1.f);
+}
 // how a GEMM epilogue combines its activated value with the `residual` operand
 __device__ __forceinline__ float combine_residual(float o, float r, int act)
 {

@@ -229,8 +229,13 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void layernorm_bwd_cl_kernel(const T *__restrict__ x, const T *__restrict__ dy,
                                                               const float *__restrict__ w, T *__restrict__ dx,
                                                               float *__restrict__ part, long rows, int C, float eps,
-                                                              int rpw)
+                                                              int rpw, const T *__restrict__ gres,
+                                                              const float *__restrict__ mask, long rps,
+                                                              T *__restrict__ dxm)
 {
+    // gres / mask / dxm (round 3, the residual stream of a block): dx <- dx + gres, the gradient reaching the block input
+    // through the skip connection added here instead of by a separate launch; dxm = that sum * mask[sample], the gradient
+    // of the PREVIOUS residual branch under stochastic depth (x = x_prev + branch * mask) -- one pass, two outputs.
     extern __shared__ float ln_red[];          // [4 waves][2 C]: the waves' (dgamma, dbeta) rows, folded before they leave
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -289,7 +294,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cl_kernel(const T *__restri
                     float o[V];
 #pragma unroll
                     for (int v = 0; v < V; ++v) o[v] = rstd * (gv[it][v] * gam[it][v] - s1 - xv[it][v] * s2);
+                    if (gres) {
+                        float rv[V];
+                        load_pack<T, V>(gres + r * C + c0, rv);
+#pragma unroll
+                        for (int v = 0; v < V; ++v) o[v] += rv[v];
+                    }
                     store_pack<T, V>(dx + r * C + c0, o);
+                    if (dxm) {
+                        const float m = mask ? mask[r / rps] : 1.f;
+#pragma unroll
+                        for (int v = 0; v < V; ++v) o[v] = Cvt<T>::to_f(Cvt<T>::from_f(o[v])) * m;
+                        store_pack<T, V>(dxm + r * C + c0, o);
+                    }
                 }
             }
     }
@@ -320,7 +337,9 @@ template <typename T, int V, int LPR>
 __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const T *__restrict__ x, const T *__restrict__ dy,
                                                                 const float *__restrict__ w, T *__restrict__ dx,
                                                                 float *__restrict__ part, long rows, int C, float eps,
-                                                                int rpw)
+                                                                int rpw, const T *__restrict__ gres,
+                                                                const float *__restrict__ mask, long rps,
+                                                                T *__restrict__ dxm)
 {
     constexpr int RPW = kWave / LPR;
     __shared__ float red[4][2 * LPR * V];     // the four waves' (dgamma, dbeta) rows, folded before they leave the block
@@ -387,7 +406,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const T *__rest
             float o_[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) o_[v] = rstd * (gv[v] * gam[v] - s1 - xv[v] * s2);
+            if (gres) {
+                float rv[V];
+                load_pack<T, V>(gres + r * C + c0, rv);
+#pragma unroll
+                for (int v = 0; v < V; ++v) o_[v] += rv[v];
+            }
             store_pack<T, V>(dx + r * C + c0, o_);
+            if (dxm) {
+                const float m = mask ? mask[r / rps] : 1.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) o_[v] = Cvt<T>::to_f(Cvt<T>::from_f(o_[v])) * m;
+                store_pack<T, V>(dxm + r * C + c0, o_);
+            }
         }
     }
     // fold the RPW row slots of the wave (lanes with equal `sub`), then slot 0 writes the partial row
@@ -472,7 +503,8 @@ __global__ __launch_bounds__(256) void dw_pack_kernel(const float *__restrict__ 
 template <typename T, int KS, int V, int TW>
 __global__ __launch_bounds__(256) void dwconv_cl_kernel(const T *__restrict__ x, const float *__restrict__ wt,
                                                        const float *__restrict__ bt, T *__restrict__ y, int B,
-                                                       int H, int W, int C, int act, long nthreads)
+                                                       int H, int W, int C, int act, long nthreads,
+                                                       T *__restrict__ ypre = nullptr, int flip = 0)
 {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= nthreads) return;
@@ -501,7 +533,8 @@ __global__ __launch_bounds__(256) void dwconv_cl_kernel(const T *__restrict__ x,
         if (hy < 0 || hy >= H) continue;
         float wr[KS][V];
 #pragma unroll
-        for (int dx = 0; dx < KS; ++dx) load_pack<float, V>(wt + (long)(dy * KS + dx) * C + c0, wr[dx]);
+        for (int dx = 0; dx < KS; ++dx)   // flip: the taps mirrored through the centre (the stencil's adjoint)
+            load_pack<float, V>(wt + (long)(flip ? KS * KS - 1 - (dy * KS + dx) : dy * KS + dx) * C + c0, wr[dx]);
         float xin[TW + KS - 1][V];
 #pragma unroll
         for (int i = 0; i < TW + KS - 1; ++i) {
@@ -525,6 +558,11 @@ __global__ __launch_bounds__(256) void dwconv_cl_kernel(const T *__restrict__ x,
     for (int t = 0; t < TW; ++t) {
         if (w0 + t < W) {
             float o[V];
+            if (ypre) {   // training: the pre-activation leaves too, and the activation is taken of it AS STORED
+                store_pack<T, V>(ypre + (long)b * H * W * C + c0 + ((long)h * W + w0 + t) * C, acc[t]);
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[t][v] = Cvt<T>::to_f(Cvt<T>::from_f(acc[t][v]));
+            }
 #pragma unroll
             for (int v = 0; v < V; ++v) o[v] = apply_act(acc[t][v], act);
             store_pack<T, V>(yb + ((long)h * W + w0 + t) * C, o);
@@ -574,8 +612,10 @@ __device__ __forceinline__ void dw_cvt4(const DwRaw<T> &raw, float (&out)[4])
 template <typename T, int KS, int TW>
 __global__ __launch_bounds__(256) void dwconv4_cl_kernel(const T *__restrict__ x, const float *__restrict__ wt,
                                                         const float *__restrict__ bt, T *__restrict__ y, int B,
-                                                        int H, int W, int C, int act)
+                                                        int H, int W, int C, int act, T *__restrict__ ypre, int flip)
 {
+    // flip (training): the taps mirrored through the centre -- the input gradient of the stencil is the same stencil with
+    // flipped taps, read in place instead of from a flipped copy made per call
     constexpr int V = 4, R = KS / 2, NI = TW + KS - 1;
     // grid (x: channel-group x column-tile items of one row, y: row, z: image): no 64-bit index arithmetic (the
     // flat-index form spent ~3k cycles per wave in three emulated 64-bit divisions)
@@ -638,7 +678,8 @@ __global__ __launch_bounds__(256) void dwconv4_cl_kernel(const T *__restrict__ x
 #pragma unroll
         for (int dx = 0; dx < KS; ++dx) {
             const dw_v4f v = __builtin_bit_cast(
-                dw_v4f, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, (unsigned)(dy * KS + dx) * (unsigned)C * 4u, 0));
+                dw_v4f, __builtin_amdgcn_raw_buffer_load_b128(
+                            rw, woff, (unsigned)(flip ? KS * KS - 1 - (dy * KS + dx) : dy * KS + dx) * (unsigned)C * 4u, 0));
             const dw_v2f w01 = {v.x, v.y}, w23 = {v.z, v.w};
 #pragma unroll
             for (int t = 0; t < TW; ++t) {
@@ -661,8 +702,13 @@ __global__ __launch_bounds__(256) void dwconv4_cl_kernel(const T *__restrict__ x
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
         if (w0 + t < W) {
-            float o[V] = {apply_act(acc[t][0].x, act), apply_act(acc[t][0].y, act), apply_act(acc[t][1].x, act),
-                          apply_act(acc[t][1].y, act)};
+            float p[V] = {acc[t][0].x, acc[t][0].y, acc[t][1].x, acc[t][1].y};
+            if (ypre) {   // training (block-uniform): the pre-activation leaves too, the activation is taken of it AS STORED
+                store_pack<T, V>(ypre + (long)b * H * W * C + c0 + ((long)h * W + w0 + t) * C, p);
+#pragma unroll
+                for (int v = 0; v < V; ++v) p[v] = Cvt<T>::to_f(Cvt<T>::from_f(p[v]));
+            }
+            float o[V] = {apply_act(p[0], act), apply_act(p[1], act), apply_act(p[2], act), apply_act(p[3], act)};
             store_pack<T, V>(yb + ((long)h * W + w0 + t) * C, o);
         }
     }
@@ -821,7 +867,7 @@ __global__ __launch_bounds__(dwg_waves(KS) * kWave) void dwconv_wgrad_cl_kernel(
 
 template <typename T, int KS>
 static int launch_dw(const void *x, const float *wt, const float *bt, void *y, int B, int H, int W, int C, int act,
-                     hipStream_t s)
+                     hipStream_t s, void *ypre = nullptr, int flip = 0)
 {
     // columns per thread: the stencil is L1/TA-bandwidth bound (every thread re-reads the ks*ks taps and ks rows
     // of TW + ks - 1 pixels), so the wide 7x7 amortises them over 8 outputs; 3x3 / 5x5 keep 4 (more threads)
@@ -832,11 +878,12 @@ static int launch_dw(const void *x, const float *wt, const float *bt, void *y, i
     dim3 grid((unsigned)((nthreads + 255) / 256)), block(256);
 #define GO_(V_)                                                                                            \
     hipLaunchKernelGGL((dwconv_cl_kernel<T, KS, V_, TW>), grid, block, 0, s, (const T *)x, wt, bt, (T *)y, B, H, W, \
-                       C, act, nthreads)
+                       C, act, nthreads, (T *)ypre, flip)
     // buffer-addressed kernel: 4 channels per lane, every wave inside one image, 32-bit byte offsets
     if (v == 4 && H <= 65535 && B <= 65535 && (double)H * W * C * sizeof(T) < 2147483648.0) {
         dim3 g3((unsigned)(((long)(C / 4) * wtiles + 255) / 256), (unsigned)H, (unsigned)B);
-        hipLaunchKernelGGL((dwconv4_cl_kernel<T, KS, TW>), g3, block, 0, s, (const T *)x, wt, bt, (T *)y, B, H, W, C, act);
+        hipLaunchKernelGGL((dwconv4_cl_kernel<T, KS, TW>), g3, block, 0, s, (const T *)x, wt, bt, (T *)y, B, H, W, C, act,
+                           (T *)ypre, flip);
         TRAMBA_LAUNCH_CHECK();
         return TRAMBA_OK;
     }
@@ -893,7 +940,17 @@ extern "C" int64_t tramba_layernorm_bwd_parts(int64_t rows, int c, int dtype)
 extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const float *w, void *dx, float *part,
                                        int64_t rows, int c, float eps, int dtype, void *stream)
 {
+    return tramba_layernorm_bwd_res_cl(x, dy, w, dx, part, nullptr, nullptr, 0, nullptr, rows, c, eps, dtype, stream);
+}
+
+extern "C" int tramba_layernorm_bwd_res_cl(const void *x, const void *dy, const float *w, void *dx, float *part,
+                                           const void *gres, const float *mask, int64_t rows_per_sample, void *dxm,
+                                           int64_t rows, int c, float eps, int dtype, void *stream)
+{
     TRAMBA_CHECK(x && dy && w && dx && part, "layernorm_bwd_cl: null tensor");
+    TRAMBA_CHECK(!mask || rows_per_sample > 0, "layernorm_bwd_cl: rows_per_sample must be positive with a mask");
+    TRAMBA_CHECK((!gres || aligned16(gres)) && (!dxm || aligned16(dxm)), "layernorm_bwd_cl: tensors must be 16-byte aligned");
+    const long rps = rows_per_sample > 0 ? (long)rows_per_sample : 1;
     TRAMBA_CHECK(rows > 0 && c > 0, "layernorm_bwd_cl: empty shape");
     TRAMBA_CHECK(aligned16(x) && aligned16(dy) && aligned16(dx), "layernorm_bwd_cl: tensors must be 16-byte aligned");
     const int v = (c % 4 == 0) ? 4 : ((c % 2 == 0) ? 2 : 1);
@@ -909,7 +966,7 @@ extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const floa
         while (lpr < c / vm) lpr <<= 1;
 #define GOB_(T, V_, L_)                                                                                             \
     hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, V_, L_>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, \
-                       part, (long)rows, c, eps, (int)rpw)
+                       part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm)
 #define BYL_(T, V_)                    \
     switch (lpr) {                     \
     case 1: GOB_(T, V_, 1); break;     \
@@ -930,9 +987,9 @@ extern "C" int tramba_layernorm_bwd_cl(const void *x, const void *dy, const floa
     }
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
         const size_t lds = (size_t)8 * c * sizeof(float);
-        if (v == 4) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 4>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
-        else if (v == 2) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 2>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
-        else hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 1>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw);
+        if (v == 4) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 4>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm);
+        else if (v == 2) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 2>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm);
+        else hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 1>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm);
     });
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
@@ -1206,15 +1263,22 @@ extern "C" int tramba_col2im3x3_cl(const void *gcols, void *gx, int batch, int h
 extern "C" int tramba_dwconv_cl(const void *x, const float *wt, const float *bt, void *y, int batch, int h,
                                 int wd, int c, int ks, int act, int dtype, void *stream)
 {
+    return tramba_dwconv_dual_cl(x, wt, bt, nullptr, y, batch, h, wd, c, ks, act, 0, dtype, stream);
+}
+
+extern "C" int tramba_dwconv_dual_cl(const void *x, const float *wt, const float *bt, void *y_pre, void *y, int batch,
+                                     int h, int wd, int c, int ks, int act, int flip_taps, int dtype, void *stream)
+{
     TRAMBA_CHECK(x && wt && bt && y, "dwconv_cl: null tensor");
+    TRAMBA_CHECK(!y_pre || aligned16(y_pre), "dwconv_cl: tensors must be 16-byte aligned");
     TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0, "dwconv_cl: empty shape");
     TRAMBA_CHECK(ks == 3 || ks == 5 || ks == 7, "dwconv_cl: kernel size %d unsupported (3,5,7)", ks);
     TRAMBA_CHECK(aligned16(x) && aligned16(y) && aligned16(wt) && aligned16(bt), "dwconv_cl: tensors must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
-        if (ks == 3) return launch_dw<T, 3>(x, wt, bt, y, batch, h, wd, c, act, s);
-        if (ks == 5) return launch_dw<T, 5>(x, wt, bt, y, batch, h, wd, c, act, s);
-        return launch_dw<T, 7>(x, wt, bt, y, batch, h, wd, c, act, s);
+        if (ks == 3) return launch_dw<T, 3>(x, wt, bt, y, batch, h, wd, c, act, s, y_pre, flip_taps);
+        if (ks == 5) return launch_dw<T, 5>(x, wt, bt, y, batch, h, wd, c, act, s, y_pre, flip_taps);
+        return launch_dw<T, 7>(x, wt, bt, y, batch, h, wd, c, act, s, y_pre, flip_taps);
     });
     return TRAMBA_OK;
 }

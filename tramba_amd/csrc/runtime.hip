@@ -57,7 +57,10 @@ ProfScope::~ProfScope()
 using namespace tramba;
 
 extern "C" const char *tramba_last_error(void) { return g_err; }
-extern "C" int tramba_abi_version(void) { return 3; }   // 3: layernorm_bwd_parts(rows, c, dtype), shadow / slab-sum entries
+// 3: layernorm_bwd_parts(rows, c, dtype), shadow / slab-sum entries
+// 4: fused training entries (add_layernorm, layernorm_bwd_res, dwconv_dual, merge_grad, ss2d_bwd_prep / assemble,
+//    dw_unpack_grad); a_log / flags arguments of the fused scan forward / backward
+extern "C" int tramba_abi_version(void) { return 4; }
 
 static int g_tune[TRAMBA_TUNE_COUNT] = {0};
 extern "C" int tramba_tune_set(int knob, int value)

@@ -169,8 +169,11 @@ struct ScanWave {
     int hi, r32, R;
     float *st;               // this wave's LDS stage: [0] x-row byte offsets, [1] B*ln2, [2] C per position
 
+    // a_log (training): `Aneg` holds the PARAMETER A_logs and the kernel forms A = -exp(A_logs) (vmamba.py:246) itself --
+    // one exp per lane at start-up instead of an exp and a negation launch per block and step (and two more for their gradient)
     __device__ __forceinline__ void init(const float *dt_w, const float *dt_bias, const float *Aneg, const float *Ds,
-                                         long kd, int R_, int RG, int PC, int D, int lane, int cc_, float *st_)
+                                         long kd, int R_, int RG, int PC, int D, int lane, int cc_, float *st_,
+                                         int a_log = 0)
     {
         r32 = lane & 31;
         hi = lane >> 5;
@@ -192,7 +195,7 @@ struct ScanWave {
             roff[kk] = (unsigned)((r0 < R8 ? r0 : 0) * 4);
         }
         bias2 = dt_bias[kd] * 1.44269504088896f;
-        An = Aneg[kd];
+        An = a_log ? -__expf(Aneg[kd]) : Aneg[kd];
         Dk = Ds[kd];
         bcoff = (unsigned)(R8 * 4);
         cx = (unsigned)(cc_ * (int)sizeof(T));
@@ -380,7 +383,8 @@ template <typename T, typename TY, int NK, bool SPLIT, bool SAVE = false>
 __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
-    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W, float *__restrict__ hst = nullptr)
+    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W, float *__restrict__ hst = nullptr,
+    int a_log = 0)
 {
     __shared__ float agg[2][kMaxW][2][kTP];
     __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const int PC = K * RG;
 
     ScanWave<T, NK, SPLIT> w;
-    w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + cc_, R, RG, PC, D, lane, cc_, &stage[wv][0][0]);
+    w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + cc_, R, RG, PC, D, lane, cc_, &stage[wv][0][0], a_log);
 
     // wave-uniform descriptors (host guarantees every extent < 2^31 bytes)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
@@ -530,7 +534,8 @@ template <typename T, typename TY, int NK, int R8, int W, bool SAVE = false>
 __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
-    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, float *__restrict__ hst = nullptr)
+    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, float *__restrict__ hst = nullptr,
+    int a_log = 0)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass needs this kernel's launch stub, not its body, and hipcc
                                       // silently drops the stub of a kernel template whose body holds vector-register asm
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
     const int PC = K * RG;
 
     ScanWave<T, NK, false> w;
-    w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + c, R, RG, PC, D, lane, c, &stage[wv][0][0]);
+    w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + c, R, RG, PC, D, lane, c, &stage[wv][0][0], a_log);
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
     const __amdgpu_buffer_rsrc_t rp =
@@ -753,8 +758,11 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
     const float *__restrict__ Ds, const TG *__restrict__ gym, T *__restrict__ gu, T *__restrict__ graw,
     float *__restrict__ gB, float *__restrict__ gC, float *__restrict__ gpar, float *__restrict__ hst, int L, int D,
-    int K, int R, int W, int bcs, int have_states)
+    int K, int R, int W, int bcs, int have_states, int flags)
 {
+    // flags & 1: `Aneg` holds A_logs (see ScanWave::init) and gpar's first plane leaves as dL/dA_logs = dL/dA * A
+    // flags & 2: gB / gC are (B, K, CT, L) tables of per-channel-tile partial sums, each element WRITTEN by exactly one wave
+    //            (no zero fill, no atomics: the caller adds the CT = ceil(D / 32) partials in a fixed order)
     constexpr int kTS = 36;   // LDS row stride (floats) of the position-sum transposes: 16-byte aligned rows
     __shared__ float agg[2][kMaxW][2][kTP];
     __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];
@@ -774,7 +782,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     const int PC = K * RG;
 
     ScanWave<T, NK, SPLIT> w;
-    w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + cc_, R, RG, PC, D, lane, cc_, &stage[wv][0][0]);
+    w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + cc_, R, RG, PC, D, lane, cc_, &stage[wv][0][0], flags & 1);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
     const __amdgpu_buffer_rsrc_t rp =
         make_rsrc(xdbl + (long)b * L * PC + (long)k * RG, ((unsigned)(L - 1) * PC + RG) * 4u);
@@ -966,8 +974,14 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
             sbc[which] = sv + __shfl_xor(sv, 32, 64);
         }
         if (hi == 0 && l0 + r32 < L) {
-            atomicAdd(gB + (((long)b * K + k) * L + l0 + r32) * bcs, sbc[0]);   // bcs: floats between positions (1, or
-            atomicAdd(gC + (((long)b * K + k) * L + l0 + r32) * bcs, sbc[1]);   // the row stride of an x_dbl-gradient table)
+            if (flags & 2) {
+                const long o = (((long)b * K + k) * gridDim.x + ctile) * L + l0 + r32;
+                gB[o] = sbc[0];
+                gC[o] = sbc[1];
+            } else {
+                atomicAdd(gB + (((long)b * K + k) * L + l0 + r32) * bcs, sbc[0]);   // bcs: floats between positions (1, or
+                atomicAdd(gC + (((long)b * K + k) * L + l0 + r32) * bcs, sbc[1]);   // the row stride of an x_dbl-gradient table)
+            }
         }
     }
     // ---- per-channel sums: two half-waves, then the W waves
@@ -989,7 +1003,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
         }
         // (B, 3, K, D): the three parameter gradients are contiguous (K, D) planes once the batch is summed
         float *gp = gpar + ((long)b * 3 * K + k) * D + c;
-        gp[0] = sA;
+        gp[0] = (flags & 1) ? sA * w.An : sA;
         gp[(long)K * D] = sD;
         gp[2l * K * D] = sb2;
     }
@@ -1346,8 +1360,11 @@ template <typename TY, typename T, int V, int NIT>
 __global__ __launch_bounds__(256) void ss2d_merge_norm_deep_kernel(
     const TY *__restrict__ ys, const int32_t *__restrict__ inv_ptr, const int32_t *__restrict__ inv_idx,
     const float *__restrict__ ln_w, const float *__restrict__ ln_b, T *__restrict__ y, long npix, int B, int L,
-    int D, int K, int H, float eps, int act)
+    int D, int K, int H, float eps, int act, const T *__restrict__ addend = nullptr, const T *__restrict__ zpre = nullptr)
 {
+    // addend / zpre (training, merge-only calls: the gradient of SS2D's input): y = (sum + addend) * silu'(zpre) -- the x_proj
+    // branch's share of the gradient added and the SiLU in front of the core (vmamba.py:283-285) differentiated in the pass
+    // that merges the scan's input gradient, instead of an add and a silu_backward launch over the map.
     // rows per batch: 32 bytes per lane and buffer (2 buffers in flight = 4 KB per wave; 58 VGPRs = 8 waves per SIMD)
     constexpr int RB = 32 / (NIT * V * (int)sizeof(TY)) > 0 ? 32 / (NIT * V * (int)sizeof(TY)) : 1;
     const int lane = threadIdx.x & (kWave - 1);
@@ -1441,7 +1458,20 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_deep_kernel(
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c0 = (it * kWave + lane) * V;
-            if (c0 + V <= D) store_pack<T, V>(orow + c0, acc[it]);
+            if (c0 + V <= D) {
+                if (zpre) {   // (wave-uniform)
+                    float av[V], zv[V];
+                    load_pack<T, V>(zpre + ((long)b * L + p) * D + c0, zv);
+                    if (addend) {
+                        load_pack<T, V>(addend + ((long)b * L + p) * D + c0, av);
+#pragma unroll
+                        for (int v = 0; v < V; ++v) acc[it][v] += av[v];
+                    }
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[it][v] *= silu_gradf_(zv[v]);
+                }
+                store_pack<T, V>(orow + c0, acc[it]);
+            }
         }
         return;
     }
@@ -1578,40 +1608,40 @@ extern "C" size_t tramba_ss2d_scan_workspace(int batch, int l, int d, int k)
 template <typename T, typename TY, int NK, int R8, int W>
 static void launch_scan_dma(dim3 grid, dim3 block, hipStream_t s, const void *x, const float *xdbl, const int32_t *table,
                             const float *dt_w, const float *dt_bias, const float *A, const float *Ds, void *ys, int l, int d,
-                            int k, int r, float *states)
+                            int k, int r, float *states, int a_log)
 {
     if constexpr (std::is_same<T, TY>::value) {
         if (states) {
             hipLaunchKernelGGL((ss2d_scan_dma_kernel<T, TY, NK, R8, W, true>), grid, block, 0, s, (const T *)x, xdbl, table,
-                               dt_w, dt_bias, A, Ds, (TY *)ys, l, d, k, r, states);
+                               dt_w, dt_bias, A, Ds, (TY *)ys, l, d, k, r, states, a_log);
             return;
         }
     }
     hipLaunchKernelGGL((ss2d_scan_dma_kernel<T, TY, NK, R8, W>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, dt_bias, A,
-                       Ds, (TY *)ys, l, d, k, r, (float *)nullptr);
+                       Ds, (TY *)ys, l, d, k, r, (float *)nullptr, a_log);
 }
 
 template <typename T, typename TY, int NK, bool SP>
 static void launch_scan_ring(dim3 grid, dim3 block, hipStream_t s, const void *x, const float *xdbl, const int32_t *table,
                              const float *dt_w, const float *dt_bias, const float *A, const float *Ds, void *ys, int l, int d,
-                             int k, int r, int W, float *states)
+                             int k, int r, int W, float *states, int a_log)
 {
     if constexpr (std::is_same<T, TY>::value) {
         if (states) {
             hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK, SP, true>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w,
-                               dt_bias, A, Ds, (TY *)ys, l, d, k, r, W, states);
+                               dt_bias, A, Ds, (TY *)ys, l, d, k, r, W, states, a_log);
             return;
         }
     }
     hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK, SP>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, dt_bias, A, Ds,
-                       (TY *)ys, l, d, k, r, W, (float *)nullptr);
+                       (TY *)ys, l, d, k, r, W, (float *)nullptr, a_log);
 }
 
 extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32_t *table,
                                    const float *dt_w, const float *dt_bias, const float *A,
                                    const float *Ds, void *ys, void *workspace, size_t workspace_bytes,
                                    int batch, int l, int d, int k, int r, int dtype, int ys_dtype,
-                                   float *states, void *stream)
+                                   float *states, int a_log, void *stream)
 {
     TRAMBA_CHECK(x && xdbl && table && dt_w && dt_bias && A && Ds && ys, "ss2d_scan_cl: null tensor");
     TRAMBA_CHECK(!states || ys_dtype == dtype, "ss2d_scan_cl: states are saved by the forms whose ys is in the input dtype");
@@ -1659,7 +1689,7 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     // (A caller that passes no workspace gets the chained form.)
     const bool seg_wins = p.nseg == 1 || ((long)batch * k * ct <= 128 && p.ntiles >= 64);
     const int form_tune = tramba_tune_get(TRAMBA_TUNE_SCAN_FORM);      // 1 = chained, 2 = wave-segment, 3 = chained on LDS-DMA
-    const bool use_seg = !states && workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) &&
+    const bool use_seg = !states && !a_log && workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) &&
                          (form_tune == 2 || (form_tune == 0 && seg_wins));   // (the LDS-DMA form below is tried first;
                                                                              //  the chained forms are the ones that save states)
     // ---- chained form on LDS-DMA staged operands (4 waves per SIMD): 16-bit maps with dt_rank <= 32 whose sequences fill
@@ -1678,7 +1708,7 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
         if (dma_ok && (scan_tune == 3 || (scan_tune == 0 && seqs * wdma >= 2048 && p.ntiles >= 4 * wdma))) {
             dim3 grid(ct, k, batch), block(wdma * kWave);
 #define DMA_(T, TY, NK_, R8_, W_) \
-    launch_scan_dma<T, TY, NK_, R8_, W_>(grid, block, s, x, xdbl, table, dt_w, dt_bias, A, Ds, ys, l, d, k, r, states)
+    launch_scan_dma<T, TY, NK_, R8_, W_>(grid, block, s, x, xdbl, table, dt_w, dt_bias, A, Ds, ys, l, d, k, r, states, a_log)
 #define DMA_W_(T, TY, NK_, R8_) \
     if (wdma == 16) { DMA_(T, TY, NK_, R8_, 16); } else { DMA_(T, TY, NK_, R8_, 8); }
 #define DMA_R_(T, TY) \
@@ -1731,7 +1761,7 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     }
     dim3 grid(ct, k, batch), block(W * kWave);
 #define GO_(T, TY, NK_, SP_) \
-    launch_scan_ring<T, TY, NK_, SP_>(grid, block, s, x, xdbl, table, dt_w, dt_bias, A, Ds, ys, l, d, k, r, W, states)
+    launch_scan_ring<T, TY, NK_, SP_>(grid, block, s, x, xdbl, table, dt_w, dt_bias, A, Ds, ys, l, d, k, r, W, states, a_log)
     BY_DTYPE_(GO_)
 #undef GO_
 #undef BY_DTYPE_
@@ -1751,7 +1781,7 @@ extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const i
                                        const float *dt_bias, const float *A, const float *Ds, const void *gym,
                                        void *gu, void *graw, float *gB, float *gC, int bc_stride, float *gpar,
                                        void *workspace, size_t workspace_bytes, int have_states, int batch, int l, int d,
-                                       int k, int r, int dtype, int gym_dtype, void *stream)
+                                       int k, int r, int dtype, int gym_dtype, int flags, void *stream)
 {
     TRAMBA_CHECK(bc_stride >= 1, "ss2d_scan_bwd_cl: bc_stride must be >= 1");
     TRAMBA_CHECK(x && xdbl && table && dt_w && dt_bias && A && Ds && gym && gu && graw && gB && gC && gpar && workspace,
@@ -1773,7 +1803,7 @@ extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const i
 #define BWD_G_(T, NK_, SP_, TG)                                                                                     \
     hipLaunchKernelGGL((ss2d_scan_bwd_cl_kernel<T, NK_, SP_, TG>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, \
                        dt_bias, A, Ds, (const TG *)gym, (T *)gu, (T *)graw, gB, gC, gpar, (float *)workspace, l, d, k, r, W, bc_stride, \
-                       have_states)
+                       have_states, flags)
 #define BWD_(T, NK_, SP_)                                                          \
     if (gym_dtype == TRAMBA_F32) { BWD_G_(T, NK_, SP_, float); } else { BWD_G_(T, NK_, SP_, T); }
 #define BWD_NK_(T, SP_)                \
@@ -1802,7 +1832,18 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
                                          int d, int k, float eps, int act, int ys_dtype, int dtype,
                                          void *stream)
 {
+    return tramba_ss2d_merge_grad_cl(ys, inv_ptr, inv_idx, ln_w, ln_b, y, nullptr, nullptr, batch, l, d, k, eps, act, ys_dtype,
+                                     dtype, stream);
+}
+
+extern "C" int tramba_ss2d_merge_grad_cl(const void *ys, const int32_t *inv_ptr, const int32_t *inv_idx,
+                                         const float *ln_w, const float *ln_b, void *y, const void *addend,
+                                         const void *zpre, int batch, int l, int d, int k, float eps, int act,
+                                         int ys_dtype, int dtype, void *stream)
+{
     TRAMBA_CHECK(ys && inv_ptr && inv_idx && y && (eps < 0.f || (ln_w && ln_b)), "ss2d_merge_norm_cl: null tensor");
+    TRAMBA_CHECK((!addend && !zpre) || (eps < 0.f && zpre && aligned16(zpre) && (!addend || aligned16(addend))),
+                 "ss2d_merge_grad_cl: the SiLU-gradient epilogue belongs to a merge-only call (eps < 0) and needs zpre");
     TRAMBA_CHECK(batch > 0 && l > 0 && d > 0 && k > 0, "ss2d_merge_norm_cl: empty shape");
     TRAMBA_CHECK(ys_dtype == TRAMBA_F32 || ys_dtype == dtype, "ss2d_merge_norm_cl: ys must be f32 or dtype");
     hipStream_t s = (hipStream_t)stream;
@@ -1852,7 +1893,7 @@ extern "C" int tramba_ss2d_merge_norm_cl(const void *ys, const int32_t *inv_ptr,
         dim3 gridd((unsigned)((npix + 3) / 4)), blockd(256);
 #define DEEP_(TY, T, V_, N_)                                                                                      \
     hipLaunchKernelGGL((ss2d_merge_norm_deep_kernel<TY, T, V_, N_>), gridd, blockd, 0, s, (const TY *)ys, inv_ptr, \
-                       inv_idx, ln_w, ln_b, (T *)y, npix, batch, l, d, k, hh, eps, act)
+                       inv_idx, ln_w, ln_b, (T *)y, npix, batch, l, d, k, hh, eps, act, (const T *)addend, (const T *)zpre)
 #define DEEP_N_(TY, T, V_)                    \
     if (nd == 1) { DEEP_(TY, T, V_, 1); }     \
     else if (nd == 2) { DEEP_(TY, T, V_, 2); } \

@@ -84,6 +84,7 @@ class GraphedTrainStep:
         self.model, self.opt, self.reducer, self.warmup = model, opt, reducer, warmup
         self._graphs = {}
         self._lr_key = None
+        self._trainable_key = None
 
     def _lrs(self):
         return tuple(float(g["lr"]) for g in self.opt.param_groups)
@@ -147,7 +148,7 @@ class GraphedTrainStep:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):                       # records, executes nothing
             loss = train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
-        keep_alive = (pool.probs, pool.buf)                 # the keep-probabilities the captured bernoulli / divide nodes read
+        keep_alive = (pool.probs, pool.buf, pool.buf32)              # the keep-probabilities the captured bernoulli / divide nodes read
         pool.forget_draw()                                  # (the table drawn during capture lives in the graph's pool)
         self._restore(saved)
         torch.cuda.set_rng_state(rng, dev)
@@ -159,10 +160,10 @@ class GraphedTrainStep:
                                "with model.train() before the next step)")
         # learning rates AND the set of trainable parameters are baked into a capture (freeze_encoder / unfreeze_encoder
         # flip requires_grad: the eager step follows them, a stale graph would keep updating frozen weights)
-        lrs = self._lrs() + tuple(p.requires_grad for g in self.opt.param_groups for p in g["params"])
-        if lrs != self._lr_key:
+        lrs, trainable = self._lrs(), tuple(p.requires_grad for g in self.opt.param_groups for p in g["params"])
+        if lrs != self._lr_key or trainable != self._trainable_key:
             self._graphs.clear()
-            self._lr_key = lrs
+            self._lr_key, self._trainable_key = lrs, trainable
         key = (tuple(images.shape), images.dtype, tuple(label.shape), label.dtype)
         entry = self._graphs.get(key)
         if entry is None:

@@ -46,19 +46,26 @@ SIGNATURES = {
     "tramba_cross_merge": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_ss2d_group_stride": (c_int, [c_int]),
     "tramba_ss2d_scan_workspace": (ctypes.c_size_t, [c_int] * 4),
-    "tramba_ss2d_scan_cl": (c_int, [c_vp] * 9 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp, c_vp]),
+    "tramba_ss2d_scan_cl": (c_int, [c_vp] * 9 + [ctypes.c_size_t] + [c_int] * 7 + [c_vp, c_int, c_vp]),
     "tramba_ss2d_scan_bwd_workspace": (ctypes.c_size_t, [c_int] * 4),
-    "tramba_ss2d_scan_bwd_cl": (c_int, [c_vp] * 12 + [c_int, c_vp, c_vp, ctypes.c_size_t] + [c_int] * 8 + [c_vp]),
+    "tramba_ss2d_scan_bwd_cl": (c_int, [c_vp] * 12 + [c_int, c_vp, c_vp, ctypes.c_size_t] + [c_int] * 9 + [c_vp]),
+    "tramba_ss2d_bwd_prep_cl": (c_int, [c_vp] * 6 + [c_int] * 6 + [c_vp]),
+    "tramba_ss2d_bwd_assemble_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_vp]),
+    "tramba_ss2d_merge_grad_cl": (c_int, [c_vp] * 8 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_ss2d_merge_norm_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_f, c_int, c_int, c_int, c_vp]),
     "tramba_layernorm_cl": (c_int, [c_vp] * 4 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_layernorm_bwd_parts": (c_i64, [c_i64, c_int, c_int]),
     "tramba_layernorm_bwd_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_f, c_int, c_vp]),
+    "tramba_layernorm_bwd_res_cl": (c_int, [c_vp] * 7 + [c_i64, c_vp, c_i64, c_int, c_f, c_int, c_vp]),
+    "tramba_add_layernorm_cl": (c_int, [c_vp] * 3 + [c_i64] + [c_vp] * 5 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_shuffle_norm_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_shuffle_norm_head_cl": (c_int, [c_vp] * 4 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_rowdot_cl": (c_int, [c_vp, c_vp, c_f, c_vp, c_i64, c_int, c_int, c_vp]),
     "tramba_saliency_stats": (c_int, [c_vp] * 4 + [c_int] * 3 + [c_vp]),
     "tramba_dw_pack": (c_int, [c_vp] * 8 + [c_int] * 2 + [c_vp]),
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
+    "tramba_dwconv_dual_cl": (c_int, [c_vp] * 5 + [c_int] * 8 + [c_vp]),
+    "tramba_dw_unpack_grad": (c_int, [c_vp] * 5 + [c_int] * 3 + [c_vp]),
     "tramba_im2col3x3_cl": (c_int, [c_vp] * 2 + [c_int] * 8 + [c_vp]),
     "tramba_upsample_bilinear_bwd": (c_int, [c_vp] * 2 + [c_int] * 5 + [c_vp]),
     "tramba_col2im3x3_cl": (c_int, [c_vp] * 2 + [c_int] * 8 + [c_vp]),
@@ -350,11 +357,13 @@ def ss2d_scan_states(x, order: ScanOrder):
     return torch.empty(lib().tramba_ss2d_scan_bwd_workspace(b, l, d, order.k), dtype=torch.uint8, device=x.device)
 
 
-def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch.float32, segmented=True, states=None):
+def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch.float32, segmented=True, states=None,
+                 a_log=False):
     """x: (B, L, D); xdbl: (B, L, K*RG) f32 -> ys (B, K, L, D).  With `segmented` a workspace is passed and
     the library picks the wave-segment or a chained form per shape (tune_set(TUNE_SCAN_FORM, ...) forces one).
     states (training): a buffer from ss2d_scan_states(); the launch saves the per-tile entering states in it (chained forms
-    only, ys in the input dtype), and the backward launch given the same buffer skips its first sweep."""
+    only, ys in the input dtype), and the backward launch given the same buffer skips its first sweep.
+    a_log (training): `A` is the parameter A_logs, the kernel forms -exp(A_logs) itself."""
     _dev(x, xdbl, dt_w, dt_bias, A, Ds)
     b, l, d = x.shape
     k, r = order.k, dt_w.shape[-1]
@@ -369,7 +378,7 @@ def ss2d_scan_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, ys_dtype=torch
         ws = _scan_workspace(x.device, ws_bytes)
     _check(lib().tramba_ss2d_scan_cl(_ptr(x), _ptr(xdbl), _ptr(order.table), _ptr(dt_w), _ptr(dt_bias), _ptr(A),
                                      _ptr(Ds), _ptr(ys), _ptr(ws), ws_bytes, b, l, d, k, r, dt(x), dt(ys), _ptr(states),
-                                     _stream()), "ss2d_scan_cl")
+                                     int(a_log), _stream()), "ss2d_scan_cl")
     return ys
 
 
@@ -383,12 +392,16 @@ def ss2d_merge_sum_cl(ys, order: ScanOrder, out_dtype):
     return y
 
 
-def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym, g_seq=None, states=None):
+def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym, g_seq=None, states=None, a_log=False,
+                     bc_partials=False):
     """Backward of ss2d_scan_cl + merge.  gym (B, L, D) f32 = gradient of the merged map.
     Returns gu, graw (B,K,L,D) x.dtype, gB, gC (B,K,L) f32, gpar (B,3,K,D) f32 (dA, dD, dbias planes).
     g_seq: a ZEROED (B,K,L,RG) f32 x_dbl-gradient table in sequence order -- gB / gC are then accumulated straight into its
     B / C columns (RG - 4, RG - 3) and returned as views of it.
-    states: the buffer the forward launch filled (ss2d_scan_cl(states=...)): the sweep that recomputes them is skipped."""
+    states: the buffer the forward launch filled (ss2d_scan_cl(states=...)): the sweep that recomputes them is skipped.
+    a_log: `A` is the parameter A_logs; gpar's first plane is then dL/dA_logs.
+    bc_partials: gB / gC come back as (B, K, ceil(D/32), L) per-channel-tile partial sums written without atomics (no zero
+    fill; ss2d_bwd_prep adds them in a fixed order)."""
     _dev(x, xdbl, dt_w, dt_bias, A, Ds, gym, g_seq)
     b, l, d = x.shape
     k, r = order.k, dt_w.shape[-1]
@@ -396,7 +409,11 @@ def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym, g_seq
         raise TrambaHipError("ss2d_scan_bwd_cl: gym must be (B, L, D) in f32 or the activation dtype")
     gu = torch.empty((b, k, l, d), dtype=x.dtype, device=x.device)
     graw = torch.empty_like(gu)
-    if g_seq is None:
+    if bc_partials:
+        gB = torch.empty((b, k, (d + 31) // 32, l), dtype=torch.float32, device=x.device)
+        gC = torch.empty_like(gB)
+        bcs = 1
+    elif g_seq is None:
         gB = torch.zeros((b, k, l), dtype=torch.float32, device=x.device)
         gC = torch.zeros_like(gB)
         bcs = 1
@@ -417,8 +434,49 @@ def ss2d_scan_bwd_cl(x, xdbl, order: ScanOrder, dt_w, dt_bias, A, Ds, gym, g_seq
     _check(lib().tramba_ss2d_scan_bwd_cl(_ptr(x), _ptr(xdbl), _ptr(order.table), _ptr(dt_w), _ptr(dt_bias), _ptr(A),
                                          _ptr(Ds), _ptr(gym), _ptr(gu), _ptr(graw), _ptr(gB), _ptr(gC), bcs, _ptr(gpar),
                                          _ptr(ws), ws_bytes, 0 if states is None else 1, b, l, d, k, r, dt(x), dt(gym),
-                                         _stream()), "ss2d_scan_bwd_cl")
+                                         (1 if a_log else 0) | (2 if bc_partials else 0), _stream()), "ss2d_scan_bwd_cl")
     return gu, graw, gB, gC, gpar
+
+
+def ss2d_bwd_prep(xdbl, order: ScanOrder, bpart, cpart, r, dtype):
+    """after ss2d_scan_bwd_cl(bc_partials=True): (ranks (B,K,L,R8) `dtype` = the dt-rank rows of xdbl in sequence order,
+    g_seq (B,K,L,RG) f32 with the summed dB / dC in columns R8, R8 + 1; the rank columns are for rows_gemm_cl to fill)"""
+    _dev(xdbl, bpart, cpart)
+    b, l, pc = xdbl.shape
+    k = order.k
+    rg = ss2d_group_stride(r)
+    if pc != k * rg or bpart.shape != cpart.shape or bpart.shape[:2] != (b, k) or bpart.shape[3] != l:
+        raise TrambaHipError("ss2d_bwd_prep: operand shapes do not match")
+    ranks = torch.empty((b, k, l, rg - 4), dtype=dtype, device=xdbl.device)
+    gseq = torch.empty((b, k, l, rg), dtype=torch.float32, device=xdbl.device)
+    _check(lib().tramba_ss2d_bwd_prep_cl(_ptr(xdbl), _ptr(order.table), _ptr(bpart), _ptr(cpart), _ptr(ranks), _ptr(gseq),
+                                         b, l, k, r, bpart.shape[2], _DT[dtype], _stream()), "ss2d_bwd_prep_cl")
+    return ranks, gseq
+
+
+def ss2d_bwd_assemble(gseq, order: ScanOrder, r, dtype):
+    """gseq (B,K,L,RG) f32 in sequence order -> (B, L, K*RG) `dtype` in spatial order (gather-sum through the inverse table)"""
+    _dev(gseq)
+    b, k, l, rg = gseq.shape
+    if k != order.k or l != order.l or rg != ss2d_group_stride(r):
+        raise TrambaHipError("ss2d_bwd_assemble: gseq does not match the scan order / dt_rank")
+    out = torch.empty((b, l, k * rg), dtype=dtype, device=gseq.device)
+    _check(lib().tramba_ss2d_bwd_assemble_cl(_ptr(gseq), _ptr(order.inv_ptr), _ptr(order.inv_idx), _ptr(out), b, l, k, r,
+                                             _DT[dtype], _stream()), "ss2d_bwd_assemble_cl")
+    return out
+
+
+def ss2d_merge_grad_cl(gu, order: ScanOrder, addend, zpre):
+    """(merge(gu) + addend) * silu'(zpre): gu (B,K,L,D) sequence order, addend / zpre (B,L,D) -> (B,L,D), zpre's dtype"""
+    _dev(gu, addend, zpre)
+    b, k, l, d = gu.shape
+    if zpre.shape != (b, l, d) or (addend is not None and (addend.shape != zpre.shape or addend.dtype != zpre.dtype)):
+        raise TrambaHipError("ss2d_merge_grad_cl: operand shapes / dtypes do not match")
+    y = torch.empty((b, l, d), dtype=zpre.dtype, device=gu.device)
+    _check(lib().tramba_ss2d_merge_grad_cl(_ptr(gu), _ptr(order.inv_ptr), _ptr(order.inv_idx), None, None, _ptr(y),
+                                           _ptr(addend), _ptr(zpre), b, l, d, k, -1.0, ACT_NONE, dt(gu), dt(y), _stream()),
+           "ss2d_merge_grad_cl")
+    return y
 
 
 def ss2d_merge_norm_cl(ys, order: ScanOrder, ln_w, ln_b, eps, act, out_dtype):
@@ -452,6 +510,41 @@ def layernorm_bwd_cl(x, dy, w, eps=1e-5):
            "layernorm_bwd_cl")
     s = slab_sum(part)
     return dx, s[0], s[1]
+
+
+def add_layernorm_cl(x, y, mask, w, b, eps=1e-5, act=ACT_NONE, dual=False):
+    """(xsum, n, n_act): xsum = x + y * mask[sample] (None when y is None), n = LayerNorm(xsum or x), n_act = act(n) when
+    `dual`.  x, y (B, ..., C) contiguous, mask (B) f32 or None."""
+    _dev(x, y, mask, w, b)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    if y is not None and (y.shape != x.shape or y.dtype != x.dtype):
+        raise TrambaHipError("add_layernorm_cl: x / y mismatch")
+    if mask is not None and (mask.dtype != torch.float32 or mask.numel() != x.shape[0]):
+        raise TrambaHipError("add_layernorm_cl: mask must be float32 with one entry per sample")
+    xsum = torch.empty_like(x) if y is not None else None
+    n = torch.empty_like(x)
+    na = torch.empty_like(x) if dual else None
+    _check(lib().tramba_add_layernorm_cl(_ptr(x), _ptr(y), _ptr(mask), rows // x.shape[0], _ptr(w), _ptr(b), _ptr(xsum),
+                                         _ptr(n), _ptr(na), rows, c, eps, act, dt(x), _stream()), "add_layernorm_cl")
+    return xsum, n, na
+
+
+def layernorm_bwd_res_cl(x, dy, w, eps=1e-5, gres=None, mask=None, want_masked=False):
+    """LayerNorm backward on the residual stream: (dx + gres, that * mask[sample] or None, dw, db)"""
+    _dev(x, dy, w, gres, mask)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    if gres is not None and (gres.shape != x.shape or gres.dtype != x.dtype):
+        raise TrambaHipError("layernorm_bwd_res_cl: gres must match x")
+    dx = torch.empty_like(x)
+    dxm = torch.empty_like(x) if want_masked else None
+    part = torch.empty((lib().tramba_layernorm_bwd_parts(rows, c, dt(x)), 2, c), dtype=torch.float32, device=x.device)
+    _check(lib().tramba_layernorm_bwd_res_cl(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(part), _ptr(gres), _ptr(mask),
+                                             rows // x.shape[0], _ptr(dxm), rows, c, eps, dt(x), _stream()),
+           "layernorm_bwd_res_cl")
+    s = slab_sum(part)
+    return dx, dxm, s[0], s[1]
 
 
 def shuffle_norm_cl(x, w, b, p, eps=1e-5):
@@ -540,6 +633,34 @@ def dwconv_cl(x, wt, bt, act=ACT_NONE):
     return y
 
 
+def dwconv_dual_cl(x, wt, bt, act=ACT_NONE, want_pre=True, flip=False):
+    """(pre, act(pre)): the stencil's output before and after its activation from one launch; flip: mirrored taps (the
+    stencil's adjoint: its input gradient)."""
+    _dev(x, wt, bt)
+    bb, h, wd, c = x.shape
+    ks = int(round(wt.shape[0] ** 0.5))
+    if wt.shape != (ks * ks, c) or bt.shape != (c,):
+        raise TrambaHipError(f"dwconv_dual_cl: packed weight {tuple(wt.shape)} does not match C={c}")
+    pre = torch.empty_like(x) if want_pre else None
+    y = torch.empty_like(x)
+    _check(lib().tramba_dwconv_dual_cl(_ptr(x), _ptr(wt), _ptr(bt), _ptr(pre), _ptr(y), bb, h, wd, c, ks, act, int(flip),
+                                       dt(x), _stream()), "dwconv_dual_cl")
+    return pre, y
+
+
+def dw_unpack_grad(gwt, ks, multiscale=False, nbias=0):
+    """gwt (ks*ks + 1, C) f32 tap-major taps + bias row -> (g7 (C,1,ks,ks), g5, g3 (multi-scale fold, else None), gb (nbias, C))"""
+    _dev(gwt)
+    c = gwt.shape[1]
+    g7 = torch.empty((c, 1, ks, ks), dtype=torch.float32, device=gwt.device)
+    g5 = torch.empty((c, 1, 5, 5), dtype=torch.float32, device=gwt.device) if multiscale else None
+    g3 = torch.empty((c, 1, 3, 3), dtype=torch.float32, device=gwt.device) if multiscale else None
+    gb = torch.empty((nbias, c), dtype=torch.float32, device=gwt.device) if nbias else None
+    _check(lib().tramba_dw_unpack_grad(_ptr(gwt), _ptr(g7), _ptr(g5), _ptr(g3), _ptr(gb), nbias, c, ks, _stream()),
+           "dw_unpack_grad")
+    return g7, g5, g3, gb
+
+
 def upsample_bilinear_bwd(gout, h, w):
     """gout (..., H, W) f32 = gradient of F.interpolate(x (..., h, w), (H, W), mode="bilinear") -> gradient of x."""
     _dev(gout)
@@ -584,6 +705,18 @@ def dwconv_wgrad_cl(x, gy, ks):
            "dwconv_wgrad_cl")
     s = slab_sum(part)
     return s[:ks * ks], s[ks * ks]
+
+
+def dwconv_wgrad_table(x, gy, ks):
+    """the same as one (ks*ks + 1, C) f32 table (taps, then the bias row): the input of dw_unpack_grad"""
+    _dev(x, gy)
+    bb, h, wd, c = x.shape
+    if gy.shape != x.shape or gy.dtype != x.dtype:
+        raise TrambaHipError("dwconv_wgrad_cl: x / gy mismatch")
+    part = torch.empty((lib().tramba_dwconv_wgrad_parts(bb, h, wd, ks), ks * ks + 1, c), dtype=torch.float32, device=x.device)
+    _check(lib().tramba_dwconv_wgrad_cl(_ptr(x), _ptr(gy), _ptr(part), bb, h, wd, c, ks, dt(x), _stream()),
+           "dwconv_wgrad_cl")
+    return slab_sum(part)
 
 
 def dct_split_cl(x, wx, wy):

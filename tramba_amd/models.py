@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import hip
 from .modules import (FinalPatchExpand_X4, FreqBlockv6, LayerNorm2d, Linear2d, MultiScaleDecoderBlock, PatchExpand,
-                      VSSMEncoder, _infer, _init_weights, model_mask_pool, _need_device, from_cl, load_pretrained_Base,
+                      VSSMEncoder, _infer, _init_weights, _run_blocks, model_mask_pool, _need_device, from_cl, load_pretrained_Base,
                       to_cl)
 from .ops import CrossMerge_Line, CrossScan_Line
 
@@ -143,8 +143,7 @@ class VSSMDecoder(nn.Module):
                 else:
                     mid = self.guide_layers[s]._forward_cl(skips_cl[-(s + 2)])
                 x = self.concat_back_dim[s]._forward_cat_cl(x, mid)
-                for blk in self.stage_layers[s].blocks:
-                    x = blk._forward_cl(x)
+                x = _run_blocks(self.stage_layers[s].blocks, x)
             if self.deep_supervision or s == n - 1:
                 outs.append(self._seg_cl(self.seg_layers[s], x))
             x_low = x

@@ -238,6 +238,7 @@ class _MaskPool:
 
     def __init__(self):
         self.slots, self.keep, self.count, self.buf, self.probs, self.fresh = {}, [], {}, None, None, False
+        self.buf32 = None
 
     def begin_step(self):
         self.count = {}
@@ -247,7 +248,8 @@ class _MaskPool:
         """the next take() draws a fresh table whatever the bookkeeping says (around a hipGraph capture)"""
         self.fresh = False
 
-    def take(self, mod, keep, batch, dtype, device):
+    def take(self, mod, keep, batch, dtype, device, want_f32=False):
+        """the mask row of this use: (batch) in `dtype`, or the fp32 row the fused residual kernels read (want_f32)"""
         import weakref
         k = self.count.get(id(mod), 0)
         if k >= 16:
@@ -266,9 +268,10 @@ class _MaskPool:
             n = len(self.keep)
             if self.probs is None or self.probs.shape != (n, 1) or self.probs.device != device:
                 self.probs = torch.tensor(self.keep, dtype=torch.float32).view(n, 1).to(device)
-            self.buf = (torch.bernoulli(self.probs.expand(n, batch)) / self.probs).to(dtype)
+            self.buf32 = torch.bernoulli(self.probs.expand(n, batch)) / self.probs
+            self.buf = self.buf32.to(dtype)
             self.fresh = True
-        return self.buf[ent[0]]
+        return self.buf32[ent[0]] if want_f32 else self.buf[ent[0]]
 
 
 _mask_pool = _MaskPool()        # DropPath instances used outside a model that owns a pool (bare blocks in tests / scripts)
@@ -302,6 +305,13 @@ class DropPath(nn.Module):
             pool = self.__dict__.get("_pool") or _mask_pool
             return pool.take(self, keep, x.shape[0], x.dtype, x.device).view(shape)
         return x.new_empty(shape).bernoulli_(keep).div_(keep)
+
+    def mask_f32(self, x):
+        """(B) fp32 keep / keep_prob per sample for the fused residual kernels, or None when this use drops nothing"""
+        if self.drop_prob == 0.0 or not self.training:
+            return None
+        pool = self.__dict__.get("_pool") or _mask_pool
+        return pool.take(self, 1.0 - self.drop_prob, x.shape[0], x.dtype, x.device, want_f32=True)
 
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
@@ -1037,6 +1047,251 @@ class _SS2DCoreCL(torch.autograd.Function):
         return (gx, g_xd.view(b, l, k * rg), g_dtw, gp[2].reshape(-1), gp[0].reshape(-1), gp[1].reshape(-1), None)
 
 
+# ----------------------------------------------------------------------------- fused training path (round 3)
+# The residual stream of a block under autograd, without framework launches between the library's kernels: a residual add is
+# DEFERRED to the LayerNorm that follows it (one pass: x' = x + y * mask, n = LN(x')), whose backward hands back both the
+# gradient of x' (its own contribution + the skip connection's) and that gradient times the stochastic-depth mask.
+class _Deferred:
+    """A pending residual add: stands for x + y * mask[sample] (mask (B) f32 or None)."""
+    __slots__ = ("x", "y", "mask")
+
+    def __init__(self, x, y, mask):
+        self.x, self.y, self.mask = x, y, mask
+
+
+class _AddMaskedF32(torch.autograd.Function):
+    """x + y * mask[sample] with an fp32 (B) mask (the end of a stage, where no LayerNorm follows to absorb the add)."""
+
+    @staticmethod
+    def forward(ctx, x, y, mask):
+        m = mask.to(y.dtype).view((-1,) + (1,) * (y.dim() - 1))
+        ctx.save_for_backward(m)
+        return torch.addcmul(x, y, m)
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        return (g if ctx.needs_input_grad[0] else None), (g * m if ctx.needs_input_grad[1] else None), None
+
+
+def _resolve(v):
+    """the tensor a value of the residual stream stands for"""
+    if not isinstance(v, _Deferred):
+        return v
+    return v.x + v.y if v.mask is None else _AddMaskedF32.apply(v.x, v.y, v.mask)
+
+
+class _AddLayerNormCL(torch.autograd.Function):
+    """(x', n, act(n)) = (x + y * mask, LayerNorm(x'), its activation) from ONE launch (tramba_add_layernorm_cl).
+    y None: no add -- x' is x itself, handed through when `passthrough` (so that the skip connection's gradient and the
+    LayerNorm's meet inside this Function's backward, one launch, instead of in an autograd add), else None.
+    act ACT_NONE: no activation output.  Backward: tramba_layernorm_bwd_res_cl."""
+
+    @staticmethod
+    def forward(ctx, x, y, mask, w, b, eps, act, passthrough):
+        x = x.contiguous()
+        wf = w.detach().float().contiguous()
+        xs, n, na = hip.add_layernorm_cl(x, None if y is None else y.contiguous(), mask, wf, b.detach().float().contiguous(),
+                                         eps, act, dual=act != hip.ACT_NONE)
+        ctx.save_for_backward(x if xs is None else xs, wf, mask)
+        ctx.eps, ctx.has_y = eps, y is not None
+        if na is not None:
+            ctx.mark_non_differentiable(na)
+        ctx.set_materialize_grads(False)
+        if xs is None:
+            xs = x if passthrough else None
+        return xs, n, na
+
+    @staticmethod
+    def backward(ctx, g_xs, g_n, _g_na):
+        xs, wf, mask = ctx.saved_tensors
+        if g_n is None:      # the normalised map was not used: only the skip connection carries a gradient
+            gy = None
+            if ctx.has_y and g_xs is not None:
+                gy = g_xs if mask is None else g_xs * mask.to(g_xs.dtype).view((-1,) + (1,) * (g_xs.dim() - 1))
+            return g_xs, gy, None, None, None, None, None, None
+        g_n = g_n.contiguous()
+        if g_n.dtype != xs.dtype:
+            g_n = g_n.to(xs.dtype)
+        if g_xs is not None:
+            g_xs = g_xs.contiguous()
+            if g_xs.dtype != xs.dtype:
+                g_xs = g_xs.to(xs.dtype)
+        want_m = ctx.has_y and mask is not None and ctx.needs_input_grad[1]
+        dx, dxm, dw, db = hip.layernorm_bwd_res_cl(xs, g_n, wf, ctx.eps, gres=g_xs, mask=mask if want_m else None,
+                                                   want_masked=want_m)
+        gy = (dxm if want_m else dx) if ctx.has_y else None
+        return dx, gy, None, dw, db, None, None, None
+
+
+def _add_ln(v, norm, act=hip.ACT_NONE):
+    """(x', n, act(n) or None) for a value of the residual stream (tensor or _Deferred) and a LayerNorm2d"""
+    if isinstance(v, _Deferred):
+        return _AddLayerNormCL.apply(v.x, v.y, v.mask, norm.weight, norm.bias, norm.eps, act, True)
+    return _AddLayerNormCL.apply(v, None, None, norm.weight, norm.bias, norm.eps, act, True)
+
+
+class _DwConvActCL(torch.autograd.Function):
+    """(z, act(z)) with z = depth-wise conv(x) + bias from one launch (tramba_dwconv_dual_cl): SS2D's conv2d + SiLU
+    (vmamba.py:283-285) on the training path.  z carries the gradient; act(z) is handed to the consumer, which owns the
+    activation's backward.  Weights arrive in the reference layout (C,1,ks,ks) / (C) and are packed tap-major here
+    (tramba_dw_pack); backward: the same stencil with mirrored taps, tramba_dwconv_wgrad_cl, tramba_dw_unpack_grad."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x = x.contiguous()
+        wt, bt = hip.dw_pack(w.detach(), None if b is None else b.detach())
+        z, a = hip.dwconv_dual_cl(x, wt, bt, act)
+        ctx.save_for_backward(x, wt)
+        ctx.ks, ctx.has_bias, ctx.wdtype = w.shape[-1], b is not None, w.dtype
+        ctx.mark_non_differentiable(a)
+        ctx.set_materialize_grads(False)
+        return z, a
+
+    @staticmethod
+    def backward(ctx, gz, _ga):
+        if gz is None:
+            return None, None, None, None
+        x, wt = ctx.saved_tensors
+        gz = gz.contiguous()
+        if gz.dtype != x.dtype:
+            gz = gz.to(x.dtype)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = hip.dwconv_dual_cl(gz, wt, _zeros_const((wt.shape[1],), torch.float32, wt.device), hip.ACT_NONE,
+                                    want_pre=False, flip=True)[1]
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            g7, _, _, gbs = hip.dw_unpack_grad(hip.dwconv_wgrad_table(x, gz, ctx.ks), ctx.ks, False, 1 if ctx.has_bias else 0)
+            gw = g7.to(ctx.wdtype)
+            gb = gbs[0] if ctx.has_bias else None
+        return gx, gw, gb, None
+
+
+class _DwmsActCL(torch.autograd.Function):
+    """(g, gelu(g)) with g = h + dw3(h) + dw5(h) + dw7(h) (vmamba.py:622-625) as ONE folded 7x7 stencil with a dual store;
+    the fold (tramba_dw_pack) and its adjoint (tramba_dw_unpack_grad) are one small launch each."""
+
+    @staticmethod
+    def forward(ctx, h, w3, b3, w5, b5, w7, b7):
+        h = h.contiguous()
+        wt, bt = hip.dw_pack(w7.detach(), b7.detach(), w3.detach(), b3.detach(), w5.detach(), b5.detach())
+        g, a = hip.dwconv_dual_cl(h, wt, bt, hip.ACT_GELU)
+        ctx.save_for_backward(h, wt)
+        ctx.wdtype = w7.dtype
+        ctx.mark_non_differentiable(a)
+        ctx.set_materialize_grads(False)
+        return g, a
+
+    @staticmethod
+    def backward(ctx, gg, _ga):
+        if gg is None:
+            return (None,) * 7
+        h, wt = ctx.saved_tensors
+        gg = gg.contiguous()
+        if gg.dtype != h.dtype:
+            gg = gg.to(h.dtype)
+        gh = None
+        if ctx.needs_input_grad[0]:
+            gh = hip.dwconv_dual_cl(gg, wt, _zeros_const((wt.shape[1],), torch.float32, wt.device), hip.ACT_NONE,
+                                    want_pre=False, flip=True)[1]
+        g7, g5, g3, gbs = hip.dw_unpack_grad(hip.dwconv_wgrad_table(h, gg, 7), 7, True, 3)
+        t = ctx.wdtype
+        return gh, g3.to(t), gbs[0], g5.to(t), gbs[1], g7.to(t), gbs[2]
+
+
+def _xproj_padded(w, dtype):
+    """the x_proj weight (K, R + 2, D) in the scan kernels' padded (K*RG, D) layout and its transpose (or None), `dtype`:
+    the shadows written after the optimizer step when they are current, else built here"""
+    k, r2, d = w.shape
+    r = r2 - 2
+    rg = hip.ss2d_group_stride(r)
+    ent = _lowp_shadow.get(id(w))
+    if (ent is not None and ent[1] == w._version and ent[0].dtype == dtype and ent[2]() is w
+            and ent[0].shape == (k * rg, d)):
+        return ent[0], ent[3]
+    wl = w.detach().to(dtype)
+    parts = [wl[:, :r]]
+    if rg - 4 - r:
+        parts.append(_zeros_const((k, rg - 4 - r, d), dtype, w.device))
+    parts += [wl[:, r:], _zeros_const((k, 2, d), dtype, w.device)]
+    return torch.cat(parts, dim=1).view(k * rg, d), None
+
+
+class _SS2DInnerCL(torch.autograd.Function):
+    """SiLU -> x_proj -> scan gather + dt_proj + selective scan -> CrossMerge of forward_corev2 (vmamba.py:230-262) on
+    channels-last tensors under autograd, every launch the library's.  Inputs: z (B,L,D) the pre-activation of the SiLU in
+    front of the core and xs = silu(z) (both from _DwConvActCL; this Function owns the SiLU's backward), the RAW parameters
+    x_proj_weight (K,R+2,D), dt_projs_weight (K,D,R), dt_projs_bias (K,D), A_logs (K*D,1), Ds (K*D).  Returns the merged map
+    (B,L,D) before out_norm.
+    Forward: x_proj once in spatial order (GEMM, fp32 rows) -> tramba_ss2d_scan_cl (A = -exp(A_logs) formed in the kernel,
+    tile-entry states saved) -> merge.  Backward: tramba_ss2d_scan_bwd_cl (dB / dC as per-channel-tile partials, no atomics)
+    -> tramba_ss2d_bwd_prep_cl (rank rows gathered, partials summed) -> the two per-direction projections on the grouped
+    matrix-core kernels -> tramba_ss2d_bwd_assemble_cl (x_dbl-row gradients back to spatial order through the inverse
+    table, deterministic) -> x_proj input gradient (GEMM) -> tramba_ss2d_merge_grad_cl: (merge(gu) + that) * silu'(z)."""
+
+    @staticmethod
+    def forward(ctx, z, xs, xw, dt_w, dt_b, a_logs, ds, order):
+        z, xs = z.contiguous(), xs.contiguous()
+        wa, wa_t = _xproj_padded(xw, xs.dtype)
+        xdbl = hip.linear_cl(xs, wa, out_dtype=torch.float32)
+        dtw, dtb = dt_w.detach().float().contiguous(), dt_b.detach().float().reshape(-1).contiguous()
+        al, dsf = a_logs.detach().float().reshape(-1).contiguous(), ds.detach().float().contiguous()
+        states = hip.ss2d_scan_states(xs, order)
+        ys = hip.ss2d_scan_cl(xs, xdbl, order, dtw, dtb, al, dsf, xs.dtype, states=states, a_log=True)
+        ctx.save_for_backward(z, xs, xdbl, dtw, dtb, al, dsf, states, wa)
+        ctx.wa_t, ctx.order = wa_t, order
+        ctx.meta = (xw.dtype, xw.shape, dt_w.dtype, dt_b.shape, a_logs.shape)
+        return hip.ss2d_merge_sum_cl(ys, order, xs.dtype)
+
+    @staticmethod
+    def backward(ctx, gym):
+        z, xs, xdbl, dtw, dtb, al, dsf, states, wa = ctx.saved_tensors
+        order = ctx.order
+        xwdtype, xwshape, dtwdtype, dtbshape, alshape = ctx.meta
+        b, l, d = xs.shape
+        k, r = order.k, dtw.shape[-1]
+        rg = hip.ss2d_group_stride(r)
+        r8 = rg - 4
+        gym = gym.contiguous()
+        if gym.dtype not in (torch.float32, xs.dtype):
+            gym = gym.float()
+        gu, graw, bpart, cpart, gpar = hip.ss2d_scan_bwd_cl(xs, xdbl, order, dtw, dtb, al, dsf, gym, states=states,
+                                                           a_log=True, bc_partials=True)
+        cd = torch.bfloat16 if xs.dtype == torch.float32 else xs.dtype
+        ranks, gseq = hip.ss2d_bwd_prep(xdbl, order, bpart, cpart, r, torch.float32 if xs.dtype == torch.float32 else cd)
+        # the two per-direction projections on the (B,K,L,.) tensors as they are:
+        #   d(dt_projs_weight)[k] = sum_{b,l} graw^T ranks   (TN, tramba_wgrad_cl with groups = K, batches = B)
+        #   d(ranks)              = graw @ dt_w[k]           (tramba_rows_gemm_cl into the first R floats of every gseq row)
+        if xs.dtype != torch.float32:
+            g_dtw = hip.wgrad_grouped_cl(graw, ranks)                                              # (K, D, R8)
+            dtw_t = torch.empty((k, r, d), dtype=cd, device=xs.device).copy_(dtw.transpose(1, 2))   # transpose + cast
+            hip.rows_gemm_cl(graw.view(b * k, l, d), dtw_t, gseq.view(b * k, l, rg), r)
+        else:   # fp32 validation mode: three passes on bf16 splits
+            gh, gl = _split16(graw)
+            rh, rl = _split16(ranks)
+            wh, wl = _split16(dtw.transpose(1, 2).contiguous())                                    # (K, R, D)
+            g_dtw = hip.wgrad_grouped_cl(gh, rh) + hip.wgrad_grouped_cl(gh, rl) + hip.wgrad_grouped_cl(gl, rh)
+            tmp = torch.empty_like(gseq)
+            hip.rows_gemm_cl(gh.view(b * k, l, d), wh, gseq.view(b * k, l, rg), r)
+            for ga_, wa_ in ((gh, wl), (gl, wh)):
+                hip.rows_gemm_cl(ga_.view(b * k, l, d), wa_, tmp.view(b * k, l, rg), r)
+                gseq[..., :r] += tmp[..., :r]
+        if g_dtw.shape[-1] != r:
+            g_dtw = g_dtw[..., :r].contiguous()
+        g_xd = hip.ss2d_bwd_assemble(gseq, order, r, xs.dtype).view(b * l, k * rg)        # spatial order, activation dtype
+        gz = None
+        if ctx.needs_input_grad[0]:
+            t = _dgrad(g_xd, wa, ctx.wa_t).view(b, l, d)                                   # the x_proj branch's share
+            gz = hip.ss2d_merge_grad_cl(gu, order, t, z)                                   # (merge(gu) + t) * silu'(z)
+        gxw = None
+        if ctx.needs_input_grad[2]:
+            gp_ = _wgrad(g_xd, xs.view(b * l, d))[0].view(k, rg, d)
+            gxw = torch.cat((gp_[:, :r], gp_[:, r8:r8 + 2]), dim=1).to(xwdtype)
+        gp = hip.slab_sum(gpar)                                                            # (3,K,D): contiguous planes
+        return (gz, None, gxw, g_dtw.to(dtwdtype), gp[2].reshape(dtbshape), gp[0].reshape(alshape), gp[1].reshape(-1), None)
+
+
+
 class SS2D(nn.Module):
     """vmamba.py:18-323, forward_type v2 / channel_first / disable_z (the only configuration the
     shipped models use).  ``scan`` / ``merge`` / ``k_group`` are the reference's plugin API."""
@@ -1154,8 +1409,32 @@ class SS2D(nn.Module):
         y = self.out_norm._forward_cl(y, act=hip.ACT_GELU)
         return y.to(x.dtype)
 
+    def _train_path_ok(self, x):
+        """the fused training path: built-in scan family, N = 1, depth-wise conv present, autograd on"""
+        return (self.with_dconv and self._train_fused_ok(x) and isinstance(self.dropout, nn.Identity)
+                and not _infer(x, self.in_proj.weight, self.x_proj_weight, self.dt_projs_weight, self.A_logs))
+
+    def _forward_train_cl(self, xn):
+        """forwardv2 (vmamba.py:275-291) under autograd on a channels-last map that has ALREADY been normalised by the
+        caller; returns out_proj's output (the residual branch, before any add).  Seven launches: in_proj, conv + SiLU (dual
+        store), x_proj, scan, merge, out_norm + GELU (dual store), out_proj."""
+        b, h, w, _ = xn.shape
+        d = self.d_inner
+        xi = _LinearTrainCL.apply(xn, self.in_proj.weight, self.in_proj.bias)
+        z, xs = _DwConvActCL.apply(xi, self.conv2d.weight, self.conv2d.bias, hip.ACT_SILU)
+        order = hip.scan_order(self.scan._tramba_family, h, w, xn.device)
+        ym = _SS2DInnerCL.apply(z.view(b, h * w, d), xs.view(b, h * w, d), self.x_proj_weight, self.dt_projs_weight,
+                                self.dt_projs_bias, self.A_logs, self.Ds, order)
+        # out_norm and the GELU of vmamba.py:270 in one pass; out_proj's input-gradient GEMM carries the GELU's gradient
+        _, yn, ya = _AddLayerNormCL.apply(ym.view(b, h, w, d), None, None, self.out_norm.weight, self.out_norm.bias,
+                                          self.out_norm.eps, hip.ACT_GELU, False)
+        return _GeluLinearTrainCL.apply(yn, self.out_proj.weight, self.out_proj.bias, ya)
+
     def _forward_cl(self, x, residual=None, pre_norm=None):
         """pre_norm: the LayerNorm2d the caller would apply to x first (folded into in_proj where possible)"""
+        if self._train_path_ok(x):
+            y = self._forward_train_cl(x if pre_norm is None else pre_norm._forward_cl(x))
+            return y if residual is None else y + residual
         x = self.in_proj._forward_norm_cl(x, pre_norm) if pre_norm is not None else self.in_proj._forward_cl(x)
         if self.with_dconv:
             if _infer(x, self.conv2d.weight):
@@ -1204,6 +1483,31 @@ class _ResidualBlock(nn.Module):
             return _AddMasked.apply(x, y, drop_path.mask_for(y))   # x + y * mask / keep in one launch
         return branch(x)
 
+    def _train_stream_ok(self, x):
+        """autograd on, device tensor, and an SS2D that takes the fused training path: the block runs on the deferred
+        residual stream (_Deferred / _add_ln)"""
+        t = x.x if isinstance(x, _Deferred) else x
+        return self.op._train_path_ok(t)
+
+    def _forward_stream(self, x, norm_a, norm_b, defer):
+        """x1 = x + dp(op(norm_a(x))); x2 = x1 + dp(mlp(norm_b(x1))) (vmamba.py:384-396) with every residual add folded into
+        the LayerNorm that follows it (and its gradient into that LayerNorm's backward); the last add is left pending for
+        the next block's first LayerNorm when `defer`."""
+        dp = self.drop_path
+        x0, n1, _ = _add_ln(x, norm_a)
+        y1 = self.op._forward_train_cl(n1)
+        x1, n2, _ = _add_ln(_Deferred(x0, y1, dp.mask_f32(y1) if isinstance(dp, DropPath) else None), norm_b)
+        y2 = self.mlp._forward_cl(n2)
+        out = _Deferred(x1, y2, dp.mask_f32(y2) if isinstance(dp, DropPath) else None)
+        return out if defer else _resolve(out)
+
+
+def _run_blocks(blocks, x):
+    """a stage's blocks in sequence on the residual stream: adds stay pending between blocks, the stage's output is a tensor"""
+    for blk in blocks:
+        x = blk._forward_cl(x, defer=True)
+    return _resolve(x)
+
 
 class VSSBlock(_ResidualBlock):
     """vmamba.py:327-396 (pre-norm): x += SS2D(LN(x)); x += Mlp(LN(x))."""
@@ -1223,7 +1527,10 @@ class VSSBlock(_ResidualBlock):
         self.mlp = Mlp(in_features=hidden_dim, hidden_features=int(hidden_dim * mlp_ratio), act_layer=mlp_act_layer,
                        drop=mlp_drop_rate, channels_first=channel_first)
 
-    def _forward_cl(self, x):
+    def _forward_cl(self, x, defer=False):
+        if self._train_stream_ok(x):
+            return self._forward_stream(x, self.norm, self.norm2, defer)
+        x = _resolve(x)
         x = self._residual(x, lambda res: self.op._forward_cl(x, residual=res, pre_norm=self.norm), self.drop_path)
         x = self._residual(x, lambda res: self.mlp._forward_cl(x, residual=res, pre_norm=self.norm2), self.drop_path)
         return x
@@ -1279,6 +1586,11 @@ class DWMSMlp(nn.Module):
                 lambda: hip.dw_pack(c7.weight, c7.bias, c3.weight, c3.bias, c5.weight, c5.bias))
             g = hip.dwconv_cl(h, wt, bt, hip.ACT_GELU)
             defer = False
+        elif self.drop.p == 0.0 and h.is_cuda and all(c.bias is not None for c in (c3, c5, c7)):
+            # training: the folded stencil writes the pre-activation and its GELU in one launch; fc2 owns the GELU's
+            # gradient (it rides in fc2's input-gradient GEMM)
+            g, ga = _DwmsActCL.apply(h, c3.weight, c3.bias, c5.weight, c5.bias, c7.weight, c7.bias)
+            return self.fc2._forward_cl(g, residual=residual, gelu_in=True, gelu_ready=ga)
         else:
             defer = self.drop.p == 0.0     # the GELU is applied by fc2 (gradient in fc2's input-gradient GEMM)
             g = _dwms_train_cl(h, c3, c5, c7)
@@ -1311,7 +1623,10 @@ class MultiScaleDecoderBlock(_ResidualBlock):
         self.mlp = DWMSMlp(in_features=hidden_dim, hidden_features=int(hidden_dim * mlp_ratio), act_layer=mlp_act_layer,
                            drop=mlp_drop_rate, channels_first=channel_first)
 
-    def _forward_cl(self, x):
+    def _forward_cl(self, x, defer=False):
+        if self._train_stream_ok(x):
+            return self._forward_stream(x, self.norm1, self.norm2, defer)
+        x = _resolve(x)
         x = self._residual(x, lambda res: self.op._forward_cl(x, residual=res, pre_norm=self.norm1), self.drop_path)
         x = self._residual(x, lambda res: self.mlp._forward_cl(x, residual=res, pre_norm=self.norm2), self.drop_path)
         return x
@@ -1471,8 +1786,7 @@ class VSSMEncoder(nn.Module):
         x = _conv_cl(pe[5], x)
         x = pe[7]._forward_cl(x)
         for s, layer in enumerate(self.layers):
-            for blk in layer.blocks:
-                x = blk._forward_cl(x)
+            x = _run_blocks(layer.blocks, x)
             feats.append(x)
             if on_stage is not None:
                 on_stage(s, x)
