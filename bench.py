@@ -17,10 +17,13 @@ Rank 0 prints ONE JSON line.  Objects on that line besides the contract's fields
   std_ms        standard deviation of the per-step device time (HIP events between the steps of the timed region)
   latency_b1    the reference's own latency protocol (Trambav6.py:219-255): batch 1, 50 warm-up + 500 timed forwards,
                 one HIP-event pair per forward, mean / std / FPS
-  roofline      the Helix-SS2D core at the decoder's 96x96 stage (K = 8, D = 256, B = 4; 2 per forward) as a PAIR of
-                launches, fused scan + merge/out_norm: SURVEY 8(d)'s fused-Helix bytes (x once + low-rank x_proj
-                rows + merged y) / the summed average duration of the two launches, timed by HIP events on the launch
-                stream inside eager single-stream forwards of the model; `traffic` = PMC bytes of the pair
+  roofline      the Helix-SS2D core at the decoder's top stage (img/4 squared positions: 96x96 at 384, 192x192 at 768; K = 8,
+                D = 256; 2 per forward) as a PAIR of launches, fused scan + merge/out_norm: `achieved` / `peak` / `frac` =
+                SURVEY 8(d)'s fused-Helix bytes (x once + low-rank x_proj rows + merged y) / the summed average duration of
+                the two launches, timed by HIP events on the launch stream inside eager single-stream forwards of the
+                model, against the HBM peak; `bound` = "valu": the pair is vector-issue bound, not HBM bound, and
+                `valu` = {issue_floor_us, frac = floor / measured, ...} prices it against THAT ceiling from the committed SQ
+                counters; `traffic` = PMC bytes of the pair (`traffic_source`: the committed summary it is read from)
   roofline_kernel_boundary   the same two launches at their own kernel boundaries (the K-fold `ys` intermediate counted
                 where it is written and where it is read)
   roofline_fused_scan_all    every fused-scan launch of a forward (33, all shapes)
@@ -31,8 +34,11 @@ Rank 0 prints ONE JSON line.  Objects on that line besides the contract's fields
   train         BASELINE configs[2]/[3]: fwd + bwd + two-group Adam at batch 8 per GPU, gradients averaged over RCCL
                 when N > 1 (bucketed, overlapped with backward), eager launches and -- when the capture succeeds on every
                 rank -- the same step replayed as one hipGraph (`train.value` = the faster of the two, both reported as
-                `train.eager` / `train.graphed`); `train.roofline` = the forward + input-gradient GEMMs of
-                the step against the dense MFMA peak.  The leg runs under a watchdog (--train-timeout): if a collective
+                `train.eager` / `train.graphed`); `train.scaling_value` = `train.value` (THE figure a data-parallel scaling
+                curve is about: the forward leg at N > 1 is independent replicas); `train.roofline` = the forward +
+                input-gradient GEMMs of the step against the dense MFMA peak, `train.roofline_wgrad` = the weight-gradient
+                GEMMs, `train.roofline_scan_bwd` = the fused scan backward (12 B per element), all launches
+                and the Helix top-stage launch alone; `train.step_ms_by_rank` = every rank's own time for the timed steps.  The leg runs under a watchdog (--train-timeout): if a collective
                 never completes, rank 0 still prints the line, with train = {"error": ...}
 """
 import argparse
@@ -70,10 +76,11 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency protocol")
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step (config: 8)")
     ap.add_argument("--bucket-dtype", default="fp32", choices=["fp32", "bf16"], help="gradient all-reduce buckets")
-    ap.add_argument("--graph-dp", action="store_true",
-                    help="with N > 1 also capture the data-parallel step (RCCL all-reduces included) as one hipGraph; off by "
-                         "default: collective capture has only been exercised on one rank, and a rank stuck in a capture "
-                         "would take the whole multi-GPU run with it")
+    ap.add_argument("--graph-dp", action="store_true", help="(default since round 3) kept for older command lines")
+    ap.add_argument("--no-graph-dp", action="store_true",
+                    help="with N > 1 do NOT attempt the data-parallel step as one hipGraph (RCCL all-reduces captured with it) "
+                         "after the eager leg.  The attempt runs under the watchdog with the eager result already in the "
+                         "line, so a rank stuck in a capture costs only the graphed figure")
     ap.add_argument("--train-timeout", type=float, default=420.0,
                     help="seconds the training leg (and the final barrier) may take before every rank gives up on it: rank 0 "
                          "then prints the line with the forward result and train = {error}, so that a stuck collective "
@@ -195,14 +202,15 @@ def cpu_baseline(img, full):
                                          "profiles/)")}
 
 
-def boundary_scan_roofline(dtype):
-    """Op-level run of the L0 selective scan on this model's largest call shape (4,1024,9216): algorithmic bytes from the
-    library's own accounting / the average launch duration from ONE pair of HIP events around 20 back-to-back launches
-    on the launch stream (a pair per launch adds the markers' own ~8 us of serialisation to a 60 us kernel)."""
+def boundary_scan_roofline(dtype, batch=4, img=384):
+    """Op-level run of the L0 selective scan on this model's largest call shape -- (B, 1024, (img/4)^2): (4,1024,9216) at the
+    BASELINE configuration, (2,1024,36864) at 768x768 batch 2: algorithmic bytes from the library's own accounting / the
+    average launch duration from ONE pair of HIP events around 20 back-to-back launches on the launch stream (a pair per
+    launch adds the markers' own ~8 us of serialisation to a 60 us kernel)."""
     import torch
     from tramba_amd import hip
     dev = torch.device("cuda")
-    nb, kd, k, l = 4, 1024, 4, 9216
+    nb, kd, k, l = batch, 1024, 4, (img // 4) ** 2
     g = torch.Generator(device="cpu").manual_seed(0)
     u = torch.randn(nb, kd, l, generator=g).to(dev, dtype)
     delta = (0.5 * torch.randn(nb, kd, l, generator=g)).to(dev, dtype)
@@ -228,20 +236,56 @@ def boundary_scan_roofline(dtype):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     gbs = bytes_per_launch * n / (ms * 1e-3) / 1e9
-    pmc = pmc_traffic("selective_scan_fwd_kernel@grid262144")
+    pmc = pmc_traffic("selective_scan_fwd_kernel@grid262144") if (nb, l, dtype != torch.float32) == (4, 9216, True) else None
     return {"bound": "hbm", "kernel": "selective_scan_fwd_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": (pmc or {}).get("bytes"),
-            "traffic_detail": pmc, "shape": [nb, kd, l], "launches": n, "avg_us": round(ms / n * 1e3, 2)}
+            "traffic_source": (pmc or {}).get("source"), "traffic_detail": pmc, "shape": [nb, kd, l], "launches": n,
+            "avg_us": round(ms / n * 1e3, 2)}
 
 
-def helix_pair_roofline(step, nrep, batch, act_bytes):
-    """The Helix-SS2D core at 96x96 (K = 8, D = 256): fused scan launch + merge/out_norm launch, both timed INSIDE eager
-    single-stream forwards of the model by the library's launch profiler (one HIP-event pair per launch on the launch
-    stream), restricted by `tramba_profile_min_units` to launches of >= 150 MB, which only this shape reaches (scan: 184
-    MB with 2-byte ys, next largest 101 MB; merge: 170 MB, next largest 94 MB)."""
+def sq_valu_floor(key):
+    """Vector-issue floor of one launch from the newest committed SQ-counter summary (profiles/*_sq_counters.json, scripts/
+    pmc_sq.sh): SQ_ACTIVE_INST_VALU (quad-cycles summed over waves) is the time the SIMDs' vector pipes were occupied;
+    spread over the chip's 1024 SIMDs at the 2.4 GHz peak clock it is the time the launch would take if nothing but vector
+    issue limited it."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))
+    try:
+        tag = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
+        paths.sort(key=lambda q: os.path.basename(q).startswith(tag + "_"))
+    except OSError:
+        pass
+    for path in reversed(paths):
+        try:
+            ks = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+        for name, cs in ks.items():
+            if key in name and "SQ_ACTIVE_INST_VALU" in cs:
+                quad = cs["SQ_ACTIVE_INST_VALU"]["value"]
+                out = {"issue_floor_us": round(quad * 4 / 1024 / 2.4e9 * 1e6, 2), "source": os.path.relpath(path, ROOT)}
+                if "SQ_INSTS_VALU" in cs:
+                    out["valu_wave_instructions"] = cs["SQ_INSTS_VALU"]["value"]
+                if "SQ_INSTS_VALU_TRANS_F32" in cs:
+                    out["transcendental_wave_instructions"] = cs["SQ_INSTS_VALU_TRANS_F32"]["value"]
+                return out
+    return None
+
+
+def helix_pair_roofline(step, nrep, batch, act_bytes, img):
+    """The Helix-SS2D core at the decoder's top stage (H = img / 4: 96x96 at 384, 192x192 at 768; K = 8, D = 256): fused scan
+    launch + merge/out_norm launch, both timed INSIDE eager single-stream forwards of the model by the library's launch
+    profiler (one HIP-event pair per launch on the launch stream), restricted by `tramba_profile_min_units` to launches of
+    at least 0.9x this shape's kernel-boundary bytes, which only this shape reaches (it is the largest fused-scan and the
+    largest merge launch of a forward)."""
     from tramba_amd import hip
-    for which in (hip.PROF_SCAN_FUSED, hip.PROF_MERGE):
-        hip.profile_min_units(which, 150e6)
+    h = img // 4
+    b, l, d, k, r = batch, h * h, 256, 8, 8
+    rg = hip.ss2d_group_stride(r)
+    scan_bytes = b * l * d * act_bytes + b * l * k * rg * 4 + b * k * l * d * act_bytes
+    merge_bytes = b * k * l * d * act_bytes + b * l * d * act_bytes
+    for which, thr in ((hip.PROF_SCAN_FUSED, 0.9 * scan_bytes), (hip.PROF_MERGE, 0.9 * merge_bytes)):
+        hip.profile_min_units(which, thr)
         hip.profile_enable(which, True)
     for _ in range(nrep):
         step()
@@ -253,31 +297,47 @@ def helix_pair_roofline(step, nrep, batch, act_bytes):
     if ns == 0 or nm == 0:
         return None, None
     us_s, us_m = ms_s / ns * 1e3, ms_m / nm * 1e3
-    b, l, d, k, r = batch, 96 * 96, 256, 8, 8
     # SURVEY 8(d), fused Helix-SS2D: read x once + low-rank (R + 2N) x_proj rows per direction (fp32 as stored) + write
     # the merged y
     alg = b * l * d * act_bytes + (r + 2) * k * b * l * 4 + b * l * d * act_bytes
     gbs = alg / ((us_s + us_m) * 1e-6) / 1e9
-    pmc_s, pmc_m = pmc_traffic("ss2d_scan_dma_kernel@helix96"), pmc_traffic("ss2d_merge_norm_deep_kernel@helix96")
+    # the committed PMC / SQ summaries were collected on the BASELINE shape (96x96, batch 4, 16-bit): quoted only there
+    base_shape = h == 96 and b == 4 and act_bytes == 2
+    pmc_s = pmc_traffic("ss2d_scan_dma_kernel@helix96") if base_shape else None
+    pmc_m = pmc_traffic("ss2d_merge_norm_deep_kernel@helix96") if base_shape else None
     traffic = pmc_s["bytes"] + pmc_m["bytes"] if pmc_s and pmc_m else None
-    pair = {"bound": "hbm",
-            "kernel": "Helix-SS2D core at 96x96 (K=8, D=256, B=%d): ss2d_scan_dma_kernel + ss2d_merge_norm_deep_kernel" % b,
+    valu = None
+    if base_shape:
+        fs, fm = sq_valu_floor("ss2d_scan_dma_kernel"), sq_valu_floor("ss2d_merge_norm_deep_kernel")
+        if fs and fm:
+            floor = fs["issue_floor_us"] + fm["issue_floor_us"]
+            valu = {"issue_floor_us": round(floor, 2), "frac": round(floor / (us_s + us_m), 4), "scan": fs, "merge": fm,
+                    "what": "time the SIMDs' vector pipes are occupied (SQ_ACTIVE_INST_VALU, 4 cycles per quad-cycle, 1024 "
+                            "SIMDs, 2.4 GHz): the ceiling of a launch limited by vector issue alone; frac = floor / measured"}
+    shape = f"{h}x{h} (K={k}, D={d}, B={b})"
+    pair = {"bound": "valu",
+            "kernel": f"Helix-SS2D core at {shape}: ss2d_scan_dma_kernel + ss2d_merge_norm_deep_kernel",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "algorithmic_bytes": alg, "launches": ns,
-            "avg_us": round(us_s + us_m, 2), "scan_us": round(us_s, 2), "merge_us": round(us_m, 2),
-            "formula": "SURVEY 8(d) fused Helix-SS2D: B*L*D*s (x once) + (R+2N)*K*B*L*4 (x_proj rows) + B*L*D*s (merged y), "
-                       "s = activation bytes; the K-fold per-direction `ys` between the two launches is NOT counted "
-                       "(it is this implementation's intermediate: roofline_kernel_boundary counts it)",
-            "note": "both launches are VALU/transcendental-issue and latency bound, not HBM bound (DESIGN.md section 4: "
-                    "SQ counters); average HIP-event durations inside eager single-stream forwards"}
-    kb = {"scan": {"bound": "hbm", "kernel": "ss2d_scan_dma_kernel (Helix 96x96)", "achieved": round(by_s / (ms_s * 1e-3) / 1e9, 1),
+            "traffic": traffic, "traffic_source": (pmc_s or {}).get("source"), "algorithmic_bytes": alg, "launches": ns,
+            "avg_us": round(us_s + us_m, 2), "scan_us": round(us_s, 2), "merge_us": round(us_m, 2), "valu": valu,
+            "formula": "achieved / peak / frac: SURVEY 8(d) fused Helix-SS2D bytes -- B*L*D*s (x once) + (R+2N)*K*B*L*4 (x_proj "
+                       "rows) + B*L*D*s (merged y), s = activation bytes -- over the summed duration of the two launches, "
+                       "against the HBM peak; the K-fold per-direction `ys` between the two launches is NOT counted (it is "
+                       "this implementation's intermediate: roofline_kernel_boundary counts it)",
+            "note": "bound = valu: both launches are vector / transcendental-issue and latency bound, not HBM bound (DESIGN.md "
+                    "section 4: 3 transcendentals + ~17 other vector instructions per element); `valu` prices the pair "
+                    "against that ceiling.  Average HIP-event durations inside eager single-stream forwards"}
+    kb = {"scan": {"bound": "valu", "kernel": f"ss2d_scan_dma_kernel (Helix {shape})",
+                   "achieved": round(by_s / (ms_s * 1e-3) / 1e9, 1),
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by_s / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                    "algorithmic_bytes": int(by_s / ns), "avg_us": round(us_s, 2), "traffic": (pmc_s or {}).get("bytes"),
+                   "traffic_source": (pmc_s or {}).get("source"),
                    "formula": "x once + x_proj rows (padded groups) + ys (B,K,L,D) written"},
-          "merge": {"bound": "hbm", "kernel": "ss2d_merge_norm_deep_kernel (Helix 96x96)",
+          "merge": {"bound": "hbm", "kernel": f"ss2d_merge_norm_deep_kernel (Helix {shape})",
                     "achieved": round(by_m / (ms_m * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(by_m / (ms_m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(by_m / nm),
                     "avg_us": round(us_m, 2), "traffic": (pmc_m or {}).get("bytes"),
+                    "traffic_source": (pmc_m or {}).get("source"),
                     "formula": "ys (B,K,L,D) read + y (B,L,D) written"}}
     return pair, kb
 
@@ -336,7 +396,7 @@ def graphed_train_leg(model, red, x, y, world, b, steps, timed):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
-def bench_train(args, world, rank, dtype, sync_all):
+def bench_train(args, world, rank, dtype, sync_all, publish=None):
     """BASELINE configs[2]/[3]: fwd + bwd (BCE+IoU on 4 outputs) + two-group Adam, batch 8 per GPU, stochastic depth
     on; gradients averaged over RCCL in 32 MB buckets launched from autograd hooks (overlapped with backward) when
     world > 1.  Timed like the forward leg: barrier + synchronize on both sides, max over ranks."""
@@ -357,20 +417,31 @@ def bench_train(args, world, rank, dtype, sync_all):
     y = (torch.rand(b, 1, args.img, args.img, generator=torch.Generator().manual_seed(200 + rank)) > 0.7).float().cuda()
     steps, warm = max(5, args.steps // 2), 3
 
-    def timed(fn):
+    by_rank = {}
+
+    def timed(fn, tag=None):
         sync_all()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0                 # this rank's own time, before it waits for the others
         sync_all()
         t = torch.tensor([time.perf_counter() - t0], device="cuda")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            every = [torch.zeros(1, device="cuda") for _ in range(world)]
+            dist.all_gather(every, torch.tensor([mine], device="cuda"))
+            mine_all = [float(e.item()) for e in every]
+        else:
+            mine_all = [mine]
+        if tag is not None:                              # host contention between the ranks of one node shows up here
+            by_rank[tag] = [round(v / steps * 1e3, 2) for v in mine_all]
         return float(t.item())
 
     for _ in range(warm):
         train.train_step(model, opt, x, y, reducer=red)
-    dt = timed(lambda: train.train_step(model, opt, x, y, reducer=red))
+    dt = timed(lambda: train.train_step(model, opt, x, y, reducer=red), "eager")
     # share of the step the collective is not hidden behind backward: the same step with the reducer left out of the
     # exchange (world 1 semantics) cannot be run without desynchronising the replicas, so time the all-reduce of the
     # buckets alone instead and report it beside the step
@@ -395,37 +466,78 @@ def bench_train(args, world, rank, dtype, sync_all):
     # the dominant kernel family of the step: forward + input-gradient GEMMs (tramba_linear_cl), HIP-event pairs around
     # every launch of two extra eager steps (not part of the timed region)
     from tramba_amd import hip
-    hip.profile_enable(hip.PROF_GEMM, True)
+    for which in (hip.PROF_GEMM, hip.PROF_WGRAD, hip.PROF_SCAN_BWD):
+        hip.profile_enable(which, True)
     for _ in range(2):
         train.train_step(model, opt, x, y, reducer=red)
     ng, msg, flops = hip.profile_read(hip.PROF_GEMM)
-    hip.profile_enable(hip.PROF_GEMM, False)
+    nw, msw, flopw = hip.profile_read(hip.PROF_WGRAD)
+    nsb, mssb, bytes_sb = hip.profile_read(hip.PROF_SCAN_BWD)
+    for which in (hip.PROF_GEMM, hip.PROF_WGRAD, hip.PROF_SCAN_BWD):
+        hip.profile_enable(which, False)
+    # the Helix top-stage launch of the scan backward alone (the largest one: 12 B x B*K*L*D elements)
+    hh = args.img // 4
+    helix_sb = 12.0 * b * 8 * hh * hh * 256
+    hip.profile_min_units(hip.PROF_SCAN_BWD, 0.9 * helix_sb)
+    hip.profile_enable(hip.PROF_SCAN_BWD, True)
+    train.train_step(model, opt, x, y, reducer=red)
+    nsh, mssh, bytes_sh = hip.profile_read(hip.PROF_SCAN_BWD)
+    hip.profile_enable(hip.PROF_SCAN_BWD, False)
+    hip.profile_min_units(hip.PROF_SCAN_BWD, 0.0)
+    tfw = flopw / (msw * 1e-3) / 1e12 if msw > 0 else 0.0
+    roof_w = {"bound": "mfma", "kernel": "wgrad_tn_kernel (+ slab_sum_kernel): weight / bias gradients of every 1x1 conv, the "
+                                         "per-direction dt_projs_weight contractions, the DCT backward",
+              "achieved": round(tfw, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfw / MFMA_PEAK_TFS, 4),
+              "traffic": None, "launches": nw // 2, "avg_us": round(msw / max(nw, 1) * 1e3, 2), "ms_per_step": round(msw / 2, 3),
+              "note": "2*M*N*K of every tramba_wgrad_cl call / HIP-event time around the call (TN GEMM + its fixed-order slab "
+                      "sum), two eager steps"}
+    gsb = bytes_sb / (mssb * 1e-3) / 1e9 if mssb > 0 else 0.0
+    roof_sb = {"bound": "valu", "kernel": "ss2d_scan_bwd_cl_kernel, all 33 launches of a step", "achieved": round(gsb, 1),
+               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gsb / HBM_PEAK_GBS, 4), "traffic": None,
+               "launches": nsb // 2, "avg_us": round(mssb / max(nsb, 1) * 1e3, 2), "ms_per_step": round(mssb / 2, 3),
+               "formula": "SURVEY 8(d) backward of the op it replaces: 12 B per (b,k,d,l) element at 16-bit activations (u, "
+                          "delta, dout read; du, ddelta written) / HIP-event time",
+               "note": "like the forward scan the kernel is vector-issue bound (recomputes dt_proj, softplus, exp and the "
+                       "forward states per tile, then runs the adjoint recurrence), not HBM bound"}
+    if nsh > 0 and mssh > 0:
+        gsh = bytes_sh / (mssh * 1e-3) / 1e9
+        roof_sb["helix_top_stage"] = {"kernel": f"ss2d_scan_bwd_cl_kernel (Helix {hh}x{hh}, K=8, D=256, B={b})",
+                                      "achieved": round(gsh, 1), "frac": round(gsh / HBM_PEAK_GBS, 4), "launches": nsh,
+                                      "avg_us": round(mssh / nsh * 1e3, 2), "algorithmic_bytes": int(bytes_sh / nsh)}
     tfs = flops / (msg * 1e-3) / 1e12
     roof = {"bound": "mfma", "kernel": "linear_dma_kernel / linear_lean_kernel: forward + input-gradient GEMMs of the step",
             "achieved": round(tfs, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_PEAK_TFS, 4),
             "traffic": None, "launches": ng // 2, "avg_us": round(msg / ng * 1e3, 2), "ms_per_step": round(msg / 2, 3),
             "note": "2*M*N*K of every tramba_linear_cl launch / HIP-event time, two eager steps; the weight-gradient GEMMs "
                     "(wgrad_tn_kernel) and the scan backward are the next two families (profiles/*_train_kernel_stats.csv)"}
-    if world > 1 and not args.graph_dp:
-        graphed = {"skipped": "N > 1: pass --graph-dp to capture the data-parallel step (collectives included)"}
-    else:
-        graphed = graphed_train_leg(model, red, x, y, world, b, steps, timed)
     eager = {"value": round(world * b * steps / dt, 2), "unit": "img/s", "ms_per_step": round(dt / steps * 1e3, 2)}
-    # `value` = the faster of the product's two ways to run the step (train.train_step launch by launch, whose rate follows the
-    # host CPU of the box: ~3400 launches per step; tramba_amd.GraphedTrainStep = fit(graph=True)); both are reported
-    best, launch = eager, "eager"
-    if isinstance(graphed, dict) and graphed.get("value", 0.0) > eager["value"]:
-        best, launch = graphed, "hipGraph replay (tramba_amd.GraphedTrainStep)"
-    return {"metric": "images/sec fwd+bwd+Adam Tramba-V 384x384", "value": best["value"],
-            "unit": "img/s", "steps": steps, "ms_per_step": best["ms_per_step"], "batch_per_gpu": b,
-            "global_batch": b * world, "launch": launch,
-            "grad_bytes_per_step": red.bytes_per_step() if world > 1 else 0,
-            "grad_bucket_bytes": red.bytes_per_step(), "grad_buckets": len(red.buckets),
-            "grad_bucket_dtype": args.bucket_dtype, "allreduce": comm,
-            "parallelism": f"dp{world}" + ((", RCCL all-reduce (ncclAvg)" if args.backend == "nccl" else ", gloo all-reduce")
-                                            + " of gradient buckets from autograd hooks" if world > 1 else ", no collective"),
-            "stochastic_depth": "on (0.6 enc / 0.2 dec)", "dtype": args.dtype + " activations, fp32 master weights",
-            "roofline": roof, "eager": eager, "graphed": graphed}
+
+    def assemble(graphed):
+        # `value` = the faster of the product's two ways to run the step (train.train_step launch by launch, whose rate
+        # follows the host CPU of the box; tramba_amd.GraphedTrainStep = fit(graph=True)); both are reported
+        best, launch = eager, "eager"
+        if isinstance(graphed, dict) and graphed.get("value", 0.0) > eager["value"]:
+            best, launch = graphed, "hipGraph replay (tramba_amd.GraphedTrainStep)"
+        return {"metric": "images/sec fwd+bwd+Adam Tramba-V 384x384", "value": best["value"],
+                "scaling_value": best["value"], "unit": "img/s", "steps": steps, "ms_per_step": best["ms_per_step"],
+                "batch_per_gpu": b, "global_batch": b * world, "launch": launch,
+                "grad_bytes_per_step": red.bytes_per_step() if world > 1 else 0,
+                "grad_bucket_bytes": red.bytes_per_step(), "grad_buckets": len(red.buckets),
+                "grad_bucket_dtype": args.bucket_dtype, "allreduce": comm,
+                "parallelism": f"dp{world}" + ((", RCCL all-reduce (ncclAvg)" if args.backend == "nccl" else ", gloo all-reduce")
+                                                + " of gradient buckets from autograd hooks" if world > 1 else ", no collective"),
+                "stochastic_depth": "on (0.6 enc / 0.2 dec)", "dtype": args.dtype + " activations, fp32 master weights",
+                "roofline": roof, "roofline_wgrad": roof_w, "roofline_scan_bwd": roof_sb, "eager": eager, "graphed": graphed,
+                "step_ms_by_rank": dict(by_rank)}
+
+    if world > 1 and (args.no_graph_dp or args.backend != "nccl"):
+        graphed = {"skipped": "--no-graph-dp" if args.no_graph_dp else
+                   "gloo collectives stage through the host and cannot be captured into a hipGraph (RCCL's can)"}
+    else:
+        if publish is not None:   # the eager result is in the line BEFORE the capture of collectives is attempted
+            publish(assemble({"pending": "graphed data-parallel leg had not finished when the line was printed"}))
+        graphed = graphed_train_leg(model, red, x, y, world, b, steps, lambda fn: timed(fn, "graphed"))
+    return assemble(graphed)
 
 def main():
     args = parse()
@@ -527,7 +639,7 @@ def main():
                         "launches": n, "avg_us": round(ms / n * 1e3, 2), "ms_per_step": round(ms / nrep, 3),
                         "note": "kernel-boundary bytes (x once + x_proj rows + ys) / HIP-event time, summed over every "
                                 "fused-scan launch of a step (single-stream eager pass, one event pair per launch)"}
-            roof, roof_kb = helix_pair_roofline(step, nrep, args.batch, 4 if dtype == torch.float32 else 2)
+            roof, roof_kb = helix_pair_roofline(step, nrep, args.batch, 4 if dtype == torch.float32 else 2, args.img)
             _models.OVERLAP_BRANCHES = overlap_was
             tfs = flops / (msg * 1e-3) / 1e12
             roof_g = {"bound": "mfma", "kernel": "linear_dma_kernel / linear_lean_kernel / linear_tiled_kernel (1x1-conv projections)",
@@ -535,7 +647,7 @@ def main():
                       "traffic": None, "launches": ng, "avg_us": round(msg / ng * 1e3, 2), "ms_per_step": round(msg / nrep, 3),
                       "note": "2*M*N*K of every tramba_linear_cl launch of a step / their HIP-event time; these GEMMs are "
                               "small (M = 576..36864, K <= 4096): LDS- and latency-bound, far from the dense MFMA peak"}
-            roof_b = boundary_scan_roofline(dtype)
+            roof_b = boundary_scan_roofline(dtype, args.batch, args.img)
         except Exception as e:
             extras_error = f"{type(e).__name__}: {e}"[:400]
             print(f"bench.py: latency / roofline section failed: {extras_error}", file=sys.stderr)
@@ -549,7 +661,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"Tramba-V (VMamba-B encoder) {args.img}x{args.img} {args.dtype} inference, "
                                    f"batch {args.batch} per GPU, random-init weights (seed 1026), randn images",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world} replicas, no collective",
+                       "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}: the forward leg (`value`) is {world} independent replica(s), no collective; "
+                                      f"the data-parallel figure is train.scaling_value (gradient all-reduce over RCCL)",
                        "launch": ("hipGraph replay" if graph_used else "eager") +
                                  ("" if args.no_overlap else ", decoder guide branches on a side stream")},
             "latency_b1": lat,
@@ -567,8 +681,12 @@ def main():
         if done.wait(args.train_timeout):
             return
         if rank == 0:
-            line["train"] = {"error": f"training leg not finished after {args.train_timeout:.0f} s (rank 0 gave up; "
-                                      f"N = {world}, backend {args.backend})"}
+            msg = (f"training leg not finished after {args.train_timeout:.0f} s (rank 0 gave up; N = {world}, backend "
+                   f"{args.backend})")
+            if isinstance(line.get("train"), dict) and "eager" in line["train"]:
+                line["train"]["graphed"] = {"error": msg}      # the eager data-parallel result was already published
+            else:
+                line["train"] = {"error": msg}
             print(json.dumps(line), flush=True)
         os._exit(0 if rank == 0 else 3)
 
@@ -577,7 +695,8 @@ def main():
     if not args.no_train:
         ok = torch.ones(1, device="cuda")
         try:
-            train_obj = bench_train(args, world, rank, dtype, sync_all)
+            train_obj = bench_train(args, world, rank, dtype, sync_all,
+                                    publish=(lambda obj: line.__setitem__("train", obj)) if rank == 0 else None)
         except Exception as e:   # reported, not raised: the forward result stands on its own
             train_obj = {"error": f"{type(e).__name__}: {e}"[:400]}
             ok.zero_()

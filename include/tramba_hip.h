@@ -77,7 +77,12 @@ int tramba_profile_read(int which, double *total_ms, double *total_bytes);
 /* Time only the launches of class `which` that account for at least `min_units` bytes (flops): singles out one shape
  * (e.g. the Helix 96x96 fused scan inside a model forward).  0 = every launch (default). */
 int tramba_profile_min_units(int which, double min_units);
-/* Kernel-variant selection for A/B timing from scripts/ (never needed for correctness: 0 = the library's own choice).
+/* Kernel-variant selection for A/B timing from scripts/ and for tests that pin ONE form of a kernel against the oracle
+ * (never needed for correctness: 0 = the library's own choice).  MEASUREMENT-ONLY STATE: the knobs and the profile
+ * classes above are the library's only process-global mutable state (SURVEY 8(b) asks for none on the operator path):
+ * nothing on the product path (tramba_amd/) ever sets a knob, every knob defaults to 0, and with all knobs at 0 a call's
+ * result and kernel choice depend on its arguments alone.  Not thread-safe against concurrent launches by design: set a
+ * knob, time, reset.
  * knob TRAMBA_TUNE_MERGE_FORM: 1 = one wave per pixel (deep row pipeline), 2 = streaming (several pixels per wave). */
 int tramba_tune_set(int knob, int value);
 int tramba_tune_get(int knob);
@@ -93,7 +98,10 @@ int tramba_tune_get(int knob);
 #define TRAMBA_PROF_SCAN_FUSED 1
 #define TRAMBA_PROF_GEMM 2          /* tramba_linear_cl (1x1-conv projections) */
 #define TRAMBA_PROF_MERGE 3         /* tramba_ss2d_merge_norm_cl: K*L*D ys bytes read + L*D written, per image */
-#define TRAMBA_PROF_COUNT 4
+#define TRAMBA_PROF_SCAN_BWD 4      /* tramba_ss2d_scan_bwd_cl: SURVEY 8(d) backward bytes of the op it replaces, 12 B per (b,k,d,l)
+                                       element at 16-bit activations (u, delta, dout read; du, ddelta written), 20 B at fp32 */
+#define TRAMBA_PROF_WGRAD 5         /* tramba_wgrad_cl: 2*M*N*K flop per group and batch */
+#define TRAMBA_PROF_COUNT 6
 
 /* ------------------------------------------------------------------ scan-order tables (host) */
 /* Number of directions K of a family. */
@@ -222,6 +230,16 @@ int tramba_layernorm_bwd_cl(const void *x, const void *dy, const float *w, void 
 int tramba_layernorm_bwd_res_cl(const void *x, const void *dy, const float *w, void *dx, float *part, const void *gres,
                                 const float *mask, int64_t rows_per_sample, void *dxm, int64_t rows, int c, float eps,
                                 int dtype, void *stream);
+/* The general form behind the two entries above and tramba_shuffle_norm_bwd_cl (P > 1: dy is indexed through the pixel
+ * shuffle of x's row). */
+int tramba_layernorm_bwd_any_cl(const void *x, const void *dy, const float *w, void *dx, float *part, const void *gres,
+                                const float *mask, int64_t rows_per_sample, void *dxm, int64_t rows, int c, float eps, int P,
+                                int H, int W, int dtype, void *stream);
+/* Training: backward of tramba_shuffle_norm_cl.  x (B, H, W, P*P*C) the un-shuffled input, dy (B, H*P, W*P, C) the gradient of
+ * the shuffled, normalised map -> dx like x; part as tramba_layernorm_bwd_cl with rows = B*H*W*P*P.  The gradient is read
+ * through the shuffle: no permuted copy of either map exists (modules.py:209-218, 687-696 under autograd). */
+int tramba_shuffle_norm_bwd_cl(const void *x, const void *dy, const float *w, void *dx, float *part, int batch, int h,
+                               int wd, int c, int p, float eps, int dtype, void *stream);
 /* Residual add + stochastic depth + LayerNorm of the training path in one pass: xsum = x + y * mask[row / rows_per_sample]
  * (y NULL: no add, xsum unused), n = LayerNorm_C(xsum), n_act (NULL: not wanted) = act(n) -- the pre-activation / activation
  * pair a following `Linear(act(.))` needs under autograd.  x, y, xsum, n, n_act: (rows, C) dtype; w, b, mask f32. */
@@ -241,6 +259,13 @@ int tramba_shuffle_norm_head_cl(const void *x, const float *w, const float *b, c
  * Trambav6.py:62,67).  x (rows, C) dtype, w (C) f32, y (rows) f32. */
 int tramba_rowdot_cl(const void *x, const float *w, float bias, float *y, int64_t rows, int c, int dtype,
                      void *stream);
+/* Training: backward of tramba_rowdot_cl in one pass over x: gx (rows, C) dtype = gy[row] * w; part (P, C + 4) f32 receives P
+ * partial rows, P = tramba_rowdot_bwd_parts(rows, c, dtype) (0: the shape is not served -- rows wider than 64 x 16 bytes),
+ * columns 0 .. C = sum gy[row] * x[row, :] (the weight gradient), column C = sum gy[row] (the bias gradient); the caller sums
+ * over P (tramba_slab_sum).  gy (rows) f32. */
+int64_t tramba_rowdot_bwd_parts(int64_t rows, int c, int dtype);
+int tramba_rowdot_bwd_cl(const void *x, const float *gy, const float *w, void *gx, float *part, int64_t rows, int c,
+                         int dtype, void *stream);
 /* Depth-wise stencils take TAP-MAJOR weights wt (ks*ks, C) f32 + bias bt (C) f32 produced by
  * tramba_dw_pack from the reference layout w (C, ks, ks), bias (C) or NULL.  With w3/b3/w5/b5
  * non-NULL (ks = 7) it packs the multi-scale stencil of DWMSMlp: identity + 3x3 + 5x5 + 7x7 folded

@@ -12,5 +12,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 be
 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 scripts/pmc_scan.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 scripts/pmc_scan.py > $OUT/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python3 scripts/profile_train.py > $OUT/trace_train.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_train -- python3 scripts/profile_train.py > $OUT/trace_train.log 2>&1
 echo done

@@ -2,7 +2,8 @@
 """Distil gpurun_out/<tag>/ (written by scripts/collect_profiles.sh on the MI355X box) into profiles/.
 
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (MIOpen find-mode kernels dropped)
-  profiles/<tag>_train_kernel_stats.csv  the same for 3 training steps (scripts/profile_train.py)
+  profiles/<tag>_train_kernel_stats.csv  per-kernel time of ONE steady-state training step (the last step of
+                                    scripts/profile_train.py, cut out of the kernel trace by scripts/train_trace_steps.py)
   profiles/<tag>_bench.json         the bench.py line (and the --train line)
   profiles/<tag>_traffic.json       HBM bytes per launch of the two scan kernels from the PMC passes:
                                     traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB -- on gfx950 FETCH_SIZE counts
@@ -27,13 +28,15 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w.writeheader()
     w.writerows(rows)
 
-tstats = glob.glob(os.path.join(src, "trace_train", "*", "*kernel_stats.csv"))
-if tstats:   # 3 training steps (scripts/profile_train.py): fwd + bwd + Adam, batch 8
-    trows = [r for r in csv.DictReader(open(tstats[0])) if "naive_conv" not in r["Name"]]
-    with open(os.path.join(dst, f"{tag}_train_kernel_stats.csv"), "w", newline="") as f:
-        w = csv.DictWriter(f, fieldnames=list(trows[0].keys()))
-        w.writeheader()
-        w.writerows(trows)
+import subprocess
+if glob.glob(os.path.join(src, "trace_train", "**", "*kernel_trace.csv"), recursive=True):
+    # ONE steady-state training step (the last of scripts/profile_train.py's; fwd + bwd + Adam, batch 8): the first steps of a
+    # process also create the optimizer state and fill caches -- averaged over the whole process (as up to r02) they showed
+    # ~650 fill launches per step that a steady-state step does not have.  scripts/train_trace_steps.py cuts the trace at the
+    # weight-shadow refresh that ends every step.
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "train_trace_steps.py"), os.path.join(src, "trace_train"),
+                        os.path.join(dst, f"{tag}_train_kernel_stats.csv")], capture_output=True, text=True)
+    open(os.path.join(dst, f"{tag}_train_step_summary.txt"), "w").write(r.stdout.splitlines()[0] + "\n" if r.stdout else r.stderr)
 
 lines = {}
 for name in ("bench", "bench_train"):
@@ -90,7 +93,6 @@ print(json.dumps(traffic, indent=1))
 
 # per (kernel, grid) durations of the scan kernels in the single-stream trace: the Helix 96x96 launch that bench.py's
 # `roofline` object times is the grid=(4096,8) wg=512 row
-import subprocess
 tb = os.path.join(root, "scripts", "trace_by_grid.py")
 with open(os.path.join(dst, f"{tag}_scan_by_grid.txt"), "w") as f:
     for pat in ("ss2d_s", "ss2d_merge", "selective_scan"):

@@ -219,6 +219,18 @@ static int launch_layernorm(const void *x, const float *w, const float *b, void 
     return TRAMBA_OK;
 }
 
+// row q = ((b*H + h)*W + w)*P*P + p1*P + p2 of a (B, H, W, P*P*C) map -> row of output pixel (b, h*P + p1, w*P + p2): the
+// pixel shuffle 'b (p1 p2 c) h w -> b c (h p1) (w p2)' in channels-last rows (32-bit arithmetic, rows < 2^31)
+__device__ __forceinline__ long shuffled_row(long row, int P, int H, int W)
+{
+    if (P <= 1) return row;
+    const unsigned r32u = (unsigned)row, pp2 = (unsigned)(P * P);
+    const unsigned pp = r32u % pp2, pix = r32u / pp2;
+    const unsigned wi = pix % (unsigned)W, bh = pix / (unsigned)W;
+    const unsigned hi = bh % (unsigned)H, b = bh / (unsigned)H;
+    return ((long)b * (H * P) + (long)(hi * P + pp / P)) * (long)(W * P) + (long)(wi * P + pp % P);
+}
+
 // LayerNorm backward (training), channels-last rows: a wave walks RPW rows, all C channels in registers.
 //   xh = (x - mean) * rstd,  g = dy * gamma
 //   dx = rstd * (g - mean_C(g) - xh * mean_C(g * xh)),   dgamma += dy * xh,   dbeta += dy
@@ -231,8 +243,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cl_kernel(const T *__restri
                                                               float *__restrict__ part, long rows, int C, float eps,
                                                               int rpw, const T *__restrict__ gres,
                                                               const float *__restrict__ mask, long rps,
-                                                              T *__restrict__ dxm)
+                                                              T *__restrict__ dxm, int P = 1, int H = 1, int W = 1)
 {
+    // P > 1: the forward was tramba_shuffle_norm_cl -- dy is indexed by the SHUFFLED row of x's row (shuffled_row)
     // gres / mask / dxm (round 3, the residual stream of a block): dx <- dx + gres, the gradient reaching the block input
     // through the skip connection added here instead of by a separate launch; dxm = that sum * mask[sample], the gradient
     // of the PREVIOUS residual branch under stochastic depth (x = x_prev + branch * mask) -- one pass, two outputs.
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cl_kernel(const T *__restri
                 const int c0 = (it * kWave + lane) * V;
                 if (c0 + V <= C) {
                     load_pack<T, V>(x + r * C + c0, xv[it]);
-                    load_pack<T, V>(dy + r * C + c0, gv[it]);
+                    load_pack<T, V>(dy + shuffled_row(r, P, H, W) * C + c0, gv[it]);
                 }
             }
         }
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const T *__rest
                                                                 float *__restrict__ part, long rows, int C, float eps,
                                                                 int rpw, const T *__restrict__ gres,
                                                                 const float *__restrict__ mask, long rps,
-                                                                T *__restrict__ dxm)
+                                                                T *__restrict__ dxm, int P = 1, int H = 1, int W = 1)
 {
     constexpr int RPW = kWave / LPR;
     __shared__ float red[4][2 * LPR * V];     // the four waves' (dgamma, dbeta) rows, folded before they leave the block
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const T *__rest
         for (int v = 0; v < V; ++v) xv[v] = gv[v] = 0.f;
         if (ok) {
             load_pack<T, V>(x + r * C + c0, xv);
-            load_pack<T, V>(dy + r * C + c0, gv);
+            load_pack<T, V>(dy + shuffled_row(r, P, H, W) * C + c0, gv);
         }
         float sm = 0.f;
 #pragma unroll
@@ -947,6 +960,23 @@ extern "C" int tramba_layernorm_bwd_res_cl(const void *x, const void *dy, const 
                                            const void *gres, const float *mask, int64_t rows_per_sample, void *dxm,
                                            int64_t rows, int c, float eps, int dtype, void *stream)
 {
+    return tramba_layernorm_bwd_any_cl(x, dy, w, dx, part, gres, mask, rows_per_sample, dxm, rows, c, eps, 1, 1, 1, dtype,
+                                       stream);
+}
+
+extern "C" int tramba_shuffle_norm_bwd_cl(const void *x, const void *dy, const float *w, void *dx, float *part, int batch,
+                                          int h, int wd, int c, int p, float eps, int dtype, void *stream)
+{
+    TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0 && p >= 1, "shuffle_norm_bwd_cl: empty shape");
+    const int64_t rows = (int64_t)batch * h * wd * p * p;
+    TRAMBA_CHECK(rows < 2147483647L, "shuffle_norm_bwd_cl: too many rows for the 32-bit row index of this build");
+    return tramba_layernorm_bwd_any_cl(x, dy, w, dx, part, nullptr, nullptr, 0, nullptr, rows, c, eps, p, h, wd, dtype, stream);
+}
+
+extern "C" int tramba_layernorm_bwd_any_cl(const void *x, const void *dy, const float *w, void *dx, float *part,
+                                           const void *gres, const float *mask, int64_t rows_per_sample, void *dxm,
+                                           int64_t rows, int c, float eps, int P, int H, int W, int dtype, void *stream)
+{
     TRAMBA_CHECK(x && dy && w && dx && part, "layernorm_bwd_cl: null tensor");
     TRAMBA_CHECK(!mask || rows_per_sample > 0, "layernorm_bwd_cl: rows_per_sample must be positive with a mask");
     TRAMBA_CHECK((!gres || aligned16(gres)) && (!dxm || aligned16(dxm)), "layernorm_bwd_cl: tensors must be 16-byte aligned");
@@ -966,7 +996,7 @@ extern "C" int tramba_layernorm_bwd_res_cl(const void *x, const void *dy, const 
         while (lpr < c / vm) lpr <<= 1;
 #define GOB_(T, V_, L_)                                                                                             \
     hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, V_, L_>), grid, block, 0, s, (const T *)x, (const T *)dy, w, (T *)dx, \
-                       part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm)
+                       part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm, P, H, W)
 #define BYL_(T, V_)                    \
     switch (lpr) {                     \
     case 1: GOB_(T, V_, 1); break;     \
@@ -987,9 +1017,9 @@ extern "C" int tramba_layernorm_bwd_res_cl(const void *x, const void *dy, const 
     }
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
         const size_t lds = (size_t)8 * c * sizeof(float);
-        if (v == 4) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 4>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm);
-        else if (v == 2) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 2>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm);
-        else hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 1>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm);
+        if (v == 4) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 4>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm, P, H, W);
+        else if (v == 2) hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 2>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm, P, H, W);
+        else hipLaunchKernelGGL((layernorm_bwd_cl_kernel<T, 1>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm, P, H, W);
     });
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;

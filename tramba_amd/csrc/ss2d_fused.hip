@@ -1796,6 +1796,8 @@ extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const i
     hipStream_t s = (hipStream_t)stream;
     const int nk = (r + 15) / 16;
     const int ct = (d + kTP - 1) / kTP;
+    // SURVEY 8(d), backward of the op this replaces: u, delta, dout read + du, ddelta written per (b, k, d, l) element
+    ProfScope prof(TRAMBA_PROF_SCAN_BWD, s, (double)batch * k * l * (double)d * (dtype == TRAMBA_F32 ? 20.0 : 12.0));
     int W = kMaxW;   // ~220-250 VGPRs: 2 waves per SIMD = 2048 wave slots; size W for one resident wavefront of work
     while (W > 1 && (long)batch * k * ct * W > 2048) W >>= 1;
     if (W > (l + kTP - 1) / kTP) W = (l + kTP - 1) / kTP;

@@ -298,6 +298,77 @@ __global__ __launch_bounds__(256) void dw_unpack_grad_kernel(const float *__rest
         for (int q = 0; q < nb; ++q) gb[(long)q * C + c] = gwt[(long)ks * ks * C + c];
 }
 
+
+// ------------------------------------------------------------------------------------------------ C -> 1 head, backward
+// y[row] = <x[row, :], w> + b (tramba_rowdot_cl: the decoder's seg_layers, Trambav6.py:82,130).  One pass over x:
+//   gx[row, :] = gy[row] * w            (dtype)
+//   part[block][0 .. C) += gy[row] * x[row, :],  part[block][C] += gy[row]     (fp32 partial rows, summed by the caller)
+// LPR lanes per row (C <= 64 V), 64 / LPR rows of a wave in flight; a wave walks rpw rows.
+template <typename T, int V, int LPR>
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T *__restrict__ x, const float *__restrict__ gy,
+                                                        const float *__restrict__ w, T *__restrict__ gx,
+                                                        float *__restrict__ part, long rows, int C, int rpw)
+{
+    constexpr int RPW = kWave / LPR;
+    __shared__ float red[4][LPR * V + 4];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wv;
+    const long r0 = wave * rpw;
+    const long rend = r0 + rpw < rows ? r0 + rpw : rows;
+    const int sub = lane % LPR, slot = lane / LPR;
+    const int c0 = sub * V;
+    const bool cok = c0 + V <= C;
+    float wv_[V], gw[V], gb = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        wv_[v] = cok ? w[c0 + v] : 0.f;
+        gw[v] = 0.f;
+    }
+    for (long rb = r0; rb < rend; rb += RPW) {
+        const long r = rb + slot;
+        const bool ok = r < rend && cok;
+        float xv[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) xv[v] = 0.f;
+        float g = 0.f;
+        if (ok) {
+            load_pack<T, V>(x + r * C + c0, xv);
+            g = gy[r];
+            float o[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) o[v] = g * wv_[v];
+            store_pack<T, V>(gx + r * C + c0, o);
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) gw[v] = fmaf(g, xv[v], gw[v]);
+        if (sub == 0) gb += g;
+    }
+#pragma unroll
+    for (int o = LPR; o < kWave; o <<= 1) {   // fold the row slots of the wave (lanes with equal `sub`)
+#pragma unroll
+        for (int v = 0; v < V; ++v) gw[v] += __shfl_xor(gw[v], o, kWave);
+        gb += __shfl_xor(gb, o, kWave);
+    }
+    if (slot == 0) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) red[wv][c0 + v] = gw[v];
+        if (sub == 0) red[wv][LPR * V] = gb;
+    }
+    __syncthreads();
+    float *pw = part + (long)blockIdx.x * (C + 4);
+    for (int i = threadIdx.x; i < C + 4; i += 256) {
+        const int j = i < C ? i : LPR * V + (i - C);
+        pw[i] = i <= C ? (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]) : 0.f;
+    }
+}
+
+static long rowdot_bwd_rpw(long rows)
+{
+    long rpw = rows / 4096;
+    return rpw < 8 ? 8 : (rpw > 256 ? 256 : rpw);
+}
+
 }  // namespace tramba
 
 using namespace tramba;
@@ -359,6 +430,49 @@ extern "C" int tramba_dw_unpack_grad(const float *gwt, float *g7, float *g5, flo
     TRAMBA_CHECK((g5 == nullptr) == (g3 == nullptr) && (!g5 || ks == 7), "dw_unpack_grad: multi-scale needs ks = 7, g5 and g3");
     hipLaunchKernelGGL(dw_unpack_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gwt, g7, g5, g3, gb,
                        nb, c, ks);
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int64_t tramba_rowdot_bwd_parts(int64_t rows, int c, int dtype)
+{
+    const int vm = dtype == TRAMBA_F32 ? 4 : 8;
+    if (rows <= 0 || c <= 0 || c % vm != 0 || c > kWave * vm) return 0;     // 0: shape not served by this kernel
+    const long rpw = rowdot_bwd_rpw(rows);
+    return ((rows + rpw - 1) / rpw + 3) / 4;
+}
+
+extern "C" int tramba_rowdot_bwd_cl(const void *x, const float *gy, const float *w, void *gx, float *part, int64_t rows,
+                                    int c, int dtype, void *stream)
+{
+    TRAMBA_CHECK(x && gy && w && gx && part, "rowdot_bwd_cl: null tensor");
+    TRAMBA_CHECK(tramba_rowdot_bwd_parts(rows, c, dtype) > 0, "rowdot_bwd_cl: C=%d is not served (rows of at most 64 x 16 bytes)", c);
+    TRAMBA_CHECK(aligned16(x) && aligned16(gx) && aligned16(w), "rowdot_bwd_cl: tensors must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const long rpw = rowdot_bwd_rpw(rows);
+    const long waves = (rows + rpw - 1) / rpw;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    const int vm = dtype == TRAMBA_F32 ? 4 : 8;
+    int lpr = 1;
+    while (lpr < c / vm) lpr <<= 1;
+#define GOB_(T, V_, L_)                                                                                                   \
+    hipLaunchKernelGGL((rowdot_bwd_kernel<T, V_, L_>), grid, block, 0, s, (const T *)x, gy, w, (T *)gx, part, (long)rows, c, \
+                       (int)rpw)
+#define BYL_(T, V_)                    \
+    switch (lpr) {                     \
+    case 1: GOB_(T, V_, 1); break;     \
+    case 2: GOB_(T, V_, 2); break;     \
+    case 4: GOB_(T, V_, 4); break;     \
+    case 8: GOB_(T, V_, 8); break;     \
+    case 16: GOB_(T, V_, 16); break;   \
+    case 32: GOB_(T, V_, 32); break;   \
+    default: GOB_(T, V_, 64); break;   \
+    }
+    if (dtype == TRAMBA_F32) { BYL_(float, 4) }
+    else if (dtype == TRAMBA_BF16) { BYL_(__hip_bfloat16, 8) }
+    else { BYL_(__half, 8) }
+#undef BYL_
+#undef GOB_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }

@@ -434,6 +434,7 @@ extern "C" int tramba_wgrad_cl(const void *gy, const void *x, float *out, void *
     wgrad_plan(m, n, k, groups, nbatch, nsplit, mchunk);
     TRAMBA_CHECK((long)groups * nbatch * nsplit <= 65535, "wgrad_cl: too many token chunks");
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(TRAMBA_PROF_WGRAD, s, 2.0 * (double)m * n * k * groups * nbatch);
     WgradArgs a;
     const bool direct = nsplit * nbatch == 1;          // one slab per group: it IS the result
     a.gy = gy; a.x = x; a.part = direct ? out : (float *)workspace;

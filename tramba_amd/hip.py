@@ -20,7 +20,7 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_SIGMOID_GATE, ACT_GELU_GRAD_MUL = 0, 1, 2, 3, 
 SCAN_RASTER, SCAN_LINE, SCAN_HELIX, SCAN_WINDOW, SCAN_DILATION = range(5)
 FAMILY = {"raster": SCAN_RASTER, "line": SCAN_LINE, "helix": SCAN_HELIX, "window": SCAN_WINDOW,
           "dilation": SCAN_DILATION}
-PROF_SCAN_BOUNDARY, PROF_SCAN_FUSED, PROF_GEMM, PROF_MERGE = 0, 1, 2, 3
+PROF_SCAN_BOUNDARY, PROF_SCAN_FUSED, PROF_GEMM, PROF_MERGE, PROF_SCAN_BWD, PROF_WGRAD = 0, 1, 2, 3, 4, 5
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -57,10 +57,14 @@ SIGNATURES = {
     "tramba_layernorm_bwd_parts": (c_i64, [c_i64, c_int, c_int]),
     "tramba_layernorm_bwd_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_f, c_int, c_vp]),
     "tramba_layernorm_bwd_res_cl": (c_int, [c_vp] * 7 + [c_i64, c_vp, c_i64, c_int, c_f, c_int, c_vp]),
+    "tramba_layernorm_bwd_any_cl": (c_int, [c_vp] * 7 + [c_i64, c_vp, c_i64, c_int, c_f, c_int, c_int, c_int, c_int, c_vp]),
+    "tramba_shuffle_norm_bwd_cl": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_add_layernorm_cl": (c_int, [c_vp] * 3 + [c_i64] + [c_vp] * 5 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_shuffle_norm_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_shuffle_norm_head_cl": (c_int, [c_vp] * 4 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_rowdot_cl": (c_int, [c_vp, c_vp, c_f, c_vp, c_i64, c_int, c_int, c_vp]),
+    "tramba_rowdot_bwd_parts": (c_i64, [c_i64, c_int, c_int]),
+    "tramba_rowdot_bwd_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_vp]),
     "tramba_saliency_stats": (c_int, [c_vp] * 4 + [c_int] * 3 + [c_vp]),
     "tramba_dw_pack": (c_int, [c_vp] * 8 + [c_int] * 2 + [c_vp]),
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
@@ -558,6 +562,22 @@ def shuffle_norm_cl(x, w, b, p, eps=1e-5):
     return y
 
 
+def shuffle_norm_bwd_cl(x, dy, w, p, eps=1e-5):
+    """backward of shuffle_norm_cl: x (B,H,W,P*P*C), dy (B,H*P,W*P,C) -> (dx like x, dw (C), db (C))"""
+    _dev(x, dy, w)
+    bb, h, wd, cc = x.shape
+    c = cc // (p * p)
+    if dy.shape != (bb, h * p, wd * p, c) or dy.dtype != x.dtype:
+        raise TrambaHipError("shuffle_norm_bwd_cl: dy does not match the shuffled map")
+    rows = bb * h * wd * p * p
+    dx = torch.empty_like(x)
+    part = torch.empty((lib().tramba_layernorm_bwd_parts(rows, c, dt(x)), 2, c), dtype=torch.float32, device=x.device)
+    _check(lib().tramba_shuffle_norm_bwd_cl(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(part), bb, h, wd, c, p, eps, dt(x),
+                                            _stream()), "shuffle_norm_bwd_cl")
+    s = slab_sum(part)
+    return dx, s[0], s[1]
+
+
 def shuffle_norm_head_cl(x, w, b, head_w, head_b: float, p, eps=1e-5):
     """x: (B, H, W, P*P*C) -> (B, H*P, W*P) f32: pixel-shuffle + LayerNorm over C + dot with head_w (C) + head_b."""
     _dev(x, w, b, head_w)
@@ -606,6 +626,30 @@ def rowdot_cl(x, w, bias: float):
     y = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
     _check(lib().tramba_rowdot_cl(_ptr(x), _ptr(w), float(bias), _ptr(y), x.numel() // c, c, dt(x), _stream()), "rowdot_cl")
     return y
+
+
+def rowdot_bwd_ok(x):
+    """does the one-pass backward kernel of rowdot_cl serve this map? (rows of at most 64 x 16 bytes)"""
+    c = x.shape[-1]
+    return x.is_cuda and lib().tramba_rowdot_bwd_parts(x.numel() // c, c, dt(x)) > 0
+
+
+def rowdot_bwd_cl(x, gy, w):
+    """backward of rowdot_cl: x (..., C), gy (...) f32, w (C) f32 -> (gx like x, gw (C) f32, gb () f32)"""
+    _dev(x, gy, w)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    if gy.dtype != torch.float32 or gy.numel() != rows:
+        raise TrambaHipError("rowdot_bwd_cl: gy must be float32 with one entry per row")
+    nparts = lib().tramba_rowdot_bwd_parts(rows, c, dt(x))
+    if nparts <= 0:
+        raise TrambaHipError(f"rowdot_bwd_cl: C={c} is not served")
+    gx = torch.empty_like(x)
+    part = torch.empty((nparts, c + 4), dtype=torch.float32, device=x.device)
+    _check(lib().tramba_rowdot_bwd_cl(_ptr(x), _ptr(gy), _ptr(w), _ptr(gx), _ptr(part), rows, c, dt(x), _stream()),
+           "rowdot_bwd_cl")
+    s_ = slab_sum(part)
+    return gx, s_[:c], s_[c]
 
 
 def dw_pack(w, bias=None, w3=None, b3=None, w5=None, b5=None):

@@ -342,6 +342,9 @@ def _shadow_params(model):
             p = m.x_proj_weight
             if p.is_cuda and p.dtype == torch.float32 and p.dim() == 3 and p.shape[1] == m.dt_rank + 2:
                 out.append((p, m.dt_rank))
+            q = m.dt_projs_weight          # (K, D, R): the scan backward's rank projection reads its (K, R, D) transpose
+            if q.is_cuda and q.dtype == torch.float32 and q.dim() == 3:
+                out.append((q, "dtw"))
     return out
 
 
@@ -370,7 +373,16 @@ def refresh_lowp_shadows(model, dtype):
 
         for p, r in params:
             ent = _lowp_shadow.get(id(p))
-            if r is None:      # Linear2d weight (N, K): W and W^T
+            if r == "dtw":     # dt_projs_weight (K, D, R): only the per-direction transposes (K, R, D)
+                kk, d, rr = p.shape
+                if (ent is None or ent[3] is None or ent[3].dtype != dtype or ent[3].shape != (kk, rr, d)
+                        or ent[3].device != p.device or ent[2]() is not p):
+                    tt = torch.empty((kk, rr, d), dtype=dtype, device=p.device)
+                    ent = [tt, -1, weakref.ref(p), tt]
+                    _lowp_shadow[id(p)] = ent
+                for g in range(kk):
+                    entry(p.data_ptr() + g * d * rr * 4, 0, ent[3].data_ptr() + g * rr * d * es, d, rr, rr, d)
+            elif r is None:      # Linear2d weight (N, K): W and W^T
                 n, k = p.shape
                 if (ent is None or ent[0].dtype != dtype or ent[0].shape != p.shape or ent[0].device != p.device
                         or ent[2]() is not p or ent[3] is None):
@@ -405,8 +417,8 @@ def restamp_lowp_shadows(model):
     """Declare the shadows of `model`'s parameters current (after a hipGraph replay that refreshed them itself and a
     version bump of the parameters: tramba_amd.graph.GraphedTrainStep)."""
     for m in model.modules():
-        p = m.weight if isinstance(m, Linear2d) else (m.x_proj_weight if isinstance(m, SS2D) else None)
-        if p is not None:
+        ps = (m.weight,) if isinstance(m, Linear2d) else ((m.x_proj_weight, m.dt_projs_weight) if isinstance(m, SS2D) else ())
+        for p in ps:
             ent = _lowp_shadow.get(id(p))
             if ent is not None and ent[2]() is p:
                 ent[1] = p._version
@@ -530,6 +542,38 @@ class _LinearGeluPairTrainCL(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _Linear2TrainCL(torch.autograd.Function):
+    """y = [x1 | x2] @ w^T + b under autograd without the concatenation (decoder concat_back_dim, Trambav6.py:122-125;
+    FreqSS2Dv6, freq_mamba.py:52-56): forward tramba_linear2_cl (the K loop reads the two tensors in turn); the two input
+    gradients are GEMMs against the two row blocks of W^T, the weight gradient two TN GEMMs side by side."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, b):
+        wa = _lowp(w, x1.dtype).detach().contiguous()
+        k1, k2 = x1.shape[-1], x2.shape[-1]
+        a1, a2 = x1.reshape(-1, k1).contiguous(), x2.reshape(-1, k2).contiguous()
+        ctx.save_for_backward(a1, a2, wa)
+        ctx.wa_t = _lowp_t(w, x1.dtype)
+        ctx.wdtype, ctx.has_bias, ctx.shapes = w.dtype, b is not None, (x1.shape, x2.shape)
+        y = hip.linear2_cl(a1, a2, wa, None if b is None else b.detach().float().contiguous())
+        return y.view(x1.shape[:-1] + (wa.shape[0],))
+
+    @staticmethod
+    def backward(ctx, gy):
+        a1, a2, wa = ctx.saved_tensors
+        k1 = a1.shape[1]
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        gy2 = gy2 if gy2.is_contiguous() and gy2.dtype == a1.dtype else gy2.to(a1.dtype).contiguous()
+        wt = wa.t().contiguous() if ctx.wa_t is None else ctx.wa_t             # (K1 + K2, N)
+        g1 = hip.linear_cl(gy2, wt[:k1]).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
+        g2 = hip.linear_cl(gy2, wt[k1:]).view(ctx.shapes[1]) if ctx.needs_input_grad[1] else None
+        gw = gb = None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            gw1, gb = _wgrad(gy2, a1, ctx.has_bias)
+            gw = torch.cat((gw1, _wgrad(gy2, a2)[0]), dim=1).to(ctx.wdtype)
+        return g1, g2, gw, gb
+
+
 class _RowDotCL(torch.autograd.Function):
     """A C -> 1 segmentation head (nn.Conv2d(C, 1, 1), Trambav6.py:82,130) on a channels-last map with autograd:
     forward tramba_rowdot_cl (fp32 logits), weight gradient on tramba_wgrad_cl (the one output channel padded to the
@@ -547,6 +591,9 @@ class _RowDotCL(torch.autograd.Function):
     def backward(ctx, gy):
         x, wf = ctx.saved_tensors
         gx = gw = gb = None
+        if hip.rowdot_bwd_ok(x):   # one pass over x: input, weight and bias gradient (tramba_rowdot_bwd_cl)
+            gx, gw, gb = hip.rowdot_bwd_cl(x, gy.float().contiguous(), wf)
+            return gx, gw.reshape(ctx.wshape).to(ctx.wdtype), gb.reshape(1)
         if ctx.needs_input_grad[0]:
             gx = (gy.unsqueeze(-1) * wf).to(x.dtype)
         if ctx.needs_input_grad[1]:
@@ -603,6 +650,12 @@ class Linear2d(nn.Linear):
             w = self.weight if self.weight.dtype == x1.dtype else self.weight.to(x1.dtype)
             return hip.linear2_cl(x1.contiguous(), x2.contiguous(), w.detach(), _f32(self.bias), residual, act, out_dtype)
         gate = act == hip.ACT_SIGMOID_GATE
+        if (x1.is_cuda and x1.dtype in (torch.bfloat16, torch.float16) and x2.dtype == x1.dtype and out_dtype is None
+                and x1.shape[-1] % 64 == 0 and x2.shape[-1] % 64 == 0 and self.weight.shape[0] % 8 == 0):
+            y = _act_torch(_Linear2TrainCL.apply(x1, x2, self.weight, self.bias), hip.ACT_NONE if gate else act)
+            if gate:
+                return torch.sigmoid(y) * residual
+            return y if residual is None else y + residual
         y = self._forward_cl(torch.cat((x1, x2), dim=-1), act=hip.ACT_NONE if gate else act,
                              residual=None if gate else residual, out_dtype=out_dtype)
         return torch.sigmoid(y) * residual if gate else y
@@ -708,6 +761,29 @@ class Mlp(nn.Module):
         return from_cl(self._forward_cl(to_cl(x)))
 
 
+class _ShuffleNormCL(torch.autograd.Function):
+    """rearrange 'b (p1 p2 c) h w -> b c (h p1) (w p2)' + LayerNorm2d(c) under autograd (PatchExpand / FreqExpand2D on the
+    training path): forward tramba_shuffle_norm_cl (the shuffle is the store address of the LayerNorm), backward
+    tramba_shuffle_norm_bwd_cl (the gradient is read through the shuffle) -- no permuted copy of either map."""
+
+    @staticmethod
+    def forward(ctx, xe, w, b, p, eps):
+        xe = xe.contiguous()
+        wf = w.detach().float().contiguous()
+        ctx.save_for_backward(xe, wf)
+        ctx.p, ctx.eps = p, eps
+        return hip.shuffle_norm_cl(xe, wf, b.detach().float().contiguous(), p, eps)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xe, wf = ctx.saved_tensors
+        gy = gy.contiguous()
+        if gy.dtype != xe.dtype:
+            gy = gy.to(xe.dtype)
+        dx, dw, db = hip.shuffle_norm_bwd_cl(xe, gy, wf, ctx.p, ctx.eps)
+        return dx, dw, db, None, None
+
+
 class _ExpandShuffleNorm(nn.Module):
     """1x1 expand -> 'b (p1 p2 c) h w -> b c (h p1) (w p2)' -> LayerNorm2d(c)."""
 
@@ -717,6 +793,8 @@ class _ExpandShuffleNorm(nn.Module):
         p = self.scale
         if _infer(xe, self.norm.weight):
             return hip.shuffle_norm_cl(xe, _f32(self.norm.weight), _f32(self.norm.bias), p, self.norm.eps)
+        if xe.is_cuda:
+            return _ShuffleNormCL.apply(xe, self.norm.weight, self.norm.bias, p, self.norm.eps)
         b, h, w, cc = xe.shape
         c = cc // (p * p)
         y = xe.view(b, h, w, p, p, c).permute(0, 1, 3, 2, 4, 5).reshape(b, h * p, w * p, c)
@@ -1240,6 +1318,9 @@ class _SS2DInnerCL(torch.autograd.Function):
         ys = hip.ss2d_scan_cl(xs, xdbl, order, dtw, dtb, al, dsf, xs.dtype, states=states, a_log=True)
         ctx.save_for_backward(z, xs, xdbl, dtw, dtb, al, dsf, states, wa)
         ctx.wa_t, ctx.order = wa_t, order
+        ent = _lowp_shadow.get(id(dt_w))
+        ctx.dtw_t = ent[3] if (ent is not None and ent[1] == dt_w._version and ent[2]() is dt_w
+                               and ent[3] is not None and ent[3].dtype == xs.dtype) else None
         ctx.meta = (xw.dtype, xw.shape, dt_w.dtype, dt_b.shape, a_logs.shape)
         return hip.ss2d_merge_sum_cl(ys, order, xs.dtype)
 
@@ -1264,7 +1345,9 @@ class _SS2DInnerCL(torch.autograd.Function):
         #   d(ranks)              = graw @ dt_w[k]           (tramba_rows_gemm_cl into the first R floats of every gseq row)
         if xs.dtype != torch.float32:
             g_dtw = hip.wgrad_grouped_cl(graw, ranks)                                              # (K, D, R8)
-            dtw_t = torch.empty((k, r, d), dtype=cd, device=xs.device).copy_(dtw.transpose(1, 2))   # transpose + cast
+            dtw_t = ctx.dtw_t            # (K, R, D): the shadow written after the optimizer step, when current
+            if dtw_t is None:
+                dtw_t = torch.empty((k, r, d), dtype=cd, device=xs.device).copy_(dtw.transpose(1, 2))   # transpose + cast
             hip.rows_gemm_cl(graw.view(b * k, l, d), dtw_t, gseq.view(b * k, l, rg), r)
         else:   # fp32 validation mode: three passes on bf16 splits
             gh, gl = _split16(graw)
