@@ -109,10 +109,11 @@ def mae_metric(pred: np.ndarray, gt: np.ndarray) -> float:
 
 
 # ----------------------------------------------------------------------------- SS2D core
-def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, family):
+def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, family, merge=True):
     """vmamba.py:230-257 (non-cascade branch, no_einsum=True): scan -> grouped x_proj ->
     split [R,N,N] -> grouped dt_proj -> selective scan -> merge.  Returns (B, D, H, W)
-    BEFORE out_norm."""
+    BEFORE out_norm; merge=False: the per-direction scan outputs (B, K, L, D), sequence order,
+    channels last (what the HIP scan kernel writes before its merge kernel)."""
     b, d, h, w = x.shape
     k, _, r = dt_projs_weight.shape
     n = A_logs.shape[1]
@@ -125,5 +126,7 @@ def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, fami
     ys = selective_scan(
         xs.reshape(b, k * d, l), dts.reshape(b, k * d, l).contiguous(), a,
         bs.contiguous(), cs.contiguous(), Ds.to(x.dtype), dt_projs_bias.reshape(-1).to(x.dtype), True)
+    if not merge:
+        return ys.reshape(b, k, d, l).permute(0, 1, 3, 2).contiguous()
     y = cross_merge(ys.reshape(b, k, d, l), family, h, w)
     return y.reshape(b, d, h, w)

@@ -238,6 +238,44 @@ def test_ss2d_fused_core(dtype, fam, cfg):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("fam,b,h,d,r", [("helix", 4, 96, 256, 8), ("raster", 4, 96, 256, 8), ("helix", 4, 48, 512, 16),
+                                         ("window", 8, 48, 512, 16), ("helix", 2, 96, 256, 8)])
+def test_ss2d_lds_dma_scan_at_the_benchmarked_launches(dtype, fam, b, h, d, r):
+    """The launches bench.py's `roofline` object times -- ss2d_scan_dma_kernel + the deep / streaming merge at B=4, 96x96,
+    D=256, K=8 (BASELINE configs[1]), its K=4 sibling, the 48x48 rank-16 form and the 8-wave workgroups of a smaller batch --
+    DIRECTLY against the fp64 oracle (vmamba.py:230-257 composed with csms6s.py:161-216), 16-bit `ys` as the model runs it.
+    test_ss2d_fused_core's maps stay below the 2048-wave rule that selects this kernel."""
+    k = 8 if fam == "helix" else 4
+    g = torch.Generator().manual_seed(h * d + k + b)
+    x = torch.randn(b, d, h, h, generator=g).to(dtype)
+    wx = (torch.randn(k, r + 2, d, generator=g) * d ** -0.5).to(dtype)
+    wdt = torch.randn(k, d, r, generator=g) * r ** -0.5
+    dtb = torch.randn(k, d, generator=g) * 0.5 - 2.0
+    a_logs = torch.log(0.5 + torch.rand(k * d, 1, generator=g))
+    ds = 1 + 0.1 * torch.randn(k * d, generator=g)
+    lw, lb = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    # the oracle's per-direction outputs (B,K,L,D) before the merge, then its merge + out_norm + GELU
+    ys_want = oo.ss2d_core(x.double(), wx.double(), wdt.double(), dtb.double(), a_logs.double(), ds.double(), fam, merge=False)
+    y = oo.cross_merge(ys_want.permute(0, 1, 3, 2), fam, h, h).reshape(b, d, h, h)
+    want = F.gelu(oo.layernorm2d(y, lw.double(), lb.double())).permute(0, 2, 3, 1)
+    H = hip()
+    dev = torch.device(DEV)
+    order = H.scan_order(fam, h, h, dev)
+    xc = x.permute(0, 2, 3, 1).contiguous().view(b, h * h, d).to(dev)
+    xdbl = H.linear_cl(xc, H.pad_x_proj_weight(wx.to(dev)), out_dtype=torch.float32)
+    ys = H.ss2d_scan_cl(xc, xdbl, order, wdt.to(dev), dtb.reshape(-1).to(dev), (-torch.exp(a_logs)).reshape(-1).to(dev),
+                        ds.to(dev), dtype)
+    err = (ys.cpu().double() - ys_want).abs()
+    scale = float(ys_want.abs().max())
+    assert float(err.max()) <= 2e-2 * scale, (float(err.max()), scale)          # 16-bit rounding of ys: 2^-9 relative
+    assert float(err.pow(2).mean().sqrt()) <= 3e-3 * float(ys_want.pow(2).mean().sqrt())
+    out = H.ss2d_merge_norm_cl(ys, order, lw.to(dev), lb.to(dev), 1e-5, 2, dtype)
+    np.testing.assert_allclose(out.view(b, h, h, d).cpu().double().numpy(), want.numpy(), rtol=4e-2, atol=4e-2)
+    assert torch.equal(ys, H.ss2d_scan_cl(xc, xdbl, order, wdt.to(dev), dtb.reshape(-1).to(dev),
+                                          (-torch.exp(a_logs)).reshape(-1).to(dev), ds.to(dev), dtype))   # run-to-run bitwise
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [(2, 12, 64, 40), (1, 24, 128, 256), (1, 13, 64, 64), (1, 48, 256, 130)])
 def test_conv3x3s2_cl(dtype, cfg):
     """implicit-GEMM 3x3 / stride 2 / pad 1 conv (patch_embed[5], downsample) against F.conv2d in fp64."""

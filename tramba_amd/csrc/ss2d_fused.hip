@@ -128,6 +128,38 @@ __device__ __forceinline__ void buf_store_elem<__half>(__amdgpu_buffer_rsrc_t r,
     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), r, voff, soff, 0);
 }
 
+// Two elements of one lane (same channel, two positions): ONE packed conversion, the lower half stored by
+// buffer_store_short and the upper half by buffer_store_short_d16_hi -- a conversion per element would cost the VALU-bound
+// scan kernels 8 more instructions per tile.  hipcc has no pattern from (pk >> 16) to the d16_hi store, hence the asm;
+// device pass only (the host pass sees the generic pair of stores, which it never runs).
+template <typename TY>
+__device__ __forceinline__ void buf_store_pair(__amdgpu_buffer_rsrc_t r, unsigned v0, unsigned s0, unsigned v1, unsigned s1,
+                                               float a, float b)
+{
+    buf_store_elem<TY>(r, v0, s0, a);
+    buf_store_elem<TY>(r, v1, s1, b);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+template <>
+__device__ __forceinline__ void buf_store_pair<__hip_bfloat16>(__amdgpu_buffer_rsrc_t r, unsigned v0, unsigned s0, unsigned v1,
+                                                               unsigned s1, float a, float b)
+{
+    unsigned pk;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+    asm volatile("buffer_store_short %0, %1, %2, %3 offen" ::"v"(pk), "v"(v0), "s"(r), "s"(s0) : "memory");
+    asm volatile("buffer_store_short_d16_hi %0, %1, %2, %3 offen" ::"v"(pk), "v"(v1), "s"(r), "s"(s1) : "memory");
+}
+template <>
+__device__ __forceinline__ void buf_store_pair<__half>(__amdgpu_buffer_rsrc_t r, unsigned v0, unsigned s0, unsigned v1,
+                                                       unsigned s1, float a, float b)
+{
+    unsigned pk;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+    asm volatile("buffer_store_short %0, %1, %2, %3 offen" ::"v"(pk), "v"(v0), "s"(r), "s"(s0) : "memory");
+    asm volatile("buffer_store_short_d16_hi %0, %1, %2, %3 offen" ::"v"(pk), "v"(v1), "s"(r), "s"(s1) : "memory");
+}
+#endif
+
 template <typename T, int NK>
 struct TileOps {
     float araw[NK][8];               // x_dbl row of MY position (lane & 31), ranks 16kk + 8hi .. +7
@@ -142,11 +174,11 @@ struct TileOps {
 // Arithmetic per element (the kernels are VALU-bound, so every instruction here was counted):
 //   x' = (dt_raw + bias) * log2(e)   straight out of the MFMA: log2(e) is folded into the dt_w fragments and
 //                                    the accumulator starts at bias * log2(e)
-//   t  = x' > 30 ? x' : log2(1 + exp2(x'))             = softplus(dt_raw + bias) * log2(e)
+//   t  = med3(log2(1 + exp2(x')), x', 128)             = softplus(dt_raw + bias) * log2(e)
 //        (the reference's threshold form, x > 20 -> x, equals this to below fp32 resolution)
 //   a  = exp2(t * A)                                   = exp(dt * A)
 //   bb = t * (B*ln2 * u)                               = dt * B * u      (ln2 folded into the staged B)
-// i.e. 3 transcendentals + min, max and 4 packed-able mul/add per element.  Positions past the end of the
+// i.e. 3 transcendentals + one med3 and 4 packed-able mul/add per element.  Positions past the end of the
 // sequence start the accumulator at -1e30 instead: t = 0 exactly, hence a = 1, bb = 0 (the identity).
 // lower-half / upper-half broadcast of a wave-wide value (gfx950 v_permlane32_swap)
 __device__ __forceinline__ void half_swap(float x, float &lower, float &upper)
@@ -257,7 +289,10 @@ struct ScanWave {
     // inside the sequence (>= 32: all of them)
     // UF_READY: uf already holds the 16 inputs as floats (the LDS-DMA kernel reads bf16 straight into the upper half of
     // a zeroed register), cur.u is not looked at
-    template <bool UF_READY = false>
+    // BIAS_MFMA (LDS-DMA kernel, dt_rank padded to 8 of the MFMA's 16 k slots): the bias rides in two spare k slots -- the
+    // upper half-wave supplies A = (1, 1, 0..) and B = (bf16 hi, bf16 lo of bias * log2 e, 0..) -- so the accumulator starts
+    // at the inline constant 0 instead of 16 register copies of the bias per tile (2^-17 relative on the bias)
+    template <bool UF_READY = false, bool BIAS_MFMA = false>
     __device__ __forceinline__ void terms(const TileOps<T, NK> &cur, const float (&Bp)[16], int nvalid, float (&a)[16],
                                           float (&bb)[16], float (&uf)[16], float *tl = nullptr) const
     {
@@ -265,16 +300,30 @@ struct ScanWave {
 #pragma unroll
             for (int r = 0; r < 16; ++r) uf[r] = raw_to_f<T>(cur.u[r]);
         }
+        const float b0 = BIAS_MFMA ? 0.f : bias2;
         acc16_t acc;
-        if (nvalid < kTP) {  // wave-uniform: only the last tile of a sequence / segment
+        {
+            frag8_t ah, al;
+            pack_frag<SPLIT>(cur.araw[0], ah, al);
+            // two MFMA sites: the full tile's accumulator operand is a constant splat (the inline 0 with BIAS_MFMA), not a
+            // register tuple that a merged path would have to fill per tile
+            if (nvalid < kTP) {  // wave-uniform: only the last tile of a sequence / segment
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = (r & 3) + 8 * (r >> 2) + 4 * hi < nvalid ? bias2 : -1.0e30f;
-        } else {
+                for (int r = 0; r < 16; ++r) acc[r] = (r & 3) + 8 * (r >> 2) + 4 * hi < nvalid ? b0 : -1.0e30f;
+                acc = mfma_bf16(ah, wh[0], acc);
+            } else {
+                acc16_t c0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bias2;
+                for (int r = 0; r < 16; ++r) c0[r] = b0;
+                acc = mfma_bf16(ah, wh[0], c0);
+            }
+            if (SPLIT) {
+                acc = mfma_bf16(ah, wl[0], acc);
+                acc = mfma_bf16(al, wh[0], acc);
+            }
         }
 #pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
+        for (int kk = 1; kk < NK; ++kk) {
             frag8_t ah, al;
             pack_frag<SPLIT>(cur.araw[kk], ah, al);
             acc = mfma_bf16(ah, wh[kk], acc);
@@ -287,11 +336,13 @@ struct ScanWave {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const v2f xr = {acc[r], acc[r + 1]};
-            // x' > 30: log2(1 + 2^x') == x' to below fp32 resolution (and 2^x' may overflow to +inf, whose log2 is
-            // discarded by the select) -- one compare + select instead of min, max and an IEEE canonicalize
+            // log2(1 + 2^x') == x' to within an fp32 ulp once x' > 30, but 2^x' overflows to +inf from x' = 128 on.  The
+            // median of (log2(1 + 2^x'), x', 128) is the first below 128 and x' itself beyond -- ONE v_med3_f32 where a
+            // compare + select pair stood (the kernel is VALU-issue bound: 16 instructions per tile)
             v2f z = {__builtin_amdgcn_exp2f(xr.x), __builtin_amdgcn_exp2f(xr.y)};
             z = z + one;
-            const v2f t = {xr.x > 30.f ? xr.x : __builtin_amdgcn_logf(z.x), xr.y > 30.f ? xr.y : __builtin_amdgcn_logf(z.y)};
+            const v2f t = {__builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(z.x), xr.x, 128.f),
+                           __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(z.y), xr.y, 128.f)};
             const v2f e = t * av;
             a[r] = __builtin_amdgcn_exp2f(e.x);
             a[r + 1] = __builtin_amdgcn_exp2f(e.y);
@@ -344,7 +395,9 @@ struct ScanWave {
     // yv: byte offset of (first position of the tile + 4hi, my channel); row strides ride in the scalar
     // soffset.  MASKED (ragged tile / channel edge, wave-uniform choice): an element outside the tensor gets
     // the out-of-range VECTOR offset, which the range check drops whatever the scalar offset is.
-    template <typename TY, bool MASKED>
+    // PAIR (the LDS-DMA kernel only): two elements per conversion, stored by inline-asm buffer stores.  hipcc's vmcnt
+    // bookkeeping does not see those, which is only sound where every wait on vector memory is hand-counted.
+    template <typename TY, bool MASKED, bool PAIR = false>
     __device__ __forceinline__ void replay(__amdgpu_buffer_rsrc_t ry, unsigned yv, unsigned yrow, const float (&uf)[16],
                                            const float (&a)[16], const float (&bb)[16], const float (&Cp)[16],
                                            const float (&preA)[4], const float (&preH)[4], float hin, bool cok,
@@ -364,8 +417,12 @@ struct ScanWave {
                 const int p0 = q + 8 * g + 4 * hi;  // position of element r inside the tile
                 const unsigned v0 = !MASKED || (cok && p0 < nvalid) ? yv : kOutOfRange;
                 const unsigned v1 = !MASKED || (cok && p0 + 1 < nvalid) ? yv : kOutOfRange;
-                buf_store_elem<TY>(ry, v0, (unsigned)(q + 8 * g) * yrow, o.x);
-                buf_store_elem<TY>(ry, v1, (unsigned)(q + 1 + 8 * g) * yrow, o.y);
+                if constexpr (PAIR) {
+                    buf_store_pair<TY>(ry, v0, (unsigned)(q + 8 * g) * yrow, v1, (unsigned)(q + 1 + 8 * g) * yrow, o.x, o.y);
+                } else {
+                    buf_store_elem<TY>(ry, v0, (unsigned)(q + 8 * g) * yrow, o.x);
+                    buf_store_elem<TY>(ry, v1, (unsigned)(q + 1 + 8 * g) * yrow, o.y);
+                }
             }
         }
     }
@@ -564,6 +621,19 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
 
     ScanWave<T, NK, false> w;
     w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + c, R, RG, PC, D, lane, c, &stage[wv][0][0], a_log);
+    // rank 8: k slots 8..15 of the one MFMA are spare (the upper half-wave's fragments) -- the bias goes there (terms())
+    constexpr bool kBiasMfma = R8 == 8;
+    __shared__ __attribute__((aligned(16))) float onesrow[8];
+    if constexpr (kBiasMfma) {
+        if (threadIdx.x < 8) onesrow[threadIdx.x] = threadIdx.x < 2 ? 1.f : 0.f;
+        const __hip_bfloat16 bh = __float2bfloat16(w.bias2);
+        const __hip_bfloat16 bl = __float2bfloat16(w.bias2 - __bfloat162float(bh));
+        frag8_t f = {0, 0, 0, 0, 0, 0, 0, 0};
+        f[0] = __builtin_bit_cast(short, bh);
+        f[1] = __builtin_bit_cast(short, bl);
+        if (hi) w.wh[0] = f;
+        __syncthreads();
+    }
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
     const __amdgpu_buffer_rsrc_t rp =
@@ -621,7 +691,9 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
     // my x_dbl row: ranks 16 kk + 8 hi .. +7 (a run past the padded ranks meets all-zero dt_w fragments: run 0 instead),
     // then (B, C); my 16 token elements: positions (r&3) + 8 (r>>2) + 4 hi of channel r32
     const unsigned prow_a = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)(slot + kUB + r32 * kRowP);
-    const unsigned pa0 = prow_a + (unsigned)((hi * 8 < R8 ? hi * 8 : 0) * 4);
+    const unsigned pa0 = kBiasMfma && hi
+                             ? (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)&onesrow[0]
+                             : prow_a + (unsigned)((hi * 8 < R8 ? hi * 8 : 0) * 4);
     const unsigned pa1 = prow_a + (unsigned)((16 + hi * 8 < R8 ? 16 + hi * 8 : 0) * 4);
     const unsigned pb = prow_a + (unsigned)(R8 * 4);
     const unsigned ua = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)(slot + hi * 4 * kTP * 2 + r32 * 2);
@@ -705,7 +777,7 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
         float Bp[16], Cp[16];
         w.stage_bc(cur, Bp, Cp, false);
         float a[16], bb[16], preA[4], preH[4], runA, runH;
-        w.template terms<true>(cur, Bp, L - l0, a, bb, uf);
+        w.template terms<true, kBiasMfma>(cur, Bp, L - l0, a, bb, uf);
         w.prefix(a, bb, preA, preH, runA, runH);
         const int buf = s & 1;
         if (hi == 0) {
@@ -730,9 +802,9 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
         w.read_stage4(2, Cp);                                  // C of my 16 positions, read where it is used
         const unsigned yv = (unsigned)((l0 + 4 * hi) * D + c) * (unsigned)sizeof(TY);
         if (l0 + kTP <= L) {  // wave-uniform: ragged only at the sequence end
-            w.template replay<TY, false>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, true, kTP);
+            w.template replay<TY, false, sizeof(TY) == 2>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, true, kTP);
         } else {
-            w.template replay<TY, true>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, true, L - l0);
+            w.template replay<TY, true, sizeof(TY) == 2>(ry, yv, yrow, uf, a, bb, Cp, preA, preH, hin, true, L - l0);
         }
         __builtin_amdgcn_wave_barrier();
     }
