@@ -428,6 +428,62 @@ struct ScanWave {
     }
 };
 
+// Carry hand-over between the W waves that share a sequence, WITHOUT a workgroup barrier (r03).
+// Tile t = s W + w is owned by wave w in step s; the state entering it is the state leaving tile t - 1, owned by wave w - 1
+// (wave W - 1 of the previous step for w = 0).  Every wave publishes the state LEAVING its tile -- value, then a tag t + 1,
+// two LDS writes in program order -- into its own mailbox and reads its predecessor's mailbox -- tag, then value -- until
+// the tag matches.  The hand-over is one fused multiply-add per wave (h_out = A_tile h_in + H_tile) instead of a W-step
+// fold behind a barrier, and, more important, the waves of a workgroup are no longer in lock-step: measured on the Helix
+// launch (scripts/exp_scan_ablate.py) no single phase of the lock-step kernel -- stores, barrier, fold, LDS-DMA,
+// transcendentals -- was worth more than 10 % of its time; the step was a chain of phases every wave of the CU entered
+// together.  Decoupled, a wave does phase 1 of its next tile while its successors still wait for their carry.
+// No write-after-read hazard: wave w rewrites its mailbox for step s + 1 only after it has the carry of that step, which
+// (through waves w + 1 .. W - 1 of step s and waves 0 .. w - 1 of step s + 1) descends from wave w + 1 having READ the step-s
+// value.  Forward progress: all waves of a workgroup are resident and run the same number of steps; the spin sleeps between
+// polls and is bounded (a run that ever hit the bound would end with wrong numbers, not hang the GPU).
+struct CarryLink {
+    unsigned rd, wr;   // LDS byte addresses of (value[kTP], tag[kTP]) of my predecessor's / my own mailbox, at my channel
+
+    // reverse: the chain runs from the last wave to the first (the adjoint sweep of the backward kernel)
+    __device__ __forceinline__ void init(float *box /* [W][2][kTP] */, int wv, int W, int r32, bool reverse = false)
+    {
+        const int pred = reverse ? (wv == W - 1 ? 0 : wv + 1) : (wv == 0 ? W - 1 : wv - 1);
+        rd = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(box + (pred * 2) * kTP + r32);
+        wr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(box + (wv * 2) * kTP + r32);
+    }
+    // state leaving tile `tile - 1` (tile >= 1, in chain order); 0 for the first tile of the chain.  `base`: tag offset
+    // of this chain (a kernel that runs two chains through the same mailboxes gives the second one tags above the first's)
+    __device__ __forceinline__ float acquire(int tile, unsigned base = 0u) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (tile == 0) return 0.f;
+        float v;
+        unsigned t;
+        for (int guard = 0; guard < (1 << 20); ++guard) {
+            asm volatile("ds_read_b32 %0, %2 offset:128\n\tds_read_b32 %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(t), "=&v"(v)
+                         : "v"(rd)
+                         : "memory");
+            if (__builtin_amdgcn_ballot_w64(t != base + (unsigned)tile) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return v;
+#else
+        return 0.f;
+#endif
+    }
+    // state leaving tile `tile` (every lane of the wave holds its channel's value; the lower half-wave writes)
+    __device__ __forceinline__ void publish(float h, int tile, int hi, unsigned base = 0u) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (hi == 0) {
+            const unsigned tg = base + (unsigned)tile + 1u;
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:128" ::"v"(wr), "v"(h), "v"(tg) : "memory");
+        }
+#endif
+    }
+};
+
 // XCD-aware work order of the chained kernels (xcd_work_item, common.h).  With the plain (x = channel tile) order the
 // channel tiles of ONE sequence sit on 8 different XCDs: every gathered token row is then fetched as 64-byte halves of
 // 128-byte lines by two different L2s (PMC: 2.2x the algorithmic bytes on the Helix launch, 1.09x with the remap), and
@@ -443,7 +499,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W, float *__restrict__ hst = nullptr,
     int a_log = 0)
 {
-    __shared__ float agg[2][kMaxW][2][kTP];
+    __shared__ float mbox[kMaxW][2][kTP];   // carry mailboxes (CarryLink): value, tag per wave and channel
     __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -460,6 +516,8 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
 
     ScanWave<T, NK, SPLIT> w;
     w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + cc_, R, RG, PC, D, lane, cc_, &stage[wv][0][0], a_log);
+    CarryLink link;
+    link.init(&mbox[0][0][0], wv, W, r32);
 
     // wave-uniform descriptors (host guarantees every extent < 2^31 bytes)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
@@ -500,19 +558,10 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t) w.fetch(rx, rp, idx0[t], ops[t]);
 
-    // The per-super-chunk fold below always walks kMaxW aggregate rows (a loop with a run-time trip count
-    // inside the tile loop makes hipcc drain the gather pipeline at the loop head): rows of absent waves
-    // hold the identity (decay 1, state 0).
-    for (int i = threadIdx.x; i < 2 * kMaxW * kTP; i += blockDim.x) {
-        const int bq = i / kTP;   // buf * kMaxW + q
-        if (bq % kMaxW >= W) {
-            agg[bq / kMaxW][bq % kMaxW][0][i % kTP] = 1.f;
-            agg[bq / kMaxW][bq % kMaxW][1][i % kTP] = 0.f;
-        }
-    }
+    // mailbox tags start at 0 = "nothing published" (tile t publishes tag t + 1)
+    for (int i = threadIdx.x; i < 2 * kMaxW * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;
     __syncthreads();
     const bool cfull = ctile * kTP + kTP <= D;  // block-uniform: no channel masking needed
-    float carry = 0.f;
     // one super-chunk; STI = ring slot of tile s (compile-time: the ring must be indexed statically)
     auto step = [&](auto sti_c, int s) {
         constexpr int sti = decltype(sti_c)::value;
@@ -528,20 +577,9 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
         w.terms(cur, Bp, L - l0, a, bb, uf);
         w.prefix(a, bb, preA, preH, runA, runH);
 
-        // ---- one barrier per super-chunk: fold the preceding waves' (decay, state) pairs
-        const int buf = s & 1;
-        if (hi == 0) {
-            agg[buf][wv][0][r32] = runA;
-            agg[buf][wv][1][r32] = runH;
-        }
-        __syncthreads();
-        float h = carry, hin = carry;
-#pragma unroll
-        for (int q = 0; q < kMaxW; ++q) {   // fixed trip count: rows q >= W hold the identity (see above)
-            if (q == wv) hin = h;
-            h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
-        }
-        carry = h;
+        // ---- no barrier: the state entering my tile comes from my predecessor's mailbox, the state leaving it goes into mine
+        const float hin = link.acquire(s * W + wv);
+        link.publish(fmaf(runA, hin, runH), s * W + wv, hi);
         if constexpr (SAVE) {
             const long nta = (L + kTP - 1) / kTP + kMaxW;
             if (hi == 0 && cok && l0 < L) hst[(((long)b * K + k) * nta + (s * W + wv)) * D + c] = hin;
@@ -604,7 +642,7 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
     constexpr int kNP = (kNCH + kWave - 1) / kWave;   // 64-lane DMA pieces: 2, 3, 5 (the last one overshoots into padding)
     constexpr int kUB = kTP * kTP * 2;          // token tile: 32 positions x 32 channels x 2 bytes
     constexpr int kSlot = kUB + kNP * 1024;
-    __shared__ float agg[2][W][2][kTP];
+    __shared__ float mbox[W][2][kTP];   // carry mailboxes (CarryLink)
     __shared__ __attribute__((aligned(16))) float stage[W][3][kTP];
     __shared__ __attribute__((aligned(16))) unsigned char ring[W][kSlot];
     __shared__ __attribute__((aligned(16))) int idxbuf[W][kWave];   // the index vector of the next tile to fetch, by DMA too
@@ -632,8 +670,11 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
         f[0] = __builtin_bit_cast(short, bh);
         f[1] = __builtin_bit_cast(short, bl);
         if (hi) w.wh[0] = f;
-        __syncthreads();
     }
+    CarryLink link;
+    link.init(&mbox[0][0][0], wv, W, r32);
+    for (int i = threadIdx.x; i < 2 * W * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;   // tags: nothing published
+    __syncthreads();   // the only workgroup barrier of the kernel
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
     const __amdgpu_buffer_rsrc_t rp =
@@ -763,7 +804,6 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
     const long nta = (L + kTP - 1) / kTP + kMaxW;
     const __amdgpu_buffer_rsrc_t rh =
         make_rsrc(SAVE ? hst + ((long)b * K + k) * nta * D : nullptr, SAVE ? (unsigned)(nta * D) * 4u : 0u);
-    float carry = 0.f;
     for (int s = 0; s < nsuper; ++s) {
         if (s > 0) {
             if constexpr (SAVE) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
@@ -779,22 +819,9 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
         float a[16], bb[16], preA[4], preH[4], runA, runH;
         w.template terms<true, kBiasMfma>(cur, Bp, L - l0, a, bb, uf);
         w.prefix(a, bb, preA, preH, runA, runH);
-        const int buf = s & 1;
-        if (hi == 0) {
-            agg[buf][wv][0][r32] = runA;
-            agg[buf][wv][1][r32] = runH;
-        }
-        // raw barrier: __syncthreads() would also wait vmcnt(0), i.e. for the DMA of the NEXT tile issued above
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        float h = carry, hin = carry;
-#pragma unroll
-        for (int q = 0; q < W; ++q) {
-            if (q == wv) hin = h;
-            h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
-        }
-        carry = h;
+        // no barrier, no fold: carry by mailbox (CarryLink); the spin waits on lgkmcnt only, the DMAs above stay in flight
+        const float hin = link.acquire(s * W + wv);
+        link.publish(fmaf(runA, hin, runH), s * W + wv, hi);
         if constexpr (SAVE) {
             const unsigned ho = (hi == 0 && l0 < L) ? (unsigned)((s * W + wv) * D + c) * 4u : kOutOfRange;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hin), rh, ho, 0, 0);
@@ -836,7 +863,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     // flags & 2: gB / gC are (B, K, CT, L) tables of per-channel-tile partial sums, each element WRITTEN by exactly one wave
     //            (no zero fill, no atomics: the caller adds the CT = ceil(D / 32) partials in a fixed order)
     constexpr int kTS = 36;   // LDS row stride (floats) of the position-sum transposes: 16-byte aligned rows
-    __shared__ float agg[2][kMaxW][2][kTP];
+    __shared__ float mbox[kMaxW][2][kTP];   // carry mailboxes (CarryLink): the forward states, then the adjoint
     __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];
     __shared__ __attribute__((aligned(16))) float tr[kMaxW][kTP][kTS];
     __shared__ float red[kMaxW][3][kTP];
@@ -868,14 +895,12 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     const int nsuper = (L + span - 1) / span;
     float *hs = hst + ((long)b * K + k) * (long)((L + kTP - 1) / kTP + kMaxW) * D;   // (B, K, NTA, D), tile = position / 32
 
-    for (int i = threadIdx.x; i < 2 * kMaxW * kTP; i += blockDim.x) {   // rows of absent waves: identity
-        const int bq = i / kTP;
-        if (bq % kMaxW >= W) {
-            agg[bq / kMaxW][bq % kMaxW][0][i % kTP] = 1.f;
-            agg[bq / kMaxW][bq % kMaxW][1][i % kTP] = 0.f;
-        }
-    }
+    for (int i = threadIdx.x; i < 2 * kMaxW * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;   // tags: nothing published
     __syncthreads();
+    CarryLink fwd_link, adj_link;
+    fwd_link.init(&mbox[0][0][0], wv, W, r32);
+    adj_link.init(&mbox[0][0][0], wv, W, r32, true);
+    const unsigned adj_base = (unsigned)(nsuper * W);   // the adjoint chain's tags lie above the forward chain's
 
     auto load_idx = [&](int s) -> int {
         const int l = s * span + wv * kTP + r32;
@@ -884,7 +909,6 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
 
     // ---- sweep 1: the state entering every tile (skipped when the forward launch has saved them, block-uniform)
     if (!have_states) {
-        float carry = 0.f;
         int idx_cur = load_idx(0);
         for (int s = 0; s < nsuper; ++s) {
             TileOps<T, NK> cur;
@@ -895,19 +919,8 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
             w.stage_bc(cur, Bp, Cp, false);
             w.terms(cur, Bp, L - l0, a, bb, uf);
             w.prefix(a, bb, preA, preH, runA, runH);
-            const int buf = s & 1;
-            if (hi == 0) {
-                agg[buf][wv][0][r32] = runA;
-                agg[buf][wv][1][r32] = runH;
-            }
-            __syncthreads();
-            float h = carry, hin = carry;
-#pragma unroll
-            for (int q = 0; q < kMaxW; ++q) {
-                if (q == wv) hin = h;
-                h = fmaf(agg[buf][q][0][r32], h, agg[buf][q][1][r32]);
-            }
-            carry = h;
+            const float hin = fwd_link.acquire(s * W + wv);
+            fwd_link.publish(fmaf(runA, hin, runH), s * W + wv, hi);
             if (hi == 0 && cok) hs[(long)(s * W + wv) * D + c] = hin;
             __builtin_amdgcn_wave_barrier();
         }
@@ -916,7 +929,6 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     __syncthreads();
 
     // ---- sweep 2: right to left
-    float zc = 0.f;                         // adjoint entering the current super-chunk from the right
     float accA = 0.f, accD = 0.f, accb = 0.f;
     float *trw = &tr[wv][0][0];
     int idx_rev = load_idx(nsuper - 1);
@@ -985,19 +997,10 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
             RZ = fmaf(la, mZ, lz);
             RA = la * mA;
         }
-        const int buf = s & 1;
-        if (hi == 0) {
-            agg[buf][wv][0][r32] = RA;
-            agg[buf][wv][1][r32] = RZ;
-        }
-        __syncthreads();
-        float z = zc, zin = zc;
-#pragma unroll
-        for (int q = kMaxW - 1; q >= 0; --q) {
-            if (q == wv) zin = z;
-            z = fmaf(agg[buf][q][0][r32], z, agg[buf][q][1][r32]);
-        }
-        zc = z;
+        // adjoint entering my tile from the right: the chain runs over the tiles in DEScending order (no barrier, CarryLink)
+        const int rt = (nsuper - 1 - s) * W + (W - 1 - wv);
+        const float zin = adj_link.acquire(rt, adj_base);
+        adj_link.publish(fmaf(RA, zin, RZ), rt, hi, adj_base);
         // replay right to left, emit
         const bool full = ctile * kTP + kTP <= D && l0 + kTP <= L;
         const unsigned ov = (unsigned)((l0 + 4 * hi) * D + cc_) * (unsigned)sizeof(T);
