@@ -23,6 +23,8 @@
 //    tensors (64 x 64 tiles, tile -> tensor by binary search).  Replaces ~230 cast and ~230 transpose launches per step.
 // 4. slab_sum: out[i] = sum_s part[s][i] in a fixed order -- the partial sums of the LayerNorm / depth-wise / scan
 //    parameter gradients.
+#include <type_traits>
+
 #include "common.h"
 
 namespace tramba {
@@ -65,9 +67,17 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv >> 1, wk = wv & 1;                      // wave tile: 64 (n) x 64 (k)
-    const int n0 = blockIdx.y * kWgTile, k0 = blockIdx.x * kWgTile;
+    // XCD-aware work order (xcd_work_item, common.h): the tiles of ONE token chunk re-read the same gy / x rows -- K / 128
+    // and N / 128 times.  In launch order consecutive workgroups land on different XCDs, so every chunk was fetched by all
+    // eight L2s and re-read through the fabric (the big layers moved ~150 MB per launch at ~5.4 TB/s: that, not the matrix
+    // cores, set their 350 TFLOP/s).  Remapped, an XCD walks k tile -> n tile -> chunk: a chunk's tiles run side by side on
+    // one XCD and its operand rows (<= 2.5 MB) are served by that XCD's L2.
+    unsigned bx_, by_, bz_;
+    xcd_work_item(bx_, by_, bz_);
+    const int bx = (int)bx_, by = (int)by_, bz = (int)bz_;
+    const int n0 = by * kWgTile, k0 = bx * kWgTile;
     const int per = a.nbatch * a.nsplit;
-    const int g = (int)blockIdx.z / per, zz = (int)blockIdx.z % per;
+    const int g = bz / per, zz = bz % per;
     const int b = zz / a.nsplit, sp = zz % a.nsplit;
     const int t0 = sp * a.mchunk;
     const int t1 = t0 + a.mchunk < a.M ? t0 + a.mchunk : a.M;
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a)
     float bsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-    const bool do_bias = a.want_bias && blockIdx.x == 0;
+    const bool do_bias = a.want_bias && bx == 0;
     auto stash = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -190,7 +200,244 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a)
     }
 }
 
-// out[g][i] = sum over slabs s of part[g][s][i], i < n (fixed order); 4 floats per thread
+// ------------------------------------------------------------------------------------------------
+// The same TN GEMM with its token tiles staged by LDS-DMA (r03).  wgrad_tn_kernel above keeps ONE 32-token tile in flight
+// (registers -> ds_write -> barrier): every shape of a training step, 1 152 to 73 728 tokens, 0.5 to 9.7 GFLOP, took
+// 22-37 us = 16 K steps x ~1.5 us of memory latency, with 8 MFMAs per wave and step in between (scripts/bench_wgrad.py; an
+// XCD-aware tile order changed nothing: the launches wait on latency, not on bandwidth).  Here NSTG - 1 tiles are in flight
+// per workgroup and no VGPR is spent on staging:
+//   * a stage = (gy 32 tokens x 128 channels | x 32 x 128) 16-bit = 16 KB, rows of 256 B WITHOUT padding; a DMA piece is
+//     4 token rows (lane i -> row i / 16, 16-byte chunk position i % 16); waves 0-1 fetch gy, waves 2-3 fetch x, four
+//     pieces per wave and step;
+//   * the transposed fragment reads (ds_read_b64_tr_b16: a 16-lane group reads 4 token rows x 32 B) want those 4 rows on
+//     different banks, which the 320-byte rows of the register-staged kernel gave: here the 16-byte chunk c of token row t
+//     sits at chunk position c ^ 4 (t & 3), applied on the GLOBAL side of the DMA (lane i fetches chunk (i % 16) ^ 4 (i / 16))
+//     and undone in the per-lane read address -- the 8 (row, channel-half) pieces of a 32-lane group cover all 64 banks;
+//   * step:  s_waitcnt vmcnt(4 (NSTG - 2)) (my pieces of this tile have landed; hand-counted: hipcc does not see what an
+//            LDS-DMA writes), s_barrier, DMA of tile + NSTG - 1 into the stage just vacated, 16 hand-written
+//            ds_read_b64_tr_b16 behind counted lgkmcnt waits, 8 MFMAs;
+//   * token rows past the chunk and channel chunks past N / K arrive as zeros through the descriptor's range check.
+// Same slabs, same bias column sums (read back from the staged gy tile by the k-tile-0 workgroups), same fixed-order sum.
+#define TRAMBA_TR64_(OUT, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(OUT) : "v"(ADDR) : "memory")
+
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+
+template <typename T, int NSTG>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // (vector-register asm in a kernel template: the host pass only needs the stub)
+    static_assert(NSTG == 3 || NSTG == 4, "stage index = step % NSTG with the loop unrolled by NSTG");
+    constexpr int kTileB = kWgTok * kWgTile * 2;     // 8 KB: one operand's 32-token tile
+    constexpr int kStageB = 2 * kTileB;              // 16 KB
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTG * kStageB];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv >> 1, wk = wv & 1;                      // wave tile: 64 (n) x 64 (k)
+    unsigned bx_, by_, bz_;
+    xcd_work_item(bx_, by_, bz_);                              // a token chunk's tiles side by side on one XCD
+    const int bx = (int)bx_, by = (int)by_, bz = (int)bz_;
+    const int n0 = by * kWgTile, k0 = bx * kWgTile;
+    const int per = a.nbatch * a.nsplit;
+    const int g = bz / per, zz = bz % per;
+    const int b = zz / a.nsplit, sp = zz % a.nsplit;
+    const int t0 = sp * a.mchunk;
+    const int t1 = t0 + a.mchunk < a.M ? t0 + a.mchunk : a.M;
+    const T *gyb = (const T *)a.gy + (long)b * a.gy_bs + (long)g * a.gy_gs;
+    const T *xb = (const T *)a.x + (long)b * a.x_bs + (long)g * a.x_gs;
+    // waves 0-1 stage gy, waves 2-3 stage x; the descriptor ends with the last token of MY chunk (rows past it read as zero)
+    const bool stage_x = wv >= 2;
+    const int ld = stage_x ? a.x_ld : a.gy_ld, ncol = stage_x ? a.K : a.N, col0 = stage_x ? k0 : n0;
+    const __amdgpu_buffer_rsrc_t rs =
+        make_rsrc(stage_x ? (const void *)xb : (const void *)gyb, (unsigned)(((long)(t1 - 1) * ld + ncol) * 2l));
+    unsigned voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = ((wv & 1) * 4 + j) * 4 + (lane >> 4);            // token row inside the tile
+        const int c = (lane & 15) ^ (4 * (row & 3));                     // the chunk that belongs at my position
+        voff[j] = col0 + 8 * c < ncol ? (unsigned)(((long)(t0 + row) * ld + col0 + 8 * c) * 2l) : kOutOfRange;
+    }
+    unsigned char *mine = lds + (stage_x ? kTileB : 0) + (wv & 1) * 4096;
+    const unsigned stepb = (unsigned)(kWgTok * ld) * 2u;                 // bytes between consecutive tiles of my operand
+    // (the tile's token offset rides in the VECTOR offset: the range check that zero-fills the rows past my chunk does not
+    //  look at the scalar offset; an out-of-range channel chunk stays out of range, 2^31 + less than 2^31)
+    auto issue = [&](int st, int stg) {
+        const unsigned so = (unsigned)st * stepb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(mine + stg * kStageB + j * 1024), 16, voff[j] + so, 0, 0, 0);
+    };
+    // transposed fragment reads: 16-lane group gq = lane >> 4 -> channels 16 (gq & 1) .. +15 of a 32-channel block, tokens
+    // 8 (gq >> 1) .. +3 (the second read: +4); lane 4 q + p of the group addresses token row q, channels 4 p .. 4 p + 3
+    const int li = lane & 15, q = li >> 2, pp = li & 3, gq = lane >> 4;
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const unsigned fr0 = lbase + (unsigned)((8 * (gq >> 1) + q) * 256 + (((2 * (gq & 1) + (pp >> 1)) ^ (4 * q)) * 16) + (pp & 1) * 8);
+    // channel block cblk (a multiple of 32) moves the chunk index by cblk / 8, a multiple of 4: an XOR of the address
+    unsigned ga[2], xa[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ga[i] = fr0 ^ (unsigned)((wn * 64 + i * 32) * 2);
+        xa[i] = (fr0 ^ (unsigned)((wk * 64 + i * 32) * 2)) + (unsigned)kTileB;
+    }
+    // bias column sums (k-tile 0 only): thread t re-reads chunk positions t % 16 of rows t / 16 and t / 16 + 16 of the gy
+    // tile -- both rows hold the same channel chunk there, (t % 16) ^ 4 ((t / 16) & 3)
+    const bool do_bias = a.want_bias && bx == 0;
+    const unsigned ba = lbase + (unsigned)((tid >> 4) * 256 + (tid & 15) * 16);
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+    acc16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nstep = (t1 - t0 + kWgTok - 1) / kWgTok;
+    constexpr int DEPTH = NSTG - 1;
+#pragma unroll
+    for (int t = 0; t < DEPTH; ++t)
+        if (t < nstep) issue(t, t);
+    auto kstep = [&](int st, auto stg_c) {
+        constexpr int STG = decltype(stg_c)::value;
+        const int later = nstep - 1 - st;           // tiles after this one; DEPTH - 1 of them (4 pieces each) may be in flight
+        if (later >= DEPTH - 1) {
+            if constexpr (DEPTH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (later == 1) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + DEPTH < nstep) issue(st + DEPTH, (STG + DEPTH) % NSTG);
+        v2u32 fg[2][2][2], fx[2][2][2];             // [channel block][16-token slice][tokens 0-3 | 4-7]
+#define TRAMBA_RD_STAGE_(S)                                                                                               \
+    TRAMBA_TR64_(fg[0][0][0], ga[0], S); TRAMBA_TR64_(fg[0][0][1], ga[0], S + 1024);                                      \
+    TRAMBA_TR64_(fx[0][0][0], xa[0], S); TRAMBA_TR64_(fx[0][0][1], xa[0], S + 1024);                                      \
+    TRAMBA_TR64_(fg[1][0][0], ga[1], S); TRAMBA_TR64_(fg[1][0][1], ga[1], S + 1024);                                      \
+    TRAMBA_TR64_(fx[1][0][0], xa[1], S); TRAMBA_TR64_(fx[1][0][1], xa[1], S + 1024);                                      \
+    TRAMBA_TR64_(fg[0][1][0], ga[0], S + 4096); TRAMBA_TR64_(fg[0][1][1], ga[0], S + 5120);                               \
+    TRAMBA_TR64_(fx[0][1][0], xa[0], S + 4096); TRAMBA_TR64_(fx[0][1][1], xa[0], S + 5120);                               \
+    TRAMBA_TR64_(fg[1][1][0], ga[1], S + 4096); TRAMBA_TR64_(fg[1][1][1], ga[1], S + 5120);                               \
+    TRAMBA_TR64_(fx[1][1][0], xa[1], S + 4096); TRAMBA_TR64_(fx[1][1][1], xa[1], S + 5120)
+        if constexpr (STG == 0) { TRAMBA_RD_STAGE_(0); }
+        else if constexpr (STG == 1) { TRAMBA_RD_STAGE_(16384); }
+        else if constexpr (STG == 2) { TRAMBA_RD_STAGE_(32768); }
+        else { TRAMBA_RD_STAGE_(49152); }
+#undef TRAMBA_RD_STAGE_
+        v4u32 bv[2];
+        if (do_bias) {   // (block-uniform)
+            if constexpr (STG == 0) {
+                asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(bv[0]) : "v"(ba) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bv[1]) : "v"(ba) : "memory");
+            } else if constexpr (STG == 1) {
+                asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(bv[0]) : "v"(ba) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(bv[1]) : "v"(ba) : "memory");
+            } else if constexpr (STG == 2) {
+                asm volatile("ds_read_b128 %0, %1 offset:32768" : "=v"(bv[0]) : "v"(ba) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:36864" : "=v"(bv[1]) : "v"(ba) : "memory");
+            } else {
+                asm volatile("ds_read_b128 %0, %1 offset:49152" : "=v"(bv[0]) : "v"(ba) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:53248" : "=v"(bv[1]) : "v"(ba) : "memory");
+            }
+        }
+        auto mk = [](v2u32 lo, v2u32 hi) -> frag8s {
+            const v4u32 v = {lo.x, lo.y, hi.x, hi.y};
+            return __builtin_bit_cast(frag8s, v);
+        };
+        // counted waits (the reads return in order): slice 0 of block 0 needs the first 4 reads, block 1 four more, ...
+        if (do_bias) {
+            asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(fg[0][0][0]), "+v"(fg[0][0][1]), "+v"(fx[0][0][0]), "+v"(fx[0][0][1]) : : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(fg[0][0][0]), "+v"(fg[0][0][1]), "+v"(fx[0][0][0]), "+v"(fx[0][0][1]) : : "memory");
+        }
+        acc[0][0] = mfma16<T>(mk(fg[0][0][0], fg[0][0][1]), mk(fx[0][0][0], fx[0][0][1]), acc[0][0]);
+        if (do_bias) {
+            asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(fg[1][0][0]), "+v"(fg[1][0][1]), "+v"(fx[1][0][0]), "+v"(fx[1][0][1]) : : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fg[1][0][0]), "+v"(fg[1][0][1]), "+v"(fx[1][0][0]), "+v"(fx[1][0][1]) : : "memory");
+        }
+        acc[1][0] = mfma16<T>(mk(fg[1][0][0], fg[1][0][1]), mk(fx[0][0][0], fx[0][0][1]), acc[1][0]);
+        acc[0][1] = mfma16<T>(mk(fg[0][0][0], fg[0][0][1]), mk(fx[1][0][0], fx[1][0][1]), acc[0][1]);
+        acc[1][1] = mfma16<T>(mk(fg[1][0][0], fg[1][0][1]), mk(fx[1][0][0], fx[1][0][1]), acc[1][1]);
+        if (do_bias) {
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fg[0][1][0]), "+v"(fg[0][1][1]), "+v"(fx[0][1][0]), "+v"(fx[0][1][1]) : : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fg[0][1][0]), "+v"(fg[0][1][1]), "+v"(fx[0][1][0]), "+v"(fx[0][1][1]) : : "memory");
+        }
+        acc[0][0] = mfma16<T>(mk(fg[0][1][0], fg[0][1][1]), mk(fx[0][1][0], fx[0][1][1]), acc[0][0]);
+        if (do_bias) {
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fg[1][1][0]), "+v"(fg[1][1][1]), "+v"(fx[1][1][0]), "+v"(fx[1][1][1]) : : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fg[1][1][0]), "+v"(fg[1][1][1]), "+v"(fx[1][1][0]), "+v"(fx[1][1][1]) : : "memory");
+        }
+        acc[1][0] = mfma16<T>(mk(fg[1][1][0], fg[1][1][1]), mk(fx[0][1][0], fx[0][1][1]), acc[1][0]);
+        acc[0][1] = mfma16<T>(mk(fg[0][1][0], fg[0][1][1]), mk(fx[1][1][0], fx[1][1][1]), acc[0][1]);
+        acc[1][1] = mfma16<T>(mk(fg[1][1][0], fg[1][1][1]), mk(fx[1][1][0], fx[1][1][1]), acc[1][1]);
+        if (do_bias) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]) : : "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const Pack<T, 8> pk = __builtin_bit_cast(Pack<T, 8>, bv[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[j] += Cvt<T>::to_f(pk.v[j]);
+            }
+        }
+    };
+    int st0 = 0;
+    for (; st0 + NSTG <= nstep; st0 += NSTG) {
+        kstep(st0, std::integral_constant<int, 0>{});
+        kstep(st0 + 1, std::integral_constant<int, 1>{});
+        kstep(st0 + 2, std::integral_constant<int, 2>{});
+        if constexpr (NSTG > 3) kstep(st0 + 3, std::integral_constant<int, 3>{});
+    }
+    if (st0 < nstep) kstep(st0, std::integral_constant<int, 0>{});
+    if (st0 + 1 < nstep) kstep(st0 + 1, std::integral_constant<int, 1>{});
+    if constexpr (NSTG > 3) {
+        if (st0 + 2 < nstep) kstep(st0 + 2, std::integral_constant<int, 2>{});
+    }
+
+    // ---- partial slab of this (group, batch, split)
+    float *slab = a.part + ((long)g * per + zz) * ((long)a.N * a.K + a.N);
+    const int col_l = lane & 31, rh = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kc = k0 + wk * 64 + j * 32 + col_l;
+            if (kc < a.K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rh;
+                    if (n < a.N) slab[(long)n * a.K + kc] = acc[i][j][r];
+                }
+            }
+        }
+    if (do_bias) {   // column sums of gy: 16 row lanes per channel chunk, through LDS (the tile loop has ended)
+        float *red = reinterpret_cast<float *>(&lds[0]);   // (16, 128) floats = 8 KB
+        __syncthreads();
+        const int sch = 8 * ((tid & 15) ^ (4 * ((tid >> 4) & 3)));      // the channel chunk my two rows hold at my position
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[(tid >> 4) * kWgTile + sch + j] = bsum[j];
+        __syncthreads();
+        if (tid < kWgTile && n0 + tid < a.N) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += red[r * kWgTile + tid];
+            slab[(long)a.N * a.K + n0 + tid] = sacc;
+        }
+    }
+#endif
+}
+#undef TRAMBA_TR64_
+
+// out[g][i] = sum over slabs s of part[g][s][i], i < n (fixed order); 4 floats per thread, EIGHT slab rows requested before
+// the first is added (r03: four were not enough to cover the memory latency -- 29 MB in 18.6 us = 1.6 TB/s on the widest
+// layers of a training step, as much as the TN kernel in front of it)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__ part, float *__restrict__ out, long n,
                                                       int nslab)
 {
@@ -200,18 +447,28 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i4 + 4 <= n) {
         int s = 0;
-        for (; s + 4 <= nslab; s += 4) {
-            float4 v[4];
+        for (; s + 8 <= nslab; s += 8) {
+            float4 v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4 *>(p + (long)(s + j) * n);
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(p + (long)(s + j) * n);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
             }
         }
-        for (; s < nslab; ++s) {
-            const float4 v = *reinterpret_cast<const float4 *>(p + (long)s * n);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        if (s < nslab) {   // the last 1..7 rows: clamped re-reads weighted 0 keep the loads unconditional and in flight together
+            float4 v[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int sj = s + j < nslab ? s + j : nslab - 1;
+                v[j] = *reinterpret_cast<const float4 *>(p + (long)sj * n);
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                if (s + j < nslab) {   // (uniform)
+                    acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
+                }
+            }
         }
         *reinterpret_cast<float4 *>(out + (long)blockIdx.y * n + i4) = acc;
     } else {
@@ -394,11 +651,14 @@ using namespace tramba;
 
 static void wgrad_plan(long m, int n, int k, int groups, int nbatch, int &nsplit, int &mchunk)
 {
-    // Token splits: enough workgroups to fill the chip (~1.5 per CU) but never chunks below 512 tokens -- a block reads
-    // 512 B per token and writes a 64 KB fp32 slab, so shorter chunks spend more bytes on partial sums than on operands
-    // (r02e trace: at ~1000 blocks for every shape the slab sums cost 60 % of the GEMM time).
+    // Token splits: ONE workgroup per CU and never chunks below 512 tokens.  A workgroup's K loop runs at the rate its CU
+    // fills LDS from L2 (~30 B per cycle: a 16 KB step every ~560 cycles, whatever the staging); co-resident workgroups
+    // only share that rate, while every extra split costs another 4 N K bytes of partial sums written and read back
+    // (scripts/bench_wgrad.py, r03: 256 wanted workgroups beat 384 / 512 / 768 on 14 of 16 shapes, -8 % over the step's set).
     const long tiles = (long)((n + kWgTile - 1) / kWgTile) * ((k + kWgTile - 1) / kWgTile) * groups * nbatch;
-    long want = (384 + tiles - 1) / tiles;
+    const int tune = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE);   // 10 / 11 / 12: 384 / 512 / 768 workgroups wanted (measurements)
+    const long target = tune == 10 ? 384 : (tune == 11 ? 512 : (tune == 12 ? 768 : 256));
+    long want = (target + tiles - 1) / tiles;
     const long maxsplit = m / 512 > 1 ? m / 512 : 1;
     if (want > maxsplit) want = maxsplit;
     if (want < 1) want = 1;
@@ -441,13 +701,33 @@ extern "C" int tramba_wgrad_cl(const void *gy, const void *x, float *out, void *
     a.gy_bs = gy_bs; a.gy_gs = gy_gs; a.x_bs = x_bs; a.x_gs = x_gs; a.gy_ld = gy_ld; a.x_ld = x_ld;
     a.M = (int)m; a.N = n; a.K = k; a.nbatch = nbatch; a.nsplit = nsplit; a.mchunk = mchunk; a.want_bias = want_bias;
     dim3 grid((k + kWgTile - 1) / kWgTile, (n + kWgTile - 1) / kWgTile, groups * nbatch * nsplit), block(256);
-    if (dtype == TRAMBA_BF16) hipLaunchKernelGGL((wgrad_tn_kernel<__hip_bfloat16>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((wgrad_tn_kernel<__half>), grid, block, 0, s, a);
+    // LDS-DMA staged tiles (the default) need 32-bit byte offsets inside one (group, batch) operand -- checked above -- and
+    // rows of whole 16-byte chunks; TRAMBA_TUNE_GEMM_TILE 8 / 9 select the register-staged form / 4 stages for measurements
+    const int tune = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE);
+    if (tune == 8) {
+        if (dtype == TRAMBA_BF16) hipLaunchKernelGGL((wgrad_tn_kernel<__hip_bfloat16>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wgrad_tn_kernel<__half>), grid, block, 0, s, a);
+    } else if (tune == 9) {
+        if (dtype == TRAMBA_BF16) hipLaunchKernelGGL((wgrad_dma_kernel<__hip_bfloat16, 4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<__half, 4>), grid, block, 0, s, a);
+    } else {   // 3 stages of 16 KB: three workgroups per CU (measured 3-5 % ahead of 4 stages / two workgroups)
+        if (dtype == TRAMBA_BF16) hipLaunchKernelGGL((wgrad_dma_kernel<__hip_bfloat16, 3>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<__half, 3>), grid, block, 0, s, a);
+    }
     TRAMBA_LAUNCH_CHECK();
     if (direct) return TRAMBA_OK;
     const long slab = (long)n * k + n;
-    dim3 g2((unsigned)((slab + 1023) / 1024), groups);
-    hipLaunchKernelGGL(slab_sum_kernel, g2, dim3(256), 0, s, (const float *)workspace, out, slab, nbatch * nsplit);
+    const int nslab = nbatch * nsplit;
+    if (groups == 1 && nslab >= 32 && slab % 4 == 0) {
+        // many slabs of a small output (the 96x96 / 48x48 layers: up to 144 slabs of 33 K floats): one thread per float4
+        // would walk them as a serial chain of 18 batches from 33 workgroups (13 us); col_sum_kernel spreads the slabs over
+        // 32 row lanes per 128-byte column group and folds them through LDS in a fixed order
+        dim3 g3((unsigned)((slab / 4 + 7) / 8));
+        hipLaunchKernelGGL(col_sum_kernel, g3, dim3(256), 0, s, (const float *)workspace, out, slab, nslab);
+    } else {
+        dim3 g2((unsigned)((slab + 1023) / 1024), groups);
+        hipLaunchKernelGGL(slab_sum_kernel, g2, dim3(256), 0, s, (const float *)workspace, out, slab, nslab);
+    }
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
