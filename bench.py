@@ -518,7 +518,7 @@ def bench_train(args, world, rank, dtype, sync_all, publish=None):
         best, launch = eager, "eager"
         if isinstance(graphed, dict) and graphed.get("value", 0.0) > eager["value"]:
             best, launch = graphed, "hipGraph replay (tramba_amd.GraphedTrainStep)"
-        return {"metric": "images/sec fwd+bwd+Adam Tramba-V 384x384", "value": best["value"],
+        return {"metric": f"images/sec fwd+bwd+Adam Tramba-V {args.img}x{args.img}", "value": best["value"],
                 "scaling_value": best["value"], "unit": "img/s", "steps": steps, "ms_per_step": best["ms_per_step"],
                 "batch_per_gpu": b, "global_batch": b * world, "launch": launch,
                 "grad_bytes_per_step": red.bytes_per_step() if world > 1 else 0,
@@ -655,7 +655,7 @@ def main():
     line = None
     if rank == 0:
         line = {
-            "metric": "images/sec fwd Tramba-V 384x384", "value": round(value, 2), "unit": "img/s",
+            "metric": f"images/sec fwd Tramba-V {args.img}x{args.img}", "value": round(value, 2), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "std_ms": round(std_ms, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

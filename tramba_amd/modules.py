@@ -873,13 +873,30 @@ class DCT2DSpatialTransformLayer_y(nn.Module):
         self.register_buffer("weight", _dct_filter(height))
 
 
-def _tn_f32(a32, x):
-    """a32 (T, N) fp32 coefficients, x (G, T, K) activations -> a^T @ x[g] in fp32 accuracy on the 16-bit TN kernel:
-    the coefficient matrix enters as bf16 hi + lo (two passes); fp32 data is split the same way (a third pass)."""
-    n = a32.shape[1]
-    if n % 8:                                   # the kernel moves 16-byte rows: pad the (tiny) coefficient matrix
-        a32 = F.pad(a32, (0, 8 - n % 8))
-    ah, al = _split16(a32)
+_COEF_SPLIT = {}
+DCT_BWD_LOWP_INTERMEDIATE = True   # (scripts/ compare both forms; see _DCTSplitCL)
+
+
+def _coef_split(w, lo):
+    """(bf16 hi, bf16 lo) of one half of a DCT coefficient table -- rows [0, n/2) (lo) or [n/2, n) -- as the TN kernel's
+    coefficient-major "a" operand, columns padded to the kernel's 16-byte rows.  Cached per table (address, version): the
+    tables are constants of the architecture, and splitting them per call was 36 cast / subtract launches per training step."""
+    key = (w.data_ptr(), w._version, w.shape[0], w.shape[1], lo)
+    ent = _COEF_SPLIT.get(key)
+    if ent is None:
+        h2 = w.shape[0] // 2
+        q = (w[:h2] if lo else w[h2:]).float().contiguous()
+        if q.shape[1] % 8:
+            q = F.pad(q, (0, 8 - q.shape[1] % 8))
+        ent = _COEF_SPLIT[key] = _split16(q)
+    return ent
+
+
+def _tn_coef(split, n, x):
+    """a^T @ x[g] for a split coefficient table a = hi + lo (T, N) and activations x (G, T, K): two passes of the 16-bit TN
+    kernel on bf16 data (the coefficients keep fp32 accuracy, the data is what it is); other dtypes are split the same way
+    (a third pass)."""
+    ah, al = split
     if x.dtype == torch.bfloat16:
         out = hip.tn_shared_cl(ah, x) + hip.tn_shared_cl(al, x)
     else:
@@ -891,7 +908,9 @@ def _tn_f32(a32, x):
 class _DCTSplitCL(torch.autograd.Function):
     """DCT split with autograd (training path).  Forward = the inference kernel (tramba_dct_split_cl: LL and HH quadrants
     of Wy X Wx^T).  Backward: gX = Wy_lo^T gLow Wx_lo + Wy_hi^T gHigh Wx_hi -- each term two TN contractions on the
-    library's grouped matrix-core kernel (over the coefficient index of W, then of H), coefficients in fp32 accuracy."""
+    library's grouped matrix-core kernel (over the coefficient index of W, then of H), coefficients in fp32 accuracy.  With
+    bf16 activations the intermediate between the two contractions is a bf16 map like every other activation of the step
+    (one cast; the fp32 validation mode keeps it in hi + lo pieces)."""
 
     @staticmethod
     def forward(ctx, x, wx, wy):
@@ -909,10 +928,10 @@ class _DCTSplitCL(torch.autograd.Function):
             if g is None:
                 continue
             bsz, _, _, c = g.shape
-            wxq = (wx[:h2] if lo else wx[h2:]).float().contiguous()       # (U, W): coefficient-major = the TN "a" operand
-            wyq = (wy[:h2] if lo else wy[h2:]).float().contiguous()       # (V, H)
-            z1 = _tn_f32(wxq, g.contiguous().view(bsz * h2, h2, c))       # (B*V, W, C): contracted over u
-            z2 = _tn_f32(wyq, z1.reshape(bsz, h2, n * c))                 # (B, H, W*C): contracted over v
+            z1 = _tn_coef(_coef_split(wx, lo), n, g.contiguous().view(bsz * h2, h2, c))    # (B*V, W, C): contracted over u
+            if ctx.xdtype == torch.bfloat16 and DCT_BWD_LOWP_INTERMEDIATE:
+                z1 = z1.to(torch.bfloat16)
+            z2 = _tn_coef(_coef_split(wy, lo), n, z1.reshape(bsz, h2, n * c))              # (B, H, W*C): contracted over v
             gx = z2 if gx is None else gx + z2
         return gx.view(-1, n, n, g_high.shape[-1] if g_high is not None else g_low.shape[-1]).to(ctx.xdtype), None, None
 
