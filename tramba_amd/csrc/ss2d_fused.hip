@@ -23,9 +23,10 @@
 //     consecutive positions, interleaved with the partner lane l^32), so softplus / exp / the
 //     recurrence are pure per-lane VALU work on all 64 lanes; the two half-waves exchange their 4
 //     run aggregates once per tile and fold them in sequence order.
-//   * per super-chunk of W tiles: every wave reduces its tile to a (decay, state) pair, ONE
-//     barrier, each wave folds the preceding waves' pairs (LDS) into its carry-in, replays its
-//     16 steps from registers and streams y rows out.
+//   * per step of W tiles: every wave reduces its tile to a (decay, state) pair, takes the state
+//     entering its tile from its predecessor's LDS mailbox and publishes the state leaving it
+//     (CarryLink: no workgroup barrier, the waves run decoupled), replays its 16 steps from
+//     registers and streams y rows out.
 //   * operands are prefetched two tiles deep (index vector -> row / u gathers -> compute), all
 //     as vector loads with per-lane addresses; x_dbl groups are padded to 16-byte multiples.
 // ss2d_merge_norm_cl: one wave per pixel sums the rows listed by the inverse table
@@ -434,7 +435,7 @@ struct ScanWave {
 // two LDS writes in program order -- into its own mailbox and reads its predecessor's mailbox -- tag, then value -- until
 // the tag matches.  The hand-over is one fused multiply-add per wave (h_out = A_tile h_in + H_tile) instead of a W-step
 // fold behind a barrier, and, more important, the waves of a workgroup are no longer in lock-step: measured on the Helix
-// launch (scripts/exp_scan_ablate.py) no single phase of the lock-step kernel -- stores, barrier, fold, LDS-DMA,
+// launch (ablation builds) no single phase of the lock-step kernel -- stores, barrier, fold, LDS-DMA,
 // transcendentals -- was worth more than 10 % of its time; the step was a chain of phases every wave of the CU entered
 // together.  Decoupled, a wave does phase 1 of its next tile while its successors still wait for their carry.
 // No write-after-read hazard: wave w rewrites its mailbox for step s + 1 only after it has the carry of that step, which
@@ -1379,7 +1380,7 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_stream_kernel(
             // The row offset goes into the VECTOR offset, the scalar offset stays 0: a 16-byte buffer store with
             // an SGPR soffset is exempt from hipcc's "VALU overwrites the data of a >64-bit store" wait state,
             // yet on gfx950 under memory back-pressure the store then picked up the overwritten registers
-            // (seen as corrupted dword 0 of lanes 12-15 per 16 when two streams ran; scripts/debug_concurrent.py).
+            // (seen as corrupted dword 0 of lanes 12-15 per 16 when two streams ran; tests/test_gpu_kernels.py::test_two_stream_concurrency_is_bitwise_stable).
             const unsigned vo = (q.last ? ooff[it] : kOutOfRange) + so;
             const Pack<T, V> pk = [&] { Pack<T, V> z; for (int v = 0; v < V; ++v) z.v[v] = Cvt<T>::from_f(o[v]); return z; }();
             if constexpr (sizeof(T) * V == 16) {
