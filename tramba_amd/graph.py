@@ -146,7 +146,12 @@ class GraphedTrainStep:
         pool = model_mask_pool(self.model)
         pool.forget_draw()                                  # the step's one stochastic-depth draw must be IN the graph
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):                       # records, executes nothing
+        # With collectives in the step, ProcessGroupNCCL's watchdog / heartbeat threads keep making runtime calls (event
+        # queries on the warm-up steps' work objects) while this thread records: under the default "global" capture mode
+        # any such call from ANOTHER thread invalidates the capture.  "thread_local" flags only this thread's own unsafe
+        # calls -- what PyTorch documents for capturing NCCL collectives.
+        mode = "thread_local" if (self.reducer is not None and getattr(self.reducer, "world", 1) > 1) else "global"
+        with torch.cuda.graph(graph, capture_error_mode=mode):   # records, executes nothing
             loss = train_step(self.model, self.opt, sx, sy, reducer=self.reducer)
         keep_alive = (pool.probs, pool.buf, pool.buf32)              # the keep-probabilities the captured bernoulli / divide nodes read
         pool.forget_draw()                                  # (the table drawn during capture lives in the graph's pool)
