@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void dct_pass2_kernel(const float *__restrict_
     dct_rows<float, T, PER>(in, (long)n * C, wl, n, (hi ? hn : 0) + o0, cnt, out, (long)hn * C, cok);
 }
 
-// ---- scalar-weight form (first version): kept for maps whose cosine table does not fit LDS (n > 192)
+// ---- scalar-weight form (first version): kept for maps whose cosine table does not fit LDS (n > 112, e.g. 192 at 768x768)
 constexpr int kUT = 8;  // outputs per register tile
 constexpr int kJTo = 4; // inputs per register tile of the scalar-weight form
 
@@ -198,20 +198,6 @@ __global__ __launch_bounds__(256) void dct_pass2_sw_kernel(const float *__restri
 
 using namespace tramba;
 
-// Opt-in for more than 64 KB of dynamic LDS, once per kernel and device (not per launch: the first, eager call of a shape
-// makes it, a later hipGraph capture of the same shape finds it made).
-template <auto KFN>
-static bool big_lds(size_t bytes)
-{
-    static size_t granted[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    if (bytes <= granted[dev]) return true;
-    if (hipFuncSetAttribute((const void *)KFN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-    granted[dev] = bytes;
-    return true;
-}
-
 extern "C" int tramba_dct_split_cl(const void *x, const float *wx, const float *wy, float *tmp, void *high,
                                    void *low, int batch, int n, int c, int dtype, void *stream)
 {
@@ -222,7 +208,7 @@ extern "C" int tramba_dct_split_cl(const void *x, const float *wx, const float *
     hipStream_t s = (hipStream_t)stream;
     TRAMBA_CHECK(n <= 65535, "dct_split_cl: n exceeds grid limits");
     dim3 grid((c + kWave - 1) / kWave, n, batch), block(256);
-    if (n > 192) {   // the transposed cosine table (n x (n + 4) floats) would not fit the CU's 160 KB of LDS
+    if (n > 112) {   // the transposed cosine table (n x (n + 4) floats) would not fit 64 KB of LDS
         TRAMBA_DISPATCH_DTYPE(dtype, T, {
             hipLaunchKernelGGL(dct_pass1_sw_kernel<T>, grid, block, 0, s, (const T *)x, wx, tmp, n, c);
             hipLaunchKernelGGL(dct_pass2_sw_kernel<T>, grid, block, 0, s, (const float *)tmp, wy, (T *)high, (T *)low, n, c);
@@ -232,27 +218,12 @@ extern "C" int tramba_dct_split_cl(const void *x, const float *wx, const float *
     }
     const int per1 = ((n + 3) / 4 + 7) / 8 * 8, per2 = ((n / 2 + 3) / 4 + 7) / 8 * 8;   // outputs per wave
     const size_t lds1 = (size_t)(n * (n + 4) + per1) * 4, lds2 = (size_t)(n * (n + 4) + per2) * 4;
-    // tables above 64 KB (n > 124: the 192 x 192 maps of a 768 x 768 input, 147 KB) need the opt-in for large dynamic LDS;
-    // one workgroup per CU then, each filling the table once for its 4 x PER outputs (r03: the scalar-weight form it
-    // replaces there ran 306 + 98 us per call at n = 192, C = 128, B = 2)
-#define BIG_(K_, BYTES_) \
-    if ((BYTES_) > 65536) TRAMBA_CHECK(big_lds<(K_)>(BYTES_), "dct_split_cl: %zu bytes of LDS refused", (size_t)(BYTES_))
-#define P1_(T, P_)                                                                                              \
-    do {                                                                                                        \
-        BIG_((dct_pass1_kernel<T, P_>), lds1);                                                                  \
-        hipLaunchKernelGGL((dct_pass1_kernel<T, P_>), grid, block, lds1, s, (const T *)x, wx, tmp, n, c);        \
-    } while (0)
-#define P2_(T, P_)                                                                                              \
-    do {                                                                                                        \
-        BIG_((dct_pass2_kernel<T, P_>), lds2);                                                                  \
-        hipLaunchKernelGGL((dct_pass2_kernel<T, P_>), grid, block, lds2, s, (const float *)tmp, wy, (T *)high, (T *)low, n, c); \
-    } while (0)
+#define P1_(T, P_) hipLaunchKernelGGL((dct_pass1_kernel<T, P_>), grid, block, lds1, s, (const T *)x, wx, tmp, n, c)
+#define P2_(T, P_) hipLaunchKernelGGL((dct_pass2_kernel<T, P_>), grid, block, lds2, s, (const float *)tmp, wy, (T *)high, (T *)low, n, c)
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
-        if (per1 <= 8) P1_(T, 8); else if (per1 <= 16) P1_(T, 16); else if (per1 <= 24) P1_(T, 24);
-        else if (per1 <= 32) P1_(T, 32); else if (per1 <= 40) P1_(T, 40); else P1_(T, 48);
+        if (per1 <= 8) P1_(T, 8); else if (per1 <= 16) P1_(T, 16); else if (per1 <= 24) P1_(T, 24); else P1_(T, 32);
         if (per2 <= 8) P2_(T, 8); else if (per2 <= 16) P2_(T, 16); else P2_(T, 24);
     });
-#undef BIG_
 #undef P1_
 #undef P2_
     TRAMBA_LAUNCH_CHECK();

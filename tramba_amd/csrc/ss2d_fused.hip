@@ -1763,7 +1763,10 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     // is full, so the segment form (1.6x the arithmetic) only wins where the chained form leaves CUs idle:
     // a single-segment sequence (no recompute at all, no barriers), or <= 128 sequences of >= 64 tiles.
     // (A caller that passes no workspace gets the chained form.)
-    const bool seg_wins = p.nseg == 1 || ((long)batch * k * ct <= 128 && p.ntiles >= 64);
+    // r03, after the chained kernels lost their barrier (scripts/sweep_scan_forms.py, batch 4 and batch 1): a single-segment
+    // sequence is faster on the chained kernel with its gather pipeline (12x12 maps: 15.3 against 18.1 us at batch 4, 9.8
+    // against 16.3 at batch 1); the segment form keeps the long maps of a small batch (<= 128 sequences of >= 128 tiles).
+    const bool seg_wins = (long)batch * k * ct <= 128 && p.ntiles >= 128;   // (48x48, 72 tiles: the ring at W = 8 is ahead)
     const int form_tune = tramba_tune_get(TRAMBA_TUNE_SCAN_FORM);      // 1 = chained, 2 = wave-segment, 3 = chained on LDS-DMA
     const bool use_seg = !states && !a_log && workspace != nullptr && workspace_bytes >= tramba_ss2d_scan_workspace(batch, l, d, k) &&
                          (form_tune == 2 || (form_tune == 0 && seg_wins));   // (the LDS-DMA form below is tried first;
@@ -1781,7 +1784,10 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
         //  register ring; raster 96x96 K=4, 128 sequences -- half the CUs -- 72 against 85-89 for the wave-segment form; Helix
         //  48x48, 512 sequences x 8 waves: 42 against 52; no gain below ~4 super-chunks per sequence -- 24x24: 25 = 25 --
         //  where the two memory round trips of the prologue weigh as much as the tiles)
-        if (dma_ok && (scan_tune == 3 || (scan_tune == 0 && seqs * wdma >= 2048 && p.ntiles >= 4 * wdma))) {
+        // (r03 sweep: with the mailbox carry the register ring at 8 waves per sequence is ahead on the 48x48 K = 4 maps --
+        //  25.4 against 28.1 us -- so the LDS-DMA form wants >= 8 steps per sequence, or 8-wave workgroups with >= 8 tiles each)
+        if (dma_ok && (scan_tune == 3 || (scan_tune == 0 && seqs * wdma >= 2048 &&
+                                          p.ntiles >= 8 * wdma))) {
             dim3 grid(ct, k, batch), block(wdma * kWave);
 #define DMA_(T, TY, NK_, R8_, W_) \
     launch_scan_dma<T, TY, NK_, R8_, W_>(grid, block, s, x, xdbl, table, dt_w, dt_bias, A, Ds, ys, l, d, k, r, states, a_log)
@@ -1830,6 +1836,9 @@ extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32
     // slots in the last super-chunk (measured, scripts/probe_scan_latency.py: 24x24 K=8 is 1.8x faster at W=2).
     int W = kMaxW;
     while (W > 1 && (long)batch * k * ct * W > 2048) W >>= 1;
+    // ... and at least ~4 tiles per wave (r03 sweep, mailbox carry: 24x24 at batch 1, 128 sequences of 18 tiles: 11.9 us at
+    // W = 4 against 14.5 at W = 8; 12x12, 5 tiles: one wave per sequence)
+    while (W > 1 && (l + kTP - 1) / kTP < 4 * W) W >>= 1;
     if (W > (l + kTP - 1) / kTP) W = (l + kTP - 1) / kTP;
     if (tramba_tune_get(TRAMBA_TUNE_SCAN_W) > 0) {   // A/B timing hook (scripts/bench_scan.py)
         W = tramba_tune_get(TRAMBA_TUNE_SCAN_W) < kMaxW ? tramba_tune_get(TRAMBA_TUNE_SCAN_W) : kMaxW;
