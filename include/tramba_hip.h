@@ -348,6 +348,13 @@ size_t tramba_wgrad_workspace(int64_t m, int n, int k, int groups, int nbatch);
 int tramba_wgrad_cl(const void *gy, const void *x, float *out, void *workspace, size_t workspace_bytes, int64_t m, int n,
                     int k, int groups, int nbatch, int64_t gy_bs, int64_t gy_gs, int gy_ld, int64_t x_bs, int64_t x_gs,
                     int x_ld, int want_bias, int dtype, void *stream);
+/* The same launch stopped at the partial slabs: *nslab = slabs per group left in `workspace` as (groups, *nslab, N*K + N)
+ * fp32, or 0 when a single slab was written straight to `out`.  The caller sums them later -- tramba_slab_sum, or
+ * tramba_multi_sum together with the other pending sums of a training step (the gradient of a Linear2d hangs off the backward
+ * chain: nothing reads it before the optimizer, reference train.py:86-89). */
+int tramba_wgrad_parts_cl(const void *gy, const void *x, float *out, void *workspace, size_t workspace_bytes, int64_t m,
+                          int n, int k, int groups, int nbatch, int64_t gy_bs, int64_t gy_gs, int gy_ld, int64_t x_bs,
+                          int64_t x_gs, int x_ld, int want_bias, int dtype, void *stream, int *nslab);
 /* y[z][t][0..N) = x[z][t][:] . w[z % groups][n][:]  for z < nz, t < m: x (nz, m, K) dtype, w (groups, N, K) dtype,
  * y fp32 rows of stride ldy (>= N; the columns past N are left untouched).  N <= 64, K % 8 == 0.  The dt_rank projection
  * of the SS2D backward (vmamba.py:236 under autograd): d(x_dbl ranks) = d(dt_raw) @ dt_projs_weight[k]. */
@@ -365,6 +372,11 @@ int tramba_shadow_cast_multi(const void *table, int ntensors, int64_t total_tile
 /* out[i] = sum over s < nslab of part[s*n + i], i < n, summed in slab order (deterministic): the per-workgroup partial sums
  * of the LayerNorm / depth-wise / scan parameter gradients.  n % 4 == 0, 16-byte aligned. */
 int tramba_slab_sum(const float *part, float *out, int64_t n, int nslab, void *stream);
+/* `count` such sums in ceil(count / 32) launches: outs[i][j] = sum over s < nslab[i] of parts[i][s*n[i] + j], the same
+ * summation order as tramba_slab_sum / the slab sums of tramba_wgrad_cl.  parts / outs / n / nslab are HOST arrays of device
+ * pointers and sizes (they travel to the kernel by value: nothing is copied to the device, hipGraph-capture safe). */
+int tramba_multi_sum(const float *const *parts, float *const *outs, const int64_t *n, const int *nslab, int count,
+                     void *stream);
 
 /* The whole last decoder stage in one kernel (FinalPatchExpand_X4 + seg_layers[-1], Trambav6.py:132-137):
  * y (B, H*P, W*P) f32 = head(LayerNorm_128(pixel_shuffle_P(x @ w^T))).  x (B, H, W, Cin) dtype, w (P*P*128, Cin) dtype

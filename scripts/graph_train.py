@@ -34,11 +34,17 @@ def timed(fn, n=20):
     return (time.perf_counter() - t) / n * 1e3, float(last)
 
 
-m, opt = fresh(False)
-e, le = timed(lambda: train.train_step(m, opt, x, y))
-del m, opt
-torch.cuda.empty_cache()
-m, opt = fresh(True)
-step = ta.GraphedTrainStep(m, opt)
-g, lg = timed(lambda: step(x, y))
-print(f"batch {b}: eager {e:.2f} ms (loss {le:.4f})  graph {g:.2f} ms (loss {lg:.4f})  {e / g:.2f}x  {b / g * 1e3:.1f} img/s graphed")
+for defer in (True, False, True, False):       # the partial-sum reductions batched at the end of backward / where they are issued
+    train.DEFER_SUMS = defer
+    m, opt = fresh(False)
+    e, le = timed(lambda: train.train_step(m, opt, x, y))
+    del m, opt
+    torch.cuda.empty_cache()
+    m, opt = fresh(True)
+    step = ta.GraphedTrainStep(m, opt)
+    g, lg = timed(lambda: step(x, y))
+    print(f"batch {b}, deferred sums {defer}: eager {e:.2f} ms (loss {le:.4f})  graph {g:.2f} ms (loss {lg:.4f})  {e / g:.2f}x  "
+          f"{b / g * 1e3:.1f} img/s graphed", flush=True)
+    del m, opt, step
+    torch.cuda.empty_cache()
+train.DEFER_SUMS = True

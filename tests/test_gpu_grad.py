@@ -176,3 +176,60 @@ def test_helix_scan_at_the_benchmarked_launch():
     # and the merged, normalised map as a whole: RMS error against fp64 below 1 % of the map's RMS
     err = (out.view(b, h, h, d).cpu().double() - want)
     assert float(err.pow(2).mean().sqrt()) <= 1e-2 * float(want.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("tables", [[(3, 1024)], [(9, 33024), (144, 33024), (40, 256), (1, 4096)],
+                                    [(6, 1050624), (32, 8), (31, 2052), (200, 12288)] + [(5, 512)] * 40])
+def test_batched_partial_sums_equal_the_single_ones(tables):
+    """tramba_multi_sum (the deferred partial-sum reductions of a training step, hip._SumQueue) against one
+    tramba_slab_sum per table: bit-identical -- same bodies, same summation order -- for few and many slabs, more than
+    32 tables (several launches), sizes that are not multiples of a workgroup's share."""
+    from tramba_amd import hip
+    g = torch.Generator().manual_seed(len(tables))
+    parts = [torch.randn(s, n, generator=g).to(DEV) for s, n in tables]
+    want = [hip.slab_sum(p) for p in parts]
+    hip._sumq.poison = True
+    try:
+        with hip.deferred_sums():
+            got = [hip.slab_sum(p, defer=True) for p in parts]
+            assert hip.pending_sums() == len(tables)
+            assert all(bool(torch.isnan(o).all()) for o in got)       # recorded, not run
+        assert hip.pending_sums() == 0
+    finally:
+        hip._sumq.poison = False
+    for o, w, p in zip(got, want, parts):
+        assert torch.equal(o, w)
+        ref = p.double().sum(0)
+        assert float((o.double() - ref).abs().max()) <= 1e-5 * float(p.double().abs().sum(0).max()) + 1e-6
+    x = torch.randn(4608, 512, generator=g).to(DEV, torch.bfloat16)          # the weight-gradient GEMM's slabs the same way
+    gy = torch.randn(4608, 1024, generator=g).to(DEV, torch.bfloat16)
+    gw0, gb0 = hip.wgrad_cl(gy, x, True)
+    with hip.deferred_sums():
+        gw1, gb1 = hip.wgrad_cl(gy, x, True, defer=True)
+    assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1)
+
+
+def test_deferred_sums_leave_the_training_step_unchanged(tramba_v_grad_oracle):
+    """train.train_step runs backward inside hip.deferred_sums(): every parameter gradient of Tramba-V must equal, bit for
+    bit, the gradient of a plain loss.backward() -- with the deferred outputs NaN-filled until the batched sum has run, so
+    that a reader in front of the flush (an autograd-engine copy, an accumulation, a cast) cannot go unnoticed."""
+    from tramba_amd import hip, train
+    m, x, label, _ = tramba_v_grad_oracle
+    m = m.to(DEV).train()
+    m.compute_dtype = torch.bfloat16
+    xs, ys = x.to(DEV), label.to(DEV)
+    m.zero_grad(set_to_none=True)
+    train.tramba_loss(m(xs), ys).backward()
+    want = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    hip._sumq.poison = True
+    try:
+        loss = train.tramba_loss(m(xs), ys)
+        with hip.deferred_sums():
+            loss.backward()
+            assert hip.pending_sums() > 100
+    finally:
+        hip._sumq.poison = False
+    bad = [n for n, p in m.named_parameters() if not torch.equal(p.grad, want[n])]
+    assert not bad, (len(bad), bad[:8])
+    m.compute_dtype = None

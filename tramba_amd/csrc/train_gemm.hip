@@ -435,15 +435,14 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradArgs a)
 }
 #undef TRAMBA_TR64_
 
-// out[g][i] = sum over slabs s of part[g][s][i], i < n (fixed order); 4 floats per thread, EIGHT slab rows requested before
+// out[i] = sum over slabs s of part[s][i], i < n (fixed order); 4 floats per thread, EIGHT slab rows requested before
 // the first is added (r03: four were not enough to cover the memory latency -- 29 MB in 18.6 us = 1.6 TB/s on the widest
-// layers of a training step, as much as the TN kernel in front of it)
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__ part, float *__restrict__ out, long n,
-                                                      int nslab)
+// layers of a training step, as much as the TN kernel in front of it).  `blk`: index of the 1024-float block.
+__device__ __forceinline__ void slab_sum_body(const float *__restrict__ part, float *__restrict__ out, long n, int nslab, long blk)
 {
-    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long i4 = (blk * 256 + threadIdx.x) * 4;
     if (i4 >= n) return;
-    const float *p = part + (long)blockIdx.y * nslab * n + i4;
+    const float *p = part + i4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i4 + 4 <= n) {
         int s = 0;
@@ -470,14 +469,20 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__
                 }
             }
         }
-        *reinterpret_cast<float4 *>(out + (long)blockIdx.y * n + i4) = acc;
+        *reinterpret_cast<float4 *>(out + i4) = acc;
     } else {
         for (long i = i4; i < n; ++i) {
             float sacc = 0.f;
-            for (int s = 0; s < nslab; ++s) sacc += part[((long)blockIdx.y * nslab + s) * n + i];
-            out[(long)blockIdx.y * n + i] = sacc;
+            for (int s = 0; s < nslab; ++s) sacc += part[(long)s * n + i];
+            out[i] = sacc;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__ part, float *__restrict__ out, long n,
+                                                      int nslab)
+{
+    slab_sum_body(part + (long)blockIdx.y * nslab * n, out + (long)blockIdx.y * n, n, nslab, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -533,12 +538,11 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const T *__restrict__ x,
 // parameter gradients: 10..1000 slabs of 256..12288 floats).  A block owns 32 consecutive floats (one 128-byte line per
 // slab) and spreads the slabs over 32 row lanes, eight loads in flight per thread; the row lanes are folded through LDS in a
 // fixed order.  ~200 launches per training step of Tramba-V: about half the time of a general-purpose reduction each.
-__global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ part, float *__restrict__ out, long n,
-                                                     int nslab)
+__device__ __forceinline__ void col_sum_body(const float *__restrict__ part, float *__restrict__ out, long n, int nslab,
+                                             long blk, float4 (*red)[8])
 {
-    __shared__ float4 red[32][8];
     const int q = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const long i4 = ((long)blockIdx.x * 8 + q) * 4;
+    const long i4 = (blk * 8 + q) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i4 < n) {
         const float *p = part + i4;
@@ -568,6 +572,42 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ 
         }
         *reinterpret_cast<float4 *>(out + i4) = t;
     }
+}
+
+__global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ part, float *__restrict__ out, long n,
+                                                     int nslab)
+{
+    __shared__ float4 red[32][8];
+    col_sum_body(part, out, n, nslab, blockIdx.x, red);
+}
+
+// Up to kMultiSum partial-sum tables reduced by ONE launch (r03: the deferred sums of a training step -- the slab sums
+// of the weight-gradient GEMMs and the LayerNorm parameter gradients were ~300 launches of 4-7 us each, every one on its
+// launch floor; tramba_multi_sum).  Descriptors travel by value in the kernel arguments (nothing to copy to the device,
+// hipGraph-capture safe); a workgroup finds its table by its block index; tables of >= 32 slabs take the row-lane form
+// (32 floats per workgroup), the others the slab-order form (1024 floats per workgroup) -- the same bodies, hence the same
+// summation order, as the single-table launches.
+constexpr int kMultiSum = 32;
+struct MultiSumArgs {
+    const float *part[kMultiSum];
+    float *out[kMultiSum];
+    long n[kMultiSum];
+    int nslab[kMultiSum];
+    int first[kMultiSum + 1];   // first workgroup of every table (ascending), first[count] = grid size
+    int count;
+};
+
+__global__ __launch_bounds__(256) void multi_sum_kernel(MultiSumArgs a)
+{
+    __shared__ float4 red[32][8];
+    const int blk = blockIdx.x;
+    int t = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.count; ++i)
+        if (a.first[i] <= blk) t = i;          // (block-uniform; first[] is ascending)
+    const long local = blk - a.first[t];
+    if (a.nslab[t] >= 32) col_sum_body(a.part[t], a.out[t], a.n[t], a.nslab[t], local, red);
+    else slab_sum_body(a.part[t], a.out[t], a.n[t], a.nslab[t], local);
 }
 
 // ---- multi-tensor cast (+ transpose) of fp32 matrices: table[t] = {src, dst, dst_t, rows, cols, first_tile, dst_ld,
@@ -676,9 +716,11 @@ extern "C" size_t tramba_wgrad_workspace(int64_t m, int n, int k, int groups, in
     return (size_t)groups * nbatch * nsplit * ((size_t)n * k + n) * sizeof(float);
 }
 
-extern "C" int tramba_wgrad_cl(const void *gy, const void *x, float *out, void *workspace, size_t workspace_bytes,
-                               int64_t m, int n, int k, int groups, int nbatch, int64_t gy_bs, int64_t gy_gs, int gy_ld,
-                               int64_t x_bs, int64_t x_gs, int x_ld, int want_bias, int dtype, void *stream)
+// nslab_out: null = the slabs are summed here (tramba_wgrad_cl); else the launch stops at the slabs and reports how many
+// there are per group (0: a single slab, written straight to `out`) -- tramba_wgrad_parts_cl, for callers that sum later
+static int wgrad_launch(const void *gy, const void *x, float *out, void *workspace, size_t workspace_bytes,
+                        int64_t m, int n, int k, int groups, int nbatch, int64_t gy_bs, int64_t gy_gs, int gy_ld,
+                        int64_t x_bs, int64_t x_gs, int x_ld, int want_bias, int dtype, void *stream, int *nslab_out)
 {
     TRAMBA_CHECK(gy && x && out && workspace, "wgrad_cl: null tensor");
     TRAMBA_CHECK(m > 0 && n > 0 && k > 0 && groups > 0 && nbatch > 0, "wgrad_cl: empty shape");
@@ -715,6 +757,10 @@ extern "C" int tramba_wgrad_cl(const void *gy, const void *x, float *out, void *
         else hipLaunchKernelGGL((wgrad_dma_kernel<__half, 3>), grid, block, 0, s, a);
     }
     TRAMBA_LAUNCH_CHECK();
+    if (nslab_out) {
+        *nslab_out = direct ? 0 : nbatch * nsplit;
+        return TRAMBA_OK;
+    }
     if (direct) return TRAMBA_OK;
     const long slab = (long)n * k + n;
     const int nslab = nbatch * nsplit;
@@ -730,6 +776,24 @@ extern "C" int tramba_wgrad_cl(const void *gy, const void *x, float *out, void *
     }
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
+}
+
+extern "C" int tramba_wgrad_cl(const void *gy, const void *x, float *out, void *workspace, size_t workspace_bytes,
+                               int64_t m, int n, int k, int groups, int nbatch, int64_t gy_bs, int64_t gy_gs, int gy_ld,
+                               int64_t x_bs, int64_t x_gs, int x_ld, int want_bias, int dtype, void *stream)
+{
+    return wgrad_launch(gy, x, out, workspace, workspace_bytes, m, n, k, groups, nbatch, gy_bs, gy_gs, gy_ld, x_bs, x_gs, x_ld,
+                        want_bias, dtype, stream, nullptr);
+}
+
+extern "C" int tramba_wgrad_parts_cl(const void *gy, const void *x, float *out, void *workspace, size_t workspace_bytes,
+                                     int64_t m, int n, int k, int groups, int nbatch, int64_t gy_bs, int64_t gy_gs,
+                                     int gy_ld, int64_t x_bs, int64_t x_gs, int x_ld, int want_bias, int dtype,
+                                     void *stream, int *nslab)
+{
+    TRAMBA_CHECK(nslab, "wgrad_parts_cl: null nslab");
+    return wgrad_launch(gy, x, out, workspace, workspace_bytes, m, n, k, groups, nbatch, gy_bs, gy_gs, gy_ld, x_bs, x_gs, x_ld,
+                        want_bias, dtype, stream, nslab);
 }
 
 extern "C" int tramba_rows_gemm_cl(const void *x, const void *w, float *y, int nz, int64_t m, int n, int k, int groups,
@@ -774,5 +838,36 @@ extern "C" int tramba_slab_sum(const float *part, float *out, int64_t n, int nsl
     dim3 grid((unsigned)((n / 4 + 7) / 8));
     hipLaunchKernelGGL(col_sum_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, out, (long)n, nslab);
     TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_multi_sum(const float *const *parts, float *const *outs, const int64_t *n, const int *nslab, int count,
+                                void *stream)
+{
+    TRAMBA_CHECK(parts && outs && n && nslab && count > 0, "multi_sum: empty input");
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < count; base += kMultiSum) {
+        MultiSumArgs a;
+        a.count = count - base < kMultiSum ? count - base : kMultiSum;
+        long blocks = 0;
+        for (int i = 0; i < a.count; ++i) {
+            const int j = base + i;
+            TRAMBA_CHECK(parts[j] && outs[j] && n[j] > 0 && nslab[j] > 0 && n[j] % 4 == 0 && aligned16(parts[j]) && aligned16(outs[j]),
+                         "multi_sum: table %d must hold whole, 16-byte aligned float4 rows", j);
+            a.part[i] = parts[j];
+            a.out[i] = outs[j];
+            a.n[i] = n[j];
+            a.nslab[i] = nslab[j];
+            a.first[i] = (int)blocks;
+            blocks += nslab[j] >= 32 ? (n[j] / 4 + 7) / 8 : (n[j] + 1023) / 1024;
+            TRAMBA_CHECK(blocks < 2147483647L, "multi_sum: too many workgroups");
+        }
+        for (int i = a.count; i <= kMultiSum; ++i) a.first[i] = (int)blocks;
+        for (int i = a.count; i < kMultiSum; ++i) {
+            a.part[i] = nullptr; a.out[i] = nullptr; a.n[i] = 0; a.nslab[i] = 0;
+        }
+        hipLaunchKernelGGL(multi_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        TRAMBA_LAUNCH_CHECK();
+    }
     return TRAMBA_OK;
 }

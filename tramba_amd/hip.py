@@ -86,6 +86,9 @@ SIGNATURES = {
     "tramba_rows_gemm_cl": (c_int, [c_vp] * 3 + [c_int, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "tramba_shadow_cast_multi": (c_int, [c_vp, c_int, c_i64, c_int, c_vp]),
     "tramba_slab_sum": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    "tramba_multi_sum": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "tramba_wgrad_parts_cl": (c_int, [c_vp] * 4 + [ctypes.c_size_t, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_int, c_i64,
+                                                   c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     "tramba_expand_norm_head_cl": (c_int, [c_vp] * 5 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_conv3x3s2_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
     "tramba_stem_conv_ln_gelu": (c_int, [c_vp] * 6 + [c_int] * 3 + [c_f, c_int, c_int, c_vp]),
@@ -512,7 +515,7 @@ def layernorm_bwd_cl(x, dy, w, eps=1e-5):
     part = torch.empty((lib().tramba_layernorm_bwd_parts(rows, c, dt(x)), 2, c), dtype=torch.float32, device=x.device)
     _check(lib().tramba_layernorm_bwd_cl(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(part), rows, c, eps, dt(x), _stream()),
            "layernorm_bwd_cl")
-    s = slab_sum(part)
+    s = slab_sum(part, defer=True)
     return dx, s[0], s[1]
 
 
@@ -547,7 +550,7 @@ def layernorm_bwd_res_cl(x, dy, w, eps=1e-5, gres=None, mask=None, want_masked=F
     _check(lib().tramba_layernorm_bwd_res_cl(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(part), _ptr(gres), _ptr(mask),
                                              rows // x.shape[0], _ptr(dxm), rows, c, eps, dt(x), _stream()),
            "layernorm_bwd_res_cl")
-    s = slab_sum(part)
+    s = slab_sum(part, defer=True)
     return dx, dxm, s[0], s[1]
 
 
@@ -574,7 +577,7 @@ def shuffle_norm_bwd_cl(x, dy, w, p, eps=1e-5):
     part = torch.empty((lib().tramba_layernorm_bwd_parts(rows, c, dt(x)), 2, c), dtype=torch.float32, device=x.device)
     _check(lib().tramba_shuffle_norm_bwd_cl(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(part), bb, h, wd, c, p, eps, dt(x),
                                             _stream()), "shuffle_norm_bwd_cl")
-    s = slab_sum(part)
+    s = slab_sum(part, defer=True)
     return dx, s[0], s[1]
 
 
@@ -856,9 +859,10 @@ def linear2_cl(x1, x2, w, bias=None, residual=None, act=ACT_NONE, out_dtype=None
     return y
 
 
-def wgrad_cl(gy, x, want_bias=False):
+def wgrad_cl(gy, x, want_bias=False, defer=False):
     """Weight gradient of y = x @ W^T: gy (..., N), x (..., K) 16-bit, same leading shape -> (gw (N, K) f32, gb (N) f32 or
-    None).  Rows may be strided (a column slice of a wider tensor) as long as the last dim is contiguous."""
+    None).  Rows may be strided (a column slice of a wider tensor) as long as the last dim is contiguous.  defer: inside
+    `deferred_sums()` the slab sum of the launch is recorded for `flush_sums()` (see _SumQueue)."""
     n, k = gy.shape[-1], x.shape[-1]
     gy2, x2 = gy.reshape(-1, n), x.reshape(-1, k)
     if gy2.stride(-1) != 1 or x2.stride(-1) != 1:
@@ -866,7 +870,7 @@ def wgrad_cl(gy, x, want_bias=False):
     m = gy2.shape[0]
     if x2.shape[0] != m or gy2.dtype != x2.dtype:
         raise TrambaHipError("wgrad_cl: gy / x mismatch")
-    return _wgrad(gy2, x2, m, n, k, 1, 1, 0, 0, gy2.stride(0), 0, 0, x2.stride(0), want_bias)
+    return _wgrad(gy2, x2, m, n, k, 1, 1, 0, 0, gy2.stride(0), 0, 0, x2.stride(0), want_bias, defer)
 
 
 def wgrad_grouped_cl(gy, x):
@@ -892,15 +896,27 @@ def tn_shared_cl(a, x):
     return out if g > 1 else out.view(1, n, k)
 
 
-def _wgrad(gy, x, m, n, k, groups, nbatch, gy_bs, gy_gs, gy_ld, x_bs, x_gs, x_ld, want_bias):
+def _wgrad(gy, x, m, n, k, groups, nbatch, gy_bs, gy_gs, gy_ld, x_bs, x_gs, x_ld, want_bias, defer=False):
     for t in (gy, x):
         if not t.is_cuda:
             raise TrambaHipError("tramba_amd kernels need tensors on a HIP device (no CPU fallback)")
     ws_bytes = lib().tramba_wgrad_workspace(m, n, k, groups, nbatch)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=gy.device)
     out = torch.empty((groups, n * k + n), dtype=torch.float32, device=gy.device)
-    _check(lib().tramba_wgrad_cl(_ptr(gy), _ptr(x), _ptr(out), _ptr(ws), ws_bytes, m, n, k, groups, nbatch, gy_bs, gy_gs,
-                                 gy_ld, x_bs, x_gs, x_ld, int(want_bias), dt(gy), _stream()), "wgrad_cl")
+    if defer and _sumq.enabled:
+        nslab = ctypes.c_int(0)
+        _check(lib().tramba_wgrad_parts_cl(_ptr(gy), _ptr(x), _ptr(out), _ptr(ws), ws_bytes, m, n, k, groups, nbatch, gy_bs,
+                                           gy_gs, gy_ld, x_bs, x_gs, x_ld, int(want_bias), dt(gy), _stream(),
+                                           ctypes.byref(nslab)), "wgrad_parts_cl")
+        if nslab.value > 0:          # (0: a single slab, already in `out`)
+            if _sumq.poison:
+                out.fill_(float("nan"))
+            slab = n * k + n
+            for g in range(groups):
+                _enqueue_sum(_ptr(ws) + g * nslab.value * slab * 4, _ptr(out) + g * slab * 4, slab, nslab.value, (ws, out))
+    else:
+        _check(lib().tramba_wgrad_cl(_ptr(gy), _ptr(x), _ptr(out), _ptr(ws), ws_bytes, m, n, k, groups, nbatch, gy_bs, gy_gs,
+                                     gy_ld, x_bs, x_gs, x_ld, int(want_bias), dt(gy), _stream()), "wgrad_cl")
     gw = out[:, :n * k].view(groups, n, k)
     if groups == 1:
         return gw[0], (out[0, n * k:] if want_bias else None)
@@ -918,15 +934,82 @@ def rows_gemm_cl(x, w, y, n):
     return y
 
 
-def slab_sum(part):
+class _SumQueue:
+    """Pending partial-sum reductions of a training step (tramba_multi_sum).  The parameter gradients of LayerNorm and of
+    every Linear2d leave their kernels as partial tables (one row per workgroup / token split) that a small kernel adds up in
+    a fixed order.  Nothing reads those gradients before the optimizer (reference train.py:86-89), so inside
+    `deferred_sums()` a reduction is only RECORDED -- the caller gets the output tensor, to be filled later -- and all of them
+    run as a handful of launches at `flush_sums()`: ~300 launches of 4-7 us per step, each on its launch floor, become ~10.
+    Off by default: outside the context every sum runs where it is issued.  Only call sites whose result goes straight to
+    autograd as a leaf's gradient pass defer=True (anything that READS the sum must not)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.poison = False         # tests: NaN-fill a deferred output, so that a premature reader cannot go unnoticed
+        self.items = []
+        self.lock = threading.Lock()
+
+
+_sumq = _SumQueue()
+
+
+class deferred_sums:
+    """with hip.deferred_sums(): loss.backward()   -- record the deferrable partial-sum reductions, run them at the exit"""
+
+    def __enter__(self):
+        self._was = _sumq.enabled
+        _sumq.enabled = True
+        return self
+
+    def __exit__(self, *exc):
+        _sumq.enabled = self._was
+        if not self._was:
+            flush_sums()
+        return False
+
+
+def _enqueue_sum(part_ptr, out_ptr, n, nslab, keep):
+    with _sumq.lock:
+        _sumq.items.append((part_ptr, out_ptr, int(n), int(nslab), _stream(), keep))
+
+
+def flush_sums():
+    """Run every recorded reduction (one tramba_multi_sum call per stream they were recorded on)."""
+    with _sumq.lock:
+        items, _sumq.items = _sumq.items, []
+    if not items:
+        return
+    by_stream = {}
+    for it in items:
+        by_stream.setdefault(it[4], []).append(it)
+    for stream, its in by_stream.items():
+        cnt = len(its)
+        parts = (ctypes.c_void_p * cnt)(*[it[0] for it in its])
+        outs = (ctypes.c_void_p * cnt)(*[it[1] for it in its])
+        ns = (ctypes.c_int64 * cnt)(*[it[2] for it in its])
+        nsl = (ctypes.c_int * cnt)(*[it[3] for it in its])
+        _check(lib().tramba_multi_sum(parts, outs, ns, nsl, cnt, stream), "multi_sum")
+
+
+def pending_sums():
+    return len(_sumq.items)
+
+
+def slab_sum(part, defer=False):
     """part (S, ...) f32 -> sum over the first axis, slabs added in a fixed order (tramba_slab_sum); the small partial-sum
-    tables of the backward kernels."""
+    tables of the backward kernels.  defer: inside `deferred_sums()` the sum is recorded and runs at `flush_sums()` (the
+    returned tensor is filled then) -- for results that go straight to autograd as a parameter's gradient."""
     _dev(part)
     nslab = part.shape[0]
     n = part.numel() // max(nslab, 1)
     if part.dtype != torch.float32 or not part.is_contiguous() or n % 4 or nslab == 0:
         return part.sum(dim=0)
     out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+    if defer and _sumq.enabled:
+        if _sumq.poison:
+            out.fill_(float("nan"))
+        _enqueue_sum(_ptr(part), _ptr(out), n, nslab, (part, out))   # (both stay allocated until the sum has run)
+        return out
     _check(lib().tramba_slab_sum(_ptr(part), _ptr(out), n, nslab, _stream()), "slab_sum")
     return out
 

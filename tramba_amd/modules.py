@@ -107,11 +107,12 @@ def _split16(t):
     return hi, (t - hi.float()).to(torch.bfloat16)
 
 
-def _wgrad(gy2, x2, want_bias=False):
+def _wgrad(gy2, x2, want_bias=False, defer=False):
     """Weight (and bias) gradient of y = x @ W^T: gy2 (M, N), x2 (M, K) -> gw (N, K) f32 [, gb (N) f32], on
-    tramba_wgrad_cl (token-split TN GEMM, transposed LDS reads)."""
+    tramba_wgrad_cl (token-split TN GEMM, transposed LDS reads).  defer: the result goes straight to autograd as the
+    parameter's gradient -- inside hip.deferred_sums() its slab sum joins the step's batched reduction (hip._SumQueue)."""
     if gy2.dtype != torch.float32:
-        return hip.wgrad_cl(gy2, x2, want_bias)
+        return hip.wgrad_cl(gy2, x2, want_bias, defer)
     gh, gl = _split16(gy2)
     xh, xl = _split16(x2)
     gw = hip.wgrad_cl(gh, xh)[0] + hip.wgrad_cl(gh, xl)[0] + hip.wgrad_cl(gl, xh)[0]
@@ -468,7 +469,7 @@ class _LinearTrainCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _dgrad(gy2, wa, ctx.wa_t).view(ctx.xshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _wgrad(gy2, x2, ctx.has_bias)
+            gw, gb = _wgrad(gy2, x2, ctx.has_bias, defer=True)
             gw = gw.to(ctx.wdtype)
         return gx, gw, gb
 
@@ -502,7 +503,7 @@ class _GeluLinearTrainCL(torch.autograd.Function):
             wt = wa.t().contiguous() if ctx.wa_t is None else ctx.wa_t
             gh = hip.linear_cl(gy2, wt, None, h2, hip.ACT_GELU_GRAD_MUL).view(ctx.hshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _wgrad(gy2, a2, ctx.has_bias)
+            gw, gb = _wgrad(gy2, a2, ctx.has_bias, defer=True)
             gw = gw.to(ctx.wdtype)
         return gh, gw, gb, None
 
@@ -537,7 +538,7 @@ class _LinearGeluPairTrainCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _dgrad(gy2, wa, ctx.wa_t).view(ctx.xshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _wgrad(gy2, x2, ctx.has_bias)
+            gw, gb = _wgrad(gy2, x2, ctx.has_bias, defer=True)
             gw = gw.to(ctx.wdtype)
         return gx, gw, gb
 

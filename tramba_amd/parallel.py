@@ -131,6 +131,11 @@ class GradBucketReducer:
         if self._passthrough:
             self._have_local[bi] = have
             return
+        if bucket[0].is_cuda:
+            # gradients whose partial sums are still pending (hip.deferred_sums() around backward) must hold their values
+            # before they are copied into the bucket
+            from . import hip
+            hip.flush_sums()
         dst = [v for v, p, h in zip(views, bucket, have) if h and p.grad is not v]
         src = [p.grad for v, p, h in zip(views, bucket, have) if h and p.grad is not v]
         unused = [v for v, h in zip(views, have) if not h]

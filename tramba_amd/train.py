@@ -11,6 +11,7 @@ import os
 import torch
 import torch.nn.functional as F
 
+from . import hip
 from .modules import refresh_lowp_shadows
 
 
@@ -81,6 +82,9 @@ def adjust_learning_rate(optimizer, epoch, decay_epochs, base_lr, decay_factors)
     return optimizer.param_groups[1]["lr"]
 
 
+DEFER_SUMS = True   # (scripts/graph_train.py times the step both ways)
+
+
 def train_step(model, opt, images, label, reducer=None):
     """One optimisation step (train.py:74-89).  `reducer` (tramba_amd.parallel.GradBucketReducer)
     averages gradients across data-parallel ranks; its all-reduces overlap the backward."""
@@ -90,7 +94,11 @@ def train_step(model, opt, images, label, reducer=None):
         reducer.prepare()
     else:
         opt.zero_grad(set_to_none=True)
-    loss.backward()
+    if DEFER_SUMS:
+        with hip.deferred_sums():  # the parameter-gradient partial sums of the pass run as a few batched launches at the exit
+            loss.backward()
+    else:
+        loss.backward()
     if reducer is not None:
         reducer.finish()
     opt.step()
