@@ -493,7 +493,7 @@ def test_dense_conv_training_path_matches_autograd(dtype, cfg):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rc", [(500, 128), (77, 512), (4100, 256), (33, 1024), (64, 2048), (50, 40), (100003, 128), (70001, 64),
-                                (9001, 320)])
+                                (9001, 320), (301, 1536), (4608, 1024), (1153, 2048), (700, 520)])
 def test_layernorm_training_path_matches_autograd(dtype, rc):
     """_LayerNormCL (HIP forward + HIP backward with atomic dgamma/dbeta) against F.layer_norm autograd in fp64."""
     from tramba_amd import modules as M

@@ -342,6 +342,129 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cl_kernel(const T *__restri
         pw[i] = (ln_red[i] + ln_red[2 * C + i]) + (ln_red[4 * C + i] + ln_red[6 * C + i]);
 }
 
+// Wide 16-bit rows (512 < C <= 2048, C % 8 == 0: out_norm of the 24x24 / 12x12 SS2D cores, D = 1024 / 2048), r03.  The
+// general kernel above walks kNormMaxIt = 8 predicated iterations of 8-byte pieces whatever C is: 190 VGPRs (2 waves per
+// SIMD) and 34 us for 4608 x 1024 -- 47 MB, ~7 us of HBM time.  Here the iteration count is a template parameter, a lane
+// moves 16 bytes per iteration (NIT = 2 at C = 1024), and the operands of the wave's NEXT row are requested before the
+// current row is reduced.  Same contract and the same summation order per partial row as layernorm_bwd_cl_kernel.
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const T *__restrict__ x, const T *__restrict__ dy,
+                                                                const float *__restrict__ w, T *__restrict__ dx,
+                                                                float *__restrict__ part, long rows, int C, float eps,
+                                                                int rpw, const T *__restrict__ gres,
+                                                                const float *__restrict__ mask, long rps,
+                                                                T *__restrict__ dxm, int P = 1, int H = 1, int W = 1)
+{
+    constexpr int V = 8;
+    extern __shared__ float ln_red[];          // [4 waves][2 C]
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wv;
+    const long r0 = wave * rpw;
+    const long rend = r0 + rpw < rows ? r0 + rpw : rows;
+    bool ok[NIT];
+    float gam[NIT][V], gw[NIT][V], gb[NIT][V];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c0 = (it * kWave + lane) * V;
+        ok[it] = c0 + V <= C;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            gam[it][v] = ok[it] ? w[c0 + v] : 0.f;
+            gw[it][v] = 0.f;
+            gb[it][v] = 0.f;
+        }
+    }
+    typedef Pack<T, V> Raw;
+    Raw rx[NIT], rg[NIT], rr[NIT];
+    auto request = [&](long r) {   // raw bits; converted where they are used (a conversion at the load site waits for the load)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c0 = (it * kWave + lane) * V;
+            if (ok[it]) {
+                rx[it] = *reinterpret_cast<const Raw *>(x + r * C + c0);
+                rg[it] = *reinterpret_cast<const Raw *>(dy + shuffled_row(r, P, H, W) * C + c0);
+                if (gres) rr[it] = *reinterpret_cast<const Raw *>(gres + r * C + c0);
+            }
+        }
+    };
+    if (r0 < rend) request(r0);
+    for (long r = r0; r < rend; ++r) {
+        float xv[NIT][V], gv[NIT][V], rv[NIT][V];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                xv[it][v] = ok[it] ? Cvt<T>::to_f(rx[it].v[v]) : 0.f;
+                gv[it][v] = ok[it] ? Cvt<T>::to_f(rg[it].v[v]) : 0.f;
+                rv[it][v] = (ok[it] && gres) ? Cvt<T>::to_f(rr[it].v[v]) : 0.f;
+            }
+        if (r + 1 < rend) request(r + 1);      // the next row is in flight during this row's three wave reductions
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int v = 0; v < V; ++v) sum += xv[it][v];          // (channels past C hold 0)
+        const float mean = wave_sum(sum) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float t = ok[it] ? xv[it][v] - mean : 0.f;
+                q = fmaf(t, t, q);
+            }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float xh = ok[it] ? (xv[it][v] - mean) * rstd : 0.f;
+                const float g = gv[it][v] * gam[it][v];
+                xv[it][v] = xh;
+                s1 += g;
+                s2 = fmaf(g, xh, s2);
+                gw[it][v] = fmaf(gv[it][v], xh, gw[it][v]);
+                gb[it][v] += gv[it][v];
+            }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+        const float m = (dxm && mask) ? mask[r / rps] : 1.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c0 = (it * kWave + lane) * V;
+            if (ok[it]) {
+                float o[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) o[v] = rstd * (gv[it][v] * gam[it][v] - s1 - xv[it][v] * s2) + rv[it][v];
+                store_pack<T, V>(dx + r * C + c0, o);
+                if (dxm) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) o[v] = Cvt<T>::to_f(Cvt<T>::from_f(o[v])) * m;
+                    store_pack<T, V>(dxm + r * C + c0, o);
+                }
+            }
+        }
+    }
+    float *mine = ln_red + (long)wv * 2 * C;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c0 = (it * kWave + lane) * V;
+        if (ok[it]) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                mine[c0 + v] = gw[it][v];
+                mine[C + c0 + v] = gb[it][v];
+            }
+        }
+    }
+    __syncthreads();
+    float *pw = part + (long)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256)
+        pw[i] = (ln_red[i] + ln_red[2 * C + i]) + (ln_red[4 * C + i] + ln_red[6 * C + i]);
+}
+
 // Short rows (C <= 64 * V, a multiple of V): LPR lanes per row, 64 / LPR rows of a wave in flight at once, 16-byte
 // accesses -- the one-row-per-wave form above is latency-bound there (rows of 128 channels keep half a wave idle and
 // every row waits for four dependent wave reductions): 1.27 ms for the 384x384 map of the last decoder stage at batch 8.
@@ -931,7 +1054,7 @@ static long ln_bwd_rows_per_wave(long rows, bool rows_form)
     // Long rows (one row of a wave at a time, every row a chain of three wave reductions): >= 2, i.e. 4x the waves of the
     // 8-row rule -- the 24x24 / 12x12 maps otherwise run half a wave per SIMD (43.6 us per call at 4608 x 1024).
     long rpw = rows / 4096;
-    const long lo = rows_form ? 8 : 2;
+    const long lo = rows_form ? 4 : 2;   // (r03: 4, not 8 -- 4608 x 512: 17.7 -> 12.8 us, scripts/bench_ln_bwd.py; the partial rows are summed in the step's batched reduction)
     return rpw < lo ? lo : (rpw > 128 ? 128 : rpw);
 }
 
@@ -1012,6 +1135,21 @@ extern "C" int tramba_layernorm_bwd_any_cl(const void *x, const void *dy, const 
         else { BYL_(__half, 8) }
 #undef BYL_
 #undef GOB_
+        TRAMBA_LAUNCH_CHECK();
+        return TRAMBA_OK;
+    }
+    if (dtype != TRAMBA_F32 && c % 8 == 0 && c > 512 && c <= 2048) {   // wide 16-bit rows: compile-time iteration count
+        const size_t lds = (size_t)8 * c * sizeof(float);
+#define WIDE_(T, N_)                                                                                                     \
+    hipLaunchKernelGGL((layernorm_bwd_wide_kernel<T, N_>), grid, block, lds, s, (const T *)x, (const T *)dy, w, (T *)dx, part, \
+                       (long)rows, c, eps, (int)rpw, (const T *)gres, mask, rps, (T *)dxm, P, H, W)
+#define WIDE_N_(T)                         \
+    if (c <= 1024) { WIDE_(T, 2); }        \
+    else if (c <= 1536) { WIDE_(T, 3); }   \
+    else { WIDE_(T, 4); }
+        if (dtype == TRAMBA_BF16) { WIDE_N_(__hip_bfloat16) } else { WIDE_N_(__half) }
+#undef WIDE_N_
+#undef WIDE_
         TRAMBA_LAUNCH_CHECK();
         return TRAMBA_OK;
     }
