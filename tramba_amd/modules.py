@@ -885,6 +885,8 @@ def _coef_split(w, lo):
     key = (w.data_ptr(), w._version, w.shape[0], w.shape[1], lo)
     ent = _COEF_SPLIT.get(key)
     if ent is None:
+        if len(_COEF_SPLIT) >= 64:       # (tables re-created over and over, e.g. models built in a loop: start again)
+            _COEF_SPLIT.clear()
         h2 = w.shape[0] // 2
         q = (w[:h2] if lo else w[h2:]).float().contiguous()
         if q.shape[1] % 8:
