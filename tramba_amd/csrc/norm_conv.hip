@@ -1315,40 +1315,39 @@ __global__ __launch_bounds__(256) void col2im3x3_cl_kernel(const T *__restrict__
 // deep-supervision outputs of the loss (train.py:76-85) -- as a GATHER per input pixel: torch's kernel scatters with float
 // atomics, ~64 of them onto every input pixel at 8x (183 us for an 8 x 48 x 48 map).  Same source-index rule as
 // upsample_bilinear2d: src = max(scale * (dst + 0.5) - 0.5, 0), i0 = floor(src), i1 = i0 + (i0 < n - 1), weights 1 - f, f.
+// r03: one WAVE per input pixel (its window of destination pixels -- 34 x 34 at 16x -- spread over the lanes, then a wave
+// sum), not one thread: the 24x24 map of a batch of 8 was 18 workgroups walking 1156 loads each in series (131 us).
 __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float *__restrict__ gout, float *__restrict__ gin,
                                                                    int h, int w, int H, int W, long total)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= total) return;                       // wave-uniform
     const int x = (int)(i % w);
     const long t = i / w;
     const int y = (int)(t % h);
     const long plane = t / h;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     // destination rows / columns that can read source index y / x: a window of (2 / scale + 2) around the centre
-    const int ry = (int)(1.f / sy) + 2, rx = (int)(1.f / sx) + 2;
     const int Y0 = max(0, (int)((y - 1 + 0.5f) / sy - 0.5f) - 1), Y1 = min(H - 1, (int)((y + 1 + 0.5f) / sy - 0.5f) + 1);
     const int X0 = max(0, (int)((x - 1 + 0.5f) / sx - 0.5f) - 1), X1 = min(W - 1, (int)((x + 1 + 0.5f) / sx - 0.5f) + 1);
-    (void)ry; (void)rx;
+    const int nx = X1 - X0 + 1, n = (Y1 - Y0 + 1) * nx;
     const float *g = gout + plane * (long)H * W;
     float acc = 0.f;
-    for (int Y = Y0; Y <= Y1; ++Y) {
+    for (int e = lane; e < n; e += kWave) {
+        const int Y = Y0 + e / nx, X = X0 + e % nx;
         const float fy = fmaxf(sy * ((float)Y + 0.5f) - 0.5f, 0.f);
         const int y0 = (int)fy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
         const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
         const float wy = (y0 == y ? ly0 : 0.f) + (y1 == y ? ly1 : 0.f);
-        if (wy == 0.f) continue;
-        float row = 0.f;
-        for (int X = X0; X <= X1; ++X) {
-            const float fx = fmaxf(sx * ((float)X + 0.5f) - 0.5f, 0.f);
-            const int x0 = (int)fx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
-            const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
-            const float wx = (x0 == x ? lx0 : 0.f) + (x1 == x ? lx1 : 0.f);
-            row = fmaf(wx, g[(long)Y * W + X], row);
-        }
-        acc = fmaf(wy, row, acc);
+        const float fx = fmaxf(sx * ((float)X + 0.5f) - 0.5f, 0.f);
+        const int x0 = (int)fx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        const float wx = (x0 == x ? lx0 : 0.f) + (x1 == x ? lx1 : 0.f);
+        acc = fmaf(wy * wx, g[(long)Y * W + X], acc);
     }
-    gin[i] = acc;
+    acc = wave_sum(acc);                          // fixed order: the result does not depend on the launch
+    if (lane == 0) gin[i] = acc;
 }
 
 extern "C" int tramba_upsample_bilinear_bwd(const float *gout, float *gin, int planes, int h, int w, int hout, int wout,
@@ -1357,7 +1356,7 @@ extern "C" int tramba_upsample_bilinear_bwd(const float *gout, float *gin, int p
     TRAMBA_CHECK(gout && gin, "upsample_bilinear_bwd: null tensor");
     TRAMBA_CHECK(planes > 0 && h > 0 && w > 0 && hout >= h && wout >= w, "upsample_bilinear_bwd: upsampling only");
     const long total = (long)planes * h * w;
-    hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        gout, gin, h, w, hout, wout, total);
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
