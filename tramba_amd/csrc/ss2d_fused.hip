@@ -441,7 +441,7 @@ struct ScanWave {
 // No write-after-read hazard: wave w rewrites its mailbox for step s + 1 only after it has the carry of that step, which
 // (through waves w + 1 .. W - 1 of step s and waves 0 .. w - 1 of step s + 1) descends from wave w + 1 having READ the step-s
 // value.  Forward progress: all waves of a workgroup are resident and run the same number of steps; the spin sleeps between
-// polls and is bounded (a run that ever hit the bound would end with wrong numbers, not hang the GPU).
+// polls and is bounded (a run that ever hit the bound would end with NaNs in its output, not hang the GPU).
 struct CarryLink {
     unsigned rd, wr;   // LDS byte addresses of (value[kTP], tag[kTP]) of my predecessor's / my own mailbox, at my channel
 
@@ -460,7 +460,8 @@ struct CarryLink {
         if (tile == 0) return 0.f;
         float v;
         unsigned t;
-        for (int guard = 0; guard < (1 << 20); ++guard) {
+        int guard = 0;
+        for (; guard < (1 << 20); ++guard) {
             asm volatile("ds_read_b32 %0, %2 offset:128\n\tds_read_b32 %1, %2\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(t), "=&v"(v)
                          : "v"(rd)
@@ -468,7 +469,8 @@ struct CarryLink {
             if (__builtin_amdgcn_ballot_w64(t != base + (unsigned)tile) == 0) break;
             __builtin_amdgcn_s_sleep(1);
         }
-        return v;
+        // (a wave that ever ran out of polls -- ~0.1 s -- hands on NaN: the launch ends, and its output cannot pass for a result)
+        return guard < (1 << 20) ? v : __builtin_nanf("");
 #else
         return 0.f;
 #endif
