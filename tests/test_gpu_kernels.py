@@ -790,6 +790,7 @@ def test_wgrad_tn_against_fp64(m, n, k, dtype):
 
 
 @pytest.mark.parametrize("b,kk,l,d,r", [(2, 4, 144, 64, 8), (1, 8, 576, 128, 16), (2, 8, 2304, 256, 8), (1, 4, 100, 2048, 64),
+                                        (1, 4, 576, 1024, 32), (2, 4, 150, 512, 16),
                                         (1, 4, 576, 40, 8)])
 def test_ss2d_backward_small_contractions(b, kk, l, d, r):
     """the per-direction projections of the SS2D backward (vmamba.py:233-236 under autograd): d(dt_projs_weight)[k] =

@@ -488,14 +488,20 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__
 // ------------------------------------------------------------------------------------------------
 // rows_gemm: y[z][t][n] = sum_k x[z][t][k] * w[z % groups][n][k], n < N <= 64, written as fp32 rows of stride ldy.
 // One wave owns 32 token rows: A = x rows (K-contiguous, 16-byte fragment loads), B = the group's weight rows (L2).
-template <typename T>
+// KSPLIT (r03): long rows (K >= 512: the 24x24 / 48x48 cores, D = 1024 / 512) gave 4.5 workgroups per (b, k) plane -- 640
+// waves for the chip, every one streaming 32 rows of 2 KB with one fragment load in flight per step (19.9 us for 37.7 MB).
+// There the four waves of a workgroup share ONE 32-row tile and split K in quarters (4x the workgroups, 4x the loads in
+// flight per row); the partial tiles meet in LDS and are added in wave order (fixed).
+template <typename T, bool KSPLIT>
 __global__ __launch_bounds__(256) void rows_gemm_kernel(const T *__restrict__ x, const T *__restrict__ w,
                                                        float *__restrict__ y, int M, int N, int K, int groups, int ldy)
 {
+    __shared__ float part[KSPLIT ? 4 : 1][KSPLIT ? 32 : 1][KSPLIT ? 65 : 1];
     const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
     const int z = blockIdx.y, gidx = z % groups;
-    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
-    if (row0 >= M) return;                       // wave-uniform, no barriers
+    const long row0 = KSPLIT ? (long)blockIdx.x * 32 : ((long)blockIdx.x * 4 + wv) * 32;
+    if (!KSPLIT && row0 >= M) return;            // wave-uniform, no barriers on this path
     const int r32 = lane & 31, kh = (lane >> 5) * 8;
     const T *xz = x + (long)z * M * K;
     const T *wz = w + (long)gidx * N * K;
@@ -508,9 +514,12 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const T *__restrict__ x,
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const bool two = N > 32;                     // uniform
     const frag8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k0 = 0; k0 < K; k0 += 16) {         // K is a multiple of 8 (host-checked): an 8-element run is in or out whole
-        const bool in = k0 + kh < K;
-        const int kk = in ? k0 + kh : 0;
+    const int kq = KSPLIT ? K / 4 : K;           // (host: K % 64 == 0 when split)
+    const int kbeg = KSPLIT ? wv * kq : 0, kend = kbeg + kq;
+#pragma unroll 4
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {   // K is a multiple of 8 (host-checked): an 8-element run is in or out whole
+        const bool in = k0 + kh < kend;
+        const int kk = in ? k0 + kh : kbeg;
         frag8s fa = *reinterpret_cast<const frag8s *>(xz + row * K + kk);
         const frag8s f0 = *reinterpret_cast<const frag8s *>(wz + (long)c0 * K + kk);
         if (!in) fa = zero;
@@ -521,14 +530,31 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const T *__restrict__ x,
         }
     }
     float *yz = y + (long)z * M * ldy;
+    if constexpr (KSPLIT) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = j * 32 + r32;
-        if (col < N) {
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 32 + r32;
+            if (col < N) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long t = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (t < M) yz[t * ldy + col] = acc[j][r];
+                for (int r = 0; r < 16; ++r) part[wv][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][col] = acc[j][r];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * N; i += 256) {
+            const int t = i / N, col = i - t * N;
+            if (row0 + t < M)
+                yz[(row0 + t) * ldy + col] = ((part[0][t][col] + part[1][t][col]) + part[2][t][col]) + part[3][t][col];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 32 + r32;
+            if (col < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long t = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (t < M) yz[t * ldy + col] = acc[j][r];
+                }
             }
         }
     }
@@ -805,13 +831,16 @@ extern "C" int tramba_rows_gemm_cl(const void *x, const void *w, float *y, int n
     TRAMBA_CHECK(n <= 64 && k % 8 == 0 && ldy >= n && nz <= 65535, "rows_gemm_cl: needs N <= 64, K %% 8 == 0, ldy >= N");
     TRAMBA_CHECK(aligned16(x) && aligned16(w), "rows_gemm_cl: 16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)((m + 127) / 128), nz), block(256);
-    if (dtype == TRAMBA_BF16)
-        hipLaunchKernelGGL((rows_gemm_kernel<__hip_bfloat16>), grid, block, 0, s, (const __hip_bfloat16 *)x,
-                           (const __hip_bfloat16 *)w, y, (int)m, n, k, groups, ldy);
-    else
-        hipLaunchKernelGGL((rows_gemm_kernel<__half>), grid, block, 0, s, (const __half *)x, (const __half *)w, y, (int)m, n,
-                           k, groups, ldy);
+    const bool split = k >= 512 && k % 64 == 0;   // long rows: the workgroup's waves share a 32-row tile and split K
+    dim3 grid((unsigned)(split ? (m + 31) / 32 : (m + 127) / 128), nz), block(256);
+#define ROWS_(T, S_) \
+    hipLaunchKernelGGL((rows_gemm_kernel<T, S_>), grid, block, 0, s, (const T *)x, (const T *)w, y, (int)m, n, k, groups, ldy)
+    if (dtype == TRAMBA_BF16) {
+        if (split) ROWS_(__hip_bfloat16, true); else ROWS_(__hip_bfloat16, false);
+    } else {
+        if (split) ROWS_(__half, true); else ROWS_(__half, false);
+    }
+#undef ROWS_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
