@@ -272,6 +272,28 @@ def sq_valu_floor(key):
     return None
 
 
+def train_traffic(keys):
+    """HBM bytes per training step of a kernel family from the newest committed PMC summary of the training step
+    (profiles/*_train_traffic.json: scripts/pmc_train.sh + scripts/summarize_train_traffic.py, batch 8).  keys: substrings of
+    the summary's family names, summed.  (bytes, source) or (None, None)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_train_traffic.json")))
+    try:
+        tag = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
+        paths.sort(key=lambda q: os.path.basename(q).startswith(tag + "_"))
+    except OSError:
+        pass
+    for path in reversed(paths):
+        try:
+            ks = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+        tot = sum(v["traffic_bytes"] for name, v in ks.items() if any(k in name for k in keys))
+        if tot > 0:
+            return int(tot), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def helix_pair_roofline(step, nrep, batch, act_bytes, img):
     """The Helix-SS2D core at the decoder's top stage (H = img / 4: 96x96 at 384, 192x192 at 768; K = 8, D = 256): fused scan
     launch + merge/out_norm launch, both timed INSIDE eager single-stream forwards of the model by the library's launch
@@ -485,15 +507,23 @@ def bench_train(args, world, rank, dtype, sync_all, publish=None):
     hip.profile_enable(hip.PROF_SCAN_BWD, False)
     hip.profile_min_units(hip.PROF_SCAN_BWD, 0.0)
     tfw = flopw / (msw * 1e-3) / 1e12 if msw > 0 else 0.0
-    roof_w = {"bound": "mfma", "kernel": "wgrad_tn_kernel (+ slab_sum_kernel): weight / bias gradients of every 1x1 conv, the "
-                                         "per-direction dt_projs_weight contractions, the DCT backward",
+    # PMC traffic of the families (bytes per STEP at batch 8, from the committed summary: only meaningful for this batch)
+    tr_w, src_w = train_traffic(("wgrad",)) if b == 8 else (None, None)
+    tr_sb, src_sb = train_traffic(("ss2d_scan_bwd",)) if b == 8 else (None, None)
+    tr_g, src_g = train_traffic(("linear (",)) if b == 8 else (None, None)
+    roof_w = {"bound": "mfma", "kernel": "wgrad_dma_kernel: weight / bias gradients of every 1x1 conv, the per-direction "
+                                         "dt_projs_weight contractions, the DCT backward (slab sums recorded for the step's "
+                                         "batched reduction)",
               "achieved": round(tfw, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfw / MFMA_PEAK_TFS, 4),
-              "traffic": None, "launches": nw // 2, "avg_us": round(msw / max(nw, 1) * 1e3, 2), "ms_per_step": round(msw / 2, 3),
+              "traffic": tr_w, "traffic_source": src_w, "traffic_unit": "bytes per step, all launches of the family",
+              "launches": nw // 2, "avg_us": round(msw / max(nw, 1) * 1e3, 2), "ms_per_step": round(msw / 2, 3),
               "note": "2*M*N*K of every tramba_wgrad_cl call / HIP-event time around the call (TN GEMM + its fixed-order slab "
                       "sum), two eager steps"}
     gsb = bytes_sb / (mssb * 1e-3) / 1e9 if mssb > 0 else 0.0
     roof_sb = {"bound": "valu", "kernel": "ss2d_scan_bwd_cl_kernel, all 33 launches of a step", "achieved": round(gsb, 1),
-               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gsb / HBM_PEAK_GBS, 4), "traffic": None,
+               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gsb / HBM_PEAK_GBS, 4), "traffic": tr_sb,
+               "traffic_source": src_sb, "traffic_unit": "bytes per step, all launches of the family",
+               "algorithmic_bytes_per_step": int(bytes_sb / 2),
                "launches": nsb // 2, "avg_us": round(mssb / max(nsb, 1) * 1e3, 2), "ms_per_step": round(mssb / 2, 3),
                "formula": "SURVEY 8(d) backward of the op it replaces: 12 B per (b,k,d,l) element at 16-bit activations (u, "
                           "delta, dout read; du, ddelta written) / HIP-event time",
@@ -507,7 +537,8 @@ def bench_train(args, world, rank, dtype, sync_all, publish=None):
     tfs = flops / (msg * 1e-3) / 1e12
     roof = {"bound": "mfma", "kernel": "linear_dma_kernel / linear_lean_kernel: forward + input-gradient GEMMs of the step",
             "achieved": round(tfs, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_PEAK_TFS, 4),
-            "traffic": None, "launches": ng // 2, "avg_us": round(msg / ng * 1e3, 2), "ms_per_step": round(msg / 2, 3),
+            "traffic": tr_g, "traffic_source": src_g, "traffic_unit": "bytes per step, all launches of the family",
+            "launches": ng // 2, "avg_us": round(msg / ng * 1e3, 2), "ms_per_step": round(msg / 2, 3),
             "note": "2*M*N*K of every tramba_linear_cl launch / HIP-event time, two eager steps; the weight-gradient GEMMs "
                     "(wgrad_tn_kernel) and the scan backward are the next two families (profiles/*_train_kernel_stats.csv)"}
     eager = {"value": round(world * b * steps / dt, 2), "unit": "img/s", "ms_per_step": round(dt / steps * 1e3, 2)}
