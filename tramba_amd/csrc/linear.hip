@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void linear_dma_kernel(const T *__restrict__ x
     constexpr int TILE_BYTES = (BM + BN) * kBK * 2;          // 16 KB
     constexpr int EPI_BYTES = BM * (BN + 4) * 4;
     constexpr int LDS_BYTES = NSTG * TILE_BYTES > EPI_BYTES ? NSTG * TILE_BYTES : EPI_BYTES;
-    static_assert(NSTG == 3 || NSTG == 4, "stage index = kt % NSTG with the loop unrolled by NSTG (up to 8 stages are coded)");
+    static_assert(NSTG == 2 || NSTG == 3 || NSTG == 4, "stage index = kt % NSTG with the loop unrolled by NSTG (up to 8 stages are coded)");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES + (LNIN ? BM * 8 : 0)];
     typedef __attribute__((address_space(3))) void lds_void;
 
@@ -849,7 +849,8 @@ __global__ __launch_bounds__(256) void linear_dma_kernel(const T *__restrict__ x
         // my pieces of tile kt have landed: only the four pieces of each LATER tile already requested may be in flight
         const int later = nk - 1 - kt;
         if (later >= DEPTH - 1) {
-            if constexpr (DEPTH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if constexpr (DEPTH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (DEPTH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if constexpr (DEPTH == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         } else {
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(256) void linear_dma_kernel(const T *__restrict__ x
     for (; kt0 + NSTG <= nk; kt0 += NSTG) {
         kstep(kt0, std::integral_constant<int, 0>{});
         kstep(kt0 + 1, std::integral_constant<int, 1>{});
-        kstep(kt0 + 2, std::integral_constant<int, 2>{});
+        if constexpr (NSTG > 2) kstep(kt0 + 2, std::integral_constant<int, 2>{});
         if constexpr (NSTG > 3) kstep(kt0 + 3, std::integral_constant<int, 3>{});
         if constexpr (NSTG > 4) {
             kstep(kt0 + 4, std::integral_constant<int, 4>{});
@@ -913,7 +914,9 @@ __global__ __launch_bounds__(256) void linear_dma_kernel(const T *__restrict__ x
         }
     }
     if (kt0 < nk) kstep(kt0, std::integral_constant<int, 0>{});
-    if (kt0 + 1 < nk) kstep(kt0 + 1, std::integral_constant<int, 1>{});
+    if constexpr (NSTG > 2) {
+        if (kt0 + 1 < nk) kstep(kt0 + 1, std::integral_constant<int, 1>{});
+    }
     if constexpr (NSTG > 3) {
         if (kt0 + 2 < nk) kstep(kt0 + 2, std::integral_constant<int, 2>{});
     }
@@ -959,6 +962,11 @@ static bool tile96(long m, int n, int k)
     return k >= 512 && t64 <= 1024 && r96 * 96 < r64 * 64;
 }
 
+// K up to which a grid of >= 1024 tiles runs linear_dma_kernel on 2 LDS stages (5 workgroups per CU instead of 3):
+// scripts/bench_gemm_stages.py, r03 -- -12 % at M = 36864 / 73728, N = 512, K = 128, -3..7 % on the other K <= 256 shapes,
+// +5 % at K = 512
+constexpr int DMA_SHORT_K = 256;
+
 template <typename T, typename TO, bool CONV = false>
 static void launch_tiled(const void *x, const void *w, const float *bias, const void *res, void *y, long m, int n,
                          int k, int act, hipStream_t s, ConvGeom cg = ConvGeom{0, 0, 0, 0, 0},
@@ -979,9 +987,15 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
     //  there -- M = 576, N = 1024, K = 4096: 27 -> 22 us with operands that are not cache-resident; 8 stages = one block per
     //  CU by LDS, was measured slower on every shape and is not built)
     const bool dma_deep = tile_tune == 7 || (tile_tune == 0 && tiles64 <= 256 && k >= 1024);
-    if (!CONV && lean_ok && !x2 && (tile_tune == 0 || tile_tune == 6 || tile_tune == 7)) {
+    if (!CONV && lean_ok && !x2 && (tile_tune == 0 || tile_tune == 6 || tile_tune == 7 || tile_tune == 13 || tile_tune == 14)) {
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
-        if (dma_deep)
+        // short K (<= 4 steps) on a grid of many tiles: the launch is prologue + epilogue, and what it needs is workgroups in
+        // flight -- 2 stages = 32 KB of LDS = 5 per CU instead of 3 (TRAMBA_TUNE_GEMM_TILE 13 forces it, 14 forbids it)
+        const bool dma_short = tile_tune == 13 || (tile_tune == 0 && DMA_SHORT_K > 0 && k <= DMA_SHORT_K && tiles64 >= 1024);
+        if (dma_short)
+            hipLaunchKernelGGL((linear_dma_kernel<T, TO, 2>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
+                               (const T *)res, (TO *)y, m, n, k, act);
+        else if (dma_deep)
             hipLaunchKernelGGL((linear_dma_kernel<T, TO, 4>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
                                (const T *)res, (TO *)y, m, n, k, act);
         else
@@ -1148,8 +1162,12 @@ extern "C" int tramba_linear_ln_cl(const void *x, const void *w_folded, const fl
     const bool dma = tile_tune == 0 || tile_tune == 6;   // the LDS-DMA staged kernel (default)
     dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
     const LnIn li{colsum, eps};
+    const bool dma_short = dma && tile_tune == 0 && k <= DMA_SHORT_K && ((m + 63) / 64) * ((n + 63) / 64) >= 1024;   // (launch_tiled)
 #define LNIN_(T, TO)                                                                                                     \
-    if (dma)                                                                                                             \
+    if (dma_short)                                                                                                       \
+        hipLaunchKernelGGL((linear_dma_kernel<T, TO, 2, true>), grid, block, 0, s, (const T *)x, (const T *)w_folded, bias, \
+                           (const T *)residual, (TO *)y, m, n, k, act, li);                                              \
+    else if (dma)                                                                                                        \
         hipLaunchKernelGGL((linear_dma_kernel<T, TO, 3, true>), grid, block, 0, s, (const T *)x, (const T *)w_folded, bias, \
                            (const T *)residual, (TO *)y, m, n, k, act, li);                                              \
     else if (deep)                                                                                                            \
@@ -1258,15 +1276,17 @@ extern "C" int tramba_linear_dual_cl(const void *x, const void *w, const float *
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(TRAMBA_PROF_GEMM, s, 2.0 * (double)m * n * k);
     dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
+    const bool dma_short = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE) == 0 && k <= DMA_SHORT_K &&
+                           ((m + 63) / 64) * ((n + 63) / 64) >= 1024;   // (launch_tiled)
+#define DUAL_(T, S_)                                                                                                    \
+    hipLaunchKernelGGL((linear_dma_kernel<T, T, S_, false, true>), grid, block, 0, s, (const T *)x, (const T *)w, bias,   \
+                       (const T *)nullptr, (T *)y_act, m, n, k, act, LnIn{nullptr, 0.f}, (T *)y_pre)
     if (dtype == TRAMBA_BF16) {
-        using T = __hip_bfloat16;
-        hipLaunchKernelGGL((linear_dma_kernel<T, T, 3, false, true>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
-                           (const T *)nullptr, (T *)y_act, m, n, k, act, LnIn{nullptr, 0.f}, (T *)y_pre);
+        if (dma_short) DUAL_(__hip_bfloat16, 2); else DUAL_(__hip_bfloat16, 3);
     } else {
-        using T = __half;
-        hipLaunchKernelGGL((linear_dma_kernel<T, T, 3, false, true>), grid, block, 0, s, (const T *)x, (const T *)w, bias,
-                           (const T *)nullptr, (T *)y_act, m, n, k, act, LnIn{nullptr, 0.f}, (T *)y_pre);
+        if (dma_short) DUAL_(__half, 2); else DUAL_(__half, 3);
     }
+#undef DUAL_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
