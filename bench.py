@@ -38,8 +38,10 @@ Rank 0 prints ONE JSON line.  Objects on that line besides the contract's fields
                 curve is about: the forward leg at N > 1 is independent replicas); `train.roofline` = the forward +
                 input-gradient GEMMs of the step against the dense MFMA peak, `train.roofline_wgrad` = the weight-gradient
                 GEMMs, `train.roofline_scan_bwd` = the fused scan backward (12 B per element), all launches
-                and the Helix top-stage launch alone; `train.step_ms_by_rank` = every rank's own time for the timed steps.  The leg runs under a watchdog (--train-timeout): if a collective
-                never completes, rank 0 still prints the line, with train = {"error": ...}
+                and the Helix top-stage launch alone; each of the three carries `traffic` = PMC bytes per step of its kernel
+                family at batch 8 (`traffic_source`: profiles/<tag>_train_traffic.json, scripts/pmc_train.sh);
+                `train.step_ms_by_rank` = every rank's own time for the timed steps.  The leg runs under a watchdog
+                (--train-timeout): if a collective never completes, rank 0 still prints the line, with train = {"error": ...}
 """
 import argparse
 import json
