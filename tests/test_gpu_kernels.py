@@ -204,6 +204,33 @@ def test_linear_cl_small_grid_long_k(dtype, mnk):
     assert torch.equal(H.linear2_cl(x[:, :k1].contiguous(), x[:, k1:].contiguous(), w, bias, res, 2), got)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mnk", [(9216, 512, 128), (36864, 128, 256), (8200, 520, 256), (9216, 512, 320)])
+def test_linear_cl_short_k_on_two_lds_stages(dtype, mnk):
+    """Grids of >= 1024 tiles with K <= 256 run linear_dma_kernel on 2 LDS stages (5 workgroups per CU): fp64 on the same
+    16-bit inputs, ragged M / N included, and bit-identical to the 3-stage form (TRAMBA_TUNE_GEMM_TILE 14) -- the K loop
+    adds the same products in the same order whatever the ring depth; K = 320 stays on 3 stages either way.  Also the
+    dual-output (training fc1) form."""
+    m, n, k = mnk
+    H = hip()
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) + torch.arange(k)[None, :] * 0.002).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dtype).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(m, n, generator=g).to(dtype).to(DEV)
+    want = F.gelu(x.double() @ w.double().T + bias.double()) + res.double()
+    got = H.linear_cl(x, w, bias, res, 2)
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.cpu().numpy(), rtol=2e-2, atol=2e-2 * max(1.0, float(want.abs().max())))
+    H.tune_set(H.TUNE_GEMM_TILE, 14)
+    try:
+        assert torch.equal(H.linear_cl(x, w, bias, res, 2), got)
+    finally:
+        H.tune_set(H.TUNE_GEMM_TILE, 0)
+    if n % 8 == 0 and H.linear_dual_ok(x, w):
+        pre, act = H.linear_dual_cl(x, w, bias, 2)
+        assert torch.equal(act, H.linear_cl(x, w, bias, None, 2)) and torch.equal(pre, H.linear_cl(x, w, bias, None, 0))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("fam", ["raster", "helix", "window", "dilation"])
 @pytest.mark.parametrize("cfg", [(2, 12, 32, 2), (1, 24, 64, 4), (1, 16, 40, 3), (1, 48, 128, 8), (1, 12, 96, 40), (1, 24, 32, 64), (2, 96, 64, 8),
