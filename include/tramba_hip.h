@@ -415,6 +415,39 @@ int tramba_stem_conv_ln_gelu(const void *img, const float *w, const float *bias,
 int tramba_saliency_stats(const float *pred, const unsigned char *gt, long long *ints, double *dbl, int batch, int h,
                           int w, void *stream);
 
+/* ------------------------------------------------------------------ loss and optimizer of the training step */
+/* The deep-supervision loss (train.py:76-85; utils/loss.py:6-11) of ONE output: logits (planes, h, w) f32 bilinearly resized
+ * (F.interpolate(mode="bilinear"), align_corners=False; identity when the sizes agree) to the label (planes, hout, wout) f32,
+ * then per plane the three sums behind binary_cross_entropy_with_logits + iou_loss:
+ *   part[plane][blk][0..3) = sum of { max(z,0) - z y + log(1 + exp(-|z|)),  sigmoid(z) y,  sigmoid(z) + y }
+ * over the pixels workgroup blk of nblk walked (any nblk >= 1; fixed summation order).  The resized map is never stored. */
+int tramba_sod_loss_sums(const float *logits, const float *label, float *part, int planes, int h, int w, int hout, int wout,
+                         int nblk, void *stream);
+/* loss[0] = sum over outputs o < nout (<= 8) of weights[o] * ( mean bce + mean over planes of 1 - (I + 1) / (U - I + 1) ),
+ * from the tables of tramba_sod_loss_sums (parts[o]: (planes, nblk[o], 3)), accumulated in fp64, and coefs[o] (planes, 4) f32 =
+ * the per-plane coefficients { a, cI, cU, 0 } of d loss / d resized logit = a (p - y) + p (1 - p) (cI y + cU).
+ * parts / nblk / weights (NULL: all 1) / coefs are HOST arrays; they travel by value (hipGraph-capture safe).
+ * planes <= 512; npix = hout * wout. */
+int tramba_sod_loss_finish(const float *const *parts, const int *nblk, const float *weights, float *const *coefs, int nout,
+                           int planes, int64_t npix, float *loss, void *stream);
+/* glogits (planes, h, w) f32 = gscale[0] * d loss / d logits of one output (gscale: device scalar, the incoming gradient of
+ * the loss; NULL = 1).  A resized output goes through the adjoint of the bilinear resize, which is separable: the gradient
+ * at label resolution is formed once per label pixel in LDS, folded along x into `workspace` (planes, hout, w) f32 and then
+ * along y (no atomics, fixed order; cf. tramba_upsample_bilinear_bwd).  hout >= h, wout >= w, wout <= 4096. */
+size_t tramba_sod_loss_grad_workspace(int planes, int h, int w, int hout, int wout);
+int tramba_sod_loss_grad(const float *logits, const float *label, const float *coef, const float *gscale, float *glogits,
+                         void *workspace, size_t workspace_bytes, int planes, int h, int w, int hout, int wout, void *stream);
+/* One Adam step (torch.optim.Adam as train.py:266-280 builds it: amsgrad off, maximize off) on `count` fp32 tensors:
+ *   steps[i][0] += 1 (device counters, part of the optimizer's state_dict);  g += weight_decay p;
+ *   exp_avg = lerp(exp_avg, g, 1 - beta1);  exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) g g;
+ *   p -= lr / (1 - beta1^t) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps)       (bias corrections in fp64)
+ * The six arrays are HOST arrays of device pointers / element counts; the tensors travel to the kernels by value, 72 per
+ * launch (nothing is copied to the device: hipGraph-capture safe).  Any alignment; 16-byte aligned tensors take the
+ * vector path. */
+int tramba_adam_step(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                     float *const *steps, const int64_t *numel, int count, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,11 @@ SIGNATURES = {
     "tramba_expand_norm_head_cl": (c_int, [c_vp] * 5 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_conv3x3s2_cl": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
     "tramba_stem_conv_ln_gelu": (c_int, [c_vp] * 6 + [c_int] * 3 + [c_f, c_int, c_int, c_vp]),
+    "tramba_sod_loss_sums": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp]),
+    "tramba_sod_loss_finish": (c_int, [c_vp] * 4 + [c_int, c_int, c_i64, c_vp, c_vp]),
+    "tramba_sod_loss_grad_workspace": (ctypes.c_size_t, [c_int] * 5),
+    "tramba_sod_loss_grad": (c_int, [c_vp] * 6 + [ctypes.c_size_t] + [c_int] * 5 + [c_vp]),
+    "tramba_adam_step": (c_int, [c_vp] * 6 + [c_int] + [ctypes.c_double] * 5 + [c_vp]),
 }
 
 _lib = None
@@ -719,6 +724,91 @@ def upsample_bilinear_bwd(gout, h, w):
         raise TrambaHipError("upsample_bilinear_bwd: fp32 gradients only")
     _check(lib().tramba_upsample_bilinear_bwd(_ptr(gout), _ptr(gin), planes, h, w, hh, ww, _stream()), "upsample_bilinear_bwd")
     return gin
+
+
+def _loss_nblk(npix):
+    """workgroups per plane of tramba_sod_loss_sums: ~1024 pixels each"""
+    return max(1, min(256, (npix + 1023) // 1024))
+
+
+def sod_loss(outputs, label, weights=None):
+    """The deep-supervision loss of train.py:76-85 (every output resized to the label, BCE-with-logits + IoU, summed with
+    `weights`): outputs = fp32 (B, C, h_i, w_i) logit maps, label (B, C, H, W) f32.  Returns (loss 0-dim f32, coefs): coefs[i]
+    (B*C, 4) feeds `sod_loss_grad`.  One launch per output + one finishing block."""
+    _dev(label, *outputs)
+    if label.dtype != torch.float32 or any(o.dtype != torch.float32 for o in outputs):
+        raise TrambaHipError("sod_loss: fp32 logits and labels only")
+    hh, ww = label.shape[-2:]
+    planes = label.numel() // (hh * ww)
+    nout = len(outputs)
+    if not 0 < nout <= 8:
+        raise TrambaHipError(f"sod_loss: 1..8 outputs, got {nout}")
+    nblk = _loss_nblk(hh * ww)
+    stream = _stream()
+    parts = torch.empty((nout, planes, nblk, 3), dtype=torch.float32, device=label.device)
+    coefs = torch.empty((nout, planes, 4), dtype=torch.float32, device=label.device)
+    for i, o in enumerate(outputs):
+        h, w = o.shape[-2:]
+        if o.numel() != planes * h * w or h > hh or w > ww:
+            raise TrambaHipError(f"sod_loss: output {i} {tuple(o.shape)} does not match the label {tuple(label.shape)}")
+        _check(lib().tramba_sod_loss_sums(_ptr(o), _ptr(label), parts[i].data_ptr(), planes, h, w, hh, ww, nblk, stream),
+               "sod_loss_sums")
+    loss = torch.empty((), dtype=torch.float32, device=label.device)
+    pp = (ctypes.c_void_p * nout)(*[parts[i].data_ptr() for i in range(nout)])
+    cc = (ctypes.c_void_p * nout)(*[coefs[i].data_ptr() for i in range(nout)])
+    nb = (ctypes.c_int * nout)(*([nblk] * nout))
+    wt = None if weights is None else (ctypes.c_float * nout)(*[float(w) for w in weights])
+    _check(lib().tramba_sod_loss_finish(pp, nb, wt, cc, nout, planes, hh * ww, _ptr(loss), stream), "sod_loss_finish")
+    return loss, coefs
+
+
+def sod_loss_grad(output, label, coef, gscale=None):
+    """d loss / d output for one output of `sod_loss` (coef = its row of the coefficient table), times the device scalar
+    `gscale` (the gradient arriving at the loss)."""
+    _dev(output, label, coef, gscale)
+    if gscale is not None and (gscale.dtype != torch.float32 or gscale.numel() != 1):
+        raise TrambaHipError("sod_loss_grad: the incoming gradient must be one fp32 scalar")
+    hh, ww = label.shape[-2:]
+    h, w = output.shape[-2:]
+    planes = label.numel() // (hh * ww)
+    g = torch.empty_like(output)
+    nbytes = lib().tramba_sod_loss_grad_workspace(planes, h, w, hh, ww)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=output.device) if nbytes else None
+    _check(lib().tramba_sod_loss_grad(_ptr(output), _ptr(label), _ptr(coef), _ptr(gscale), _ptr(g), _ptr(ws), nbytes, planes, h, w,
+                                      hh, ww, _stream()), "sod_loss_grad")
+    return g
+
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, beta1, beta2, eps, weight_decay=0.0):
+    """One Adam step on lists of fp32 device tensors (tramba_adam_step); `steps` are the 0-dim fp32 device counters of
+    torch.optim.Adam's capturable state."""
+    n = len(params)
+    if n == 0:
+        return
+    if not (len(grads) == len(exp_avgs) == len(exp_avg_sqs) == len(steps) == n):
+        raise TrambaHipError("adam_step: the five tensor lists differ in length")
+    for group in (params, grads, exp_avgs, exp_avg_sqs, steps):
+        for t in group:
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise TrambaHipError("adam_step: contiguous fp32 tensors on a HIP device only (a sparse or strided gradient?)")
+    for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
+        if not (g.numel() == m.numel() == v.numel() == p.numel()):
+            raise TrambaHipError("adam_step: gradient / state of another size than the parameter")
+    adam_step_raw(pointer_array(params), pointer_array(grads), pointer_array(exp_avgs), pointer_array(exp_avg_sqs),
+                  pointer_array(steps), (ctypes.c_int64 * n)(*[t.numel() for t in params]), n, lr, beta1, beta2, eps,
+                  weight_decay)
+
+
+def pointer_array(tensors):
+    """host array of the tensors' device addresses, as the by-value multi-tensor entries take them"""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def adam_step_raw(params, grads, exp_avgs, exp_avg_sqs, steps, numel, n, lr, beta1, beta2, eps, weight_decay=0.0):
+    """`adam_step` on prepared pointer arrays (tramba_amd.train.Adam keeps those of the parameters and of the state between
+    steps and rebuilds only the gradients'); the caller vouches for fp32, contiguous, same-size device tensors."""
+    _check(lib().tramba_adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, numel, n, float(lr), float(beta1), float(beta2),
+                                  float(eps), float(weight_decay), _stream()), "adam_step")
 
 
 def im2col3x3_cl(x, stride, pad, ckp):

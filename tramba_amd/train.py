@@ -45,8 +45,38 @@ def _resize_bilinear(o, size):
     return F.interpolate(o, size, mode="bilinear")
 
 
+class _SodLossHIP(torch.autograd.Function):
+    """The whole loss of train.py:76-85 in the library: three sums per image and output in one pass each (the resized logit
+    map is never stored), one finishing block, and in the backward one gather per output that lands on the output's own
+    resolution.  ~10 launches where the framework issued ~140."""
+
+    @staticmethod
+    def forward(ctx, label, weights, *outs):
+        loss, coefs = hip.sod_loss(outs, label, weights)
+        ctx.save_for_backward(label, coefs, *outs)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        label, coefs, *outs = ctx.saved_tensors
+        gl = gl.to(torch.float32).contiguous()
+        return (None, None) + tuple(hip.sod_loss_grad(o, label, coefs[i], gl) if ctx.needs_input_grad[2 + i] else None
+                                    for i, o in enumerate(outs))
+
+
+def _loss_on_device(outputs, label):
+    """the library's loss takes logit maps no larger than the label, plane for plane"""
+    return (label.is_cuda and label.dim() == 4 and 0 < len(outputs) <= 8 and label.shape[0] * label.shape[1] <= 512
+            and all(o.is_cuda and o.dim() == 4 and o.shape[:2] == label.shape[:2] and o.shape[-2] <= label.shape[-2]
+                    and o.shape[-1] <= label.shape[-1] for o in outputs))
+
+
 def tramba_loss(outputs, label, loss_weights=None):
     """Sum over the deep-supervision outputs (3 for Tramba-R, 4 otherwise) of BCE-with-logits + IoU."""
+    outputs = list(outputs)
+    if _loss_on_device(outputs, label):
+        weights = None if loss_weights is None else tuple(float(w) for w in loss_weights)
+        return _SodLossHIP.apply(label.float().contiguous(), weights, *[o.float().contiguous() for o in outputs])
     h, w = label.shape[-2:]
     total = None
     for i, o in enumerate(outputs):
@@ -60,16 +90,90 @@ def tramba_loss(outputs, label, loss_weights=None):
     return total
 
 
+class Adam(torch.optim.Adam):
+    """torch.optim.Adam -- constructor, param_groups, per-parameter state {step, exp_avg, exp_avg_sq} and state_dict as the
+    reference's optimizer (train.py:266-280) -- whose step() is the library's multi-tensor kernel (tramba_adam_step): one
+    read of the gradient and one read + write of p / exp_avg / exp_avg_sq at HBM speed (torch's `fused=True` form ran the
+    111 M parameters of Tramba-V at 2.7 TB/s in 27 launches), the bias corrections in fp64 as torch computes them.  The step
+    counters live on the device (what torch does for `capturable` / `fused`), so a step can be recorded into a hipGraph.
+    fp32 parameters on a HIP device only; amsgrad / maximize / differentiable are not implemented (the reference uses none)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, capturable=False):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable)
+        self._plans = {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans = {}          # the state tensors have been replaced
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._plans = {}
+
+    def _plan(self, gi, ps):
+        """pointer arrays of the parameters and their state for group gi: rebuilt when the set of parameters with a
+        gradient or an address changes (the state tensors only change through load_state_dict)"""
+        ptrs = [p.data_ptr() for p in ps]
+        plan = self._plans.get(gi)
+        if plan is not None and plan[0] == ptrs:
+            return plan
+        ms, vs, steps = [], [], []
+        for p in ps:
+            if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                raise hip.TrambaHipError("Adam: contiguous fp32 parameters on a HIP device only (no CPU fallback)")
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if not torch.is_tensor(st["step"]) or st["step"].device != p.device or st["step"].dtype != torch.float32:
+                st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).to(p.device).reshape(())   # a non-capturable checkpoint
+            for k in ("exp_avg", "exp_avg_sq"):
+                if st[k].dtype != torch.float32 or st[k].device != p.device or not st[k].is_contiguous() or st[k].numel() != p.numel():
+                    raise hip.TrambaHipError(f"Adam: state '{k}' does not match its parameter {tuple(p.shape)}")
+            ms.append(st["exp_avg"])
+            vs.append(st["exp_avg_sq"])
+            steps.append(st["step"])
+        import ctypes
+        n = len(ps)
+        plan = (ptrs, hip.pointer_array(ps), hip.pointer_array(ms), hip.pointer_array(vs), hip.pointer_array(steps),
+                (ctypes.c_int64 * n)(*[p.numel() for p in ps]), (ms, vs, steps))
+        self._plans[gi] = plan
+        return plan
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            if group.get("amsgrad") or group.get("maximize") or group.get("differentiable"):
+                raise hip.TrambaHipError("Adam: amsgrad / maximize / differentiable are not implemented")
+            ps = [p for p in group["params"] if p.grad is not None and p.numel() > 0]
+            if not ps:
+                continue
+            grads = [p.grad for p in ps]
+            for p, g in zip(ps, grads):
+                if g.dtype != torch.float32 or g.layout != torch.strided or not g.is_contiguous() or g.numel() != p.numel():
+                    raise hip.TrambaHipError("Adam: dense contiguous fp32 gradients only")
+            plan = self._plan(gi, ps)
+            b1, b2 = group["betas"]
+            hip.adam_step_raw(plan[1], hip.pointer_array(grads), plan[2], plan[3], plan[4], plan[5], len(ps), group["lr"], b1, b2,
+                              group["eps"], group["weight_decay"])
+        return loss
+
+
 def get_opt(lr, model, capturable=False):
-    """train.py:266-280: two Adam groups, encoder parameters at lr/10.  `capturable`: step counters on the device, so
-    that the whole step can be replayed as a hipGraph (tramba_amd.graph.GraphedTrainStep).  On the GPU the update runs as
-    torch's single-pass multi-tensor Adam (`fused=True`: the same arithmetic and state_dict as the reference's default
-    optimizer, one read and one write of p / exp_avg / exp_avg_sq instead of ten passes over the 446 MB of each)."""
+    """train.py:266-280: two Adam groups, encoder parameters at lr/10.  `capturable`: the whole step can be replayed as a
+    hipGraph (tramba_amd.graph.GraphedTrainStep).  On the GPU the update is the library's one-pass multi-tensor kernel
+    (`Adam` above: the same arithmetic and state_dict as the reference's default optimizer)."""
     base = [p for n, p in model.named_parameters() if "encoder" in n]
     other = [p for n, p in model.named_parameters() if "encoder" not in n]
-    fused = all(p.is_cuda and p.is_floating_point() for p in base + other) and len(base + other) > 0
-    return torch.optim.Adam([{"params": base, "lr": lr * 0.1}, {"params": other, "lr": lr}], lr, capturable=capturable,
-                            fused=True if fused else None)
+    groups = [{"params": base, "lr": lr * 0.1}, {"params": other, "lr": lr}]
+    if len(base + other) > 0 and all(p.is_cuda and p.dtype == torch.float32 for p in base + other):
+        return Adam(groups, lr, capturable=capturable)
+    return torch.optim.Adam(groups, lr, capturable=capturable)
 
 
 def adjust_learning_rate(optimizer, epoch, decay_epochs, base_lr, decay_factors):
