@@ -235,3 +235,34 @@ def test_deferred_sums_leave_the_training_step_unchanged(tramba_v_grad_oracle):
     bad = [n for n, p in m.named_parameters() if not torch.equal(p.grad, want[n])]
     assert not bad, (len(bad), bad[:8])
     m.compute_dtype = None
+
+
+@pytest.mark.parametrize("n,c,dtype", [(24, 64, torch.bfloat16), (48, 32, torch.bfloat16), (96, 16, torch.bfloat16),
+                                       (24, 32, torch.float32), (48, 16, torch.float16)])
+@pytest.mark.parametrize("which", ["both", "low", "high"])
+def test_dct_split_backward_against_the_oracle(n, c, dtype, which):
+    """DCT_2D.py:12-29 under autograd: gX = Wy^T [gLow 0; 0 gHigh] Wx.  bf16 takes the form of the training step (both
+    quadrants' first contractions in one map, ONE second contraction over the whole table, hi + lo coefficient pieces as the
+    two batches of a launch); a missing quadrant gradient and the other dtypes take the per-quadrant form."""
+    from tramba_amd.modules import _DCTSplitCL, _dct_filter
+    b = 2
+    w = _dct_filter(n)
+    x = synth.synth_input(f"dctb_{n}_{c}", (b, n, n, c))
+    gh = synth.synth_input(f"dctb_gh_{n}_{c}", (b, n // 2, n // 2, c))
+    gl = synth.synth_input(f"dctb_gl_{n}_{c}", (b, n // 2, n // 2, c))
+    x64 = x.to(dtype).double().permute(0, 3, 1, 2).requires_grad_()
+    high, low = oo.dct2d_split(x64, w.double(), w.double())
+    ghd, gld = gh.to(dtype).double().permute(0, 3, 1, 2), gl.to(dtype).double().permute(0, 3, 1, 2)
+    ((high * ghd).sum() * (which != "low") + (low * gld).sum() * (which != "high")).backward()
+    want = x64.grad.permute(0, 2, 3, 1)
+    xd = x.to(DEV, dtype).requires_grad_()
+    hi, lo = _DCTSplitCL.apply(xd, w.to(DEV), w.to(DEV))
+    loss = 0
+    if which != "low":
+        loss = loss + (hi.float() * gh.to(DEV, dtype).float()).sum()
+    if which != "high":
+        loss = loss + (lo.float() * gl.to(DEV, dtype).float()).sum()
+    loss.backward()
+    assert xd.grad.dtype == dtype and xd.grad.shape == x.shape
+    tol = {torch.float32: 2e-5, torch.float16: 2e-3, torch.bfloat16: 8e-3}[dtype]
+    assert _rel_l2(xd.grad, want) < tol, _rel_l2(xd.grad, want)

@@ -978,11 +978,12 @@ def tn_shared_cl(a, x):
     """out[g] = a^T @ x[g]: a (T, N) 16-bit shared by every group, x (G, T, K) same dtype -> (G, N, K) f32 -- a separable
     transform along a leading axis of a channels-last tensor (the DCT backward: T = coefficients, N = pixels)."""
     _dev(a, x)
-    t, n = a.shape
+    nb = a.shape[0] if a.dim() == 3 else 1        # a (P, T, N): out[g] = sum over p of a[p]^T @ x[g] (a table kept in pieces)
+    t, n = a.shape[-2:]
     g, t2, k = x.shape
     if t2 != t or a.dtype != x.dtype:
         raise TrambaHipError("tn_shared_cl: operand shapes / dtypes do not match")
-    out, _ = _wgrad(a, x, t, n, k, g, 1, 0, 0, n, 0, t * k, k, False)
+    out, _ = _wgrad(a, x, t, n, k, g, nb, t * n, 0, n, 0, t * k, k, False)
     return out if g > 1 else out.view(1, n, k)
 
 

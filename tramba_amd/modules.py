@@ -888,20 +888,21 @@ def _coef_split(w, lo):
         if len(_COEF_SPLIT) >= 64:       # (tables re-created over and over, e.g. models built in a loop: start again)
             _COEF_SPLIT.clear()
         h2 = w.shape[0] // 2
-        q = (w[:h2] if lo else w[h2:]).float().contiguous()
+        q = (w if lo is None else w[:h2] if lo else w[h2:]).float().contiguous()     # lo = None: the whole table
         if q.shape[1] % 8:
             q = F.pad(q, (0, 8 - q.shape[1] % 8))
-        ent = _COEF_SPLIT[key] = _split16(q)
+        hi, lo_ = _split16(q)
+        ent = _COEF_SPLIT[key] = (hi, lo_, torch.stack((hi, lo_)).contiguous())     # [2]: both pieces for ONE two-batch launch
     return ent
 
 
 def _tn_coef(split, n, x):
     """a^T @ x[g] for a split coefficient table a = hi + lo (T, N) and activations x (G, T, K): two passes of the 16-bit TN
-    kernel on bf16 data (the coefficients keep fp32 accuracy, the data is what it is); other dtypes are split the same way
+    kernel's contraction on bf16 data (the coefficients keep fp32 accuracy, the data is what it is); other dtypes are split the same way
     (a third pass)."""
-    ah, al = split
+    ah, al, both = split
     if x.dtype == torch.bfloat16:
-        out = hip.tn_shared_cl(ah, x) + hip.tn_shared_cl(al, x)
+        out = hip.tn_shared_cl(both, x)       # hi and lo as two "batches" over the same x: one launch, no add
     else:
         xh, xl = _split16(x.float())
         out = hip.tn_shared_cl(ah, xh) + hip.tn_shared_cl(al, xh) + hip.tn_shared_cl(ah, xl)
@@ -926,6 +927,16 @@ class _DCTSplitCL(torch.autograd.Function):
         wx, wy = ctx.saved_tensors
         n = wx.shape[0]
         h2 = n // 2
+        if ctx.xdtype == torch.bfloat16 and DCT_BWD_LOWP_INTERMEDIATE and g_high is not None and g_low is not None:
+            # both quadrants' first contractions land in the two halves of ONE (B, v, W*C) map: the second contraction then
+            # runs over all n rows of Wy at once (no sum of two full-size maps)
+            bsz, _, _, c = g_low.shape
+            z1 = torch.empty((bsz, n, n * c), dtype=torch.bfloat16, device=g_low.device)
+            for g, lo in ((g_low, True), (g_high, False)):
+                t = _tn_coef(_coef_split(wx, lo), n, g.contiguous().view(bsz * h2, h2, c))     # (B*V, W, C): contracted over u
+                (z1[:, :h2] if lo else z1[:, h2:]).copy_(t.reshape(bsz, h2, n * c))
+            gx = _tn_coef(_coef_split(wy, None), n, z1)                                        # (B, H, W*C): contracted over v
+            return gx.view(bsz, n, n, c).to(ctx.xdtype), None, None
         gx = None
         for g, lo in ((g_low, True), (g_high, False)):
             if g is None:
