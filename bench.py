@@ -37,7 +37,8 @@ Rank 0 prints ONE JSON line.  Objects on that line besides the contract's fields
                 `train.eager` / `train.graphed`); `train.scaling_value` = `train.value` (THE figure a data-parallel scaling
                 curve is about: the forward leg at N > 1 is independent replicas); `train.roofline` = the forward +
                 input-gradient GEMMs of the step against the dense MFMA peak, `train.roofline_wgrad` = the weight-gradient
-                GEMMs, `train.roofline_scan_bwd` = the fused scan backward (12 B per element), all launches
+                GEMMs, `train.roofline_scan_bwd` = the fused scan backward (12 B per element), `train.roofline_adam`
+                = the optimizer step against the HBM peak (28 B per parameter), all launches
                 and the Helix top-stage launch alone; each of the three carries `traffic` = PMC bytes per step of its kernel
                 family at batch 8 (`traffic_source`: profiles/<tag>_train_traffic.json, scripts/pmc_train.sh);
                 `train.step_ms_by_rank` = every rank's own time for the timed steps.  The leg runs under a watchdog
@@ -509,6 +510,29 @@ def bench_train(args, world, rank, dtype, sync_all, publish=None):
     hip.profile_enable(hip.PROF_SCAN_BWD, False)
     hip.profile_min_units(hip.PROF_SCAN_BWD, 0.0)
     tfw = flopw / (msw * 1e-3) / 1e12 if msw > 0 else 0.0
+    # the optimizer alone (tramba_adam_step: 28 B per parameter -- g read, p / exp_avg / exp_avg_sq read and written), HIP
+    # events on the launch stream around 10 steps on the gradients the last training step left
+    roof_adam = None
+    if isinstance(opt, train.Adam):
+        nupd = sum(p.numel() for g in opt.param_groups for p in g["params"] if p.grad is not None)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        opt.step()
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(10):
+            opt.step()
+        ev1.record()
+        torch.cuda.synchronize()
+        us_adam = ev0.elapsed_time(ev1) / 10 * 1e3
+        tr_a, src_a = train_traffic(("adam (",)) if b == 8 else (None, None)
+        gadam = 28.0 * nupd / (us_adam * 1e-6) / 1e9
+        roof_adam = {"bound": "hbm", "kernel": "adam_kernel (tramba_adam_step), every launch of one optimizer step",
+                     "achieved": round(gadam, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gadam / HBM_PEAK_GBS, 4),
+                     "traffic": tr_a, "traffic_source": src_a, "traffic_unit": "bytes per step, all launches of the family",
+                     "algorithmic_bytes_per_step": int(28 * nupd), "parameters": int(nupd),
+                     "us_per_step": round(us_adam, 1),
+                     "formula": "28 B per parameter (gradient read; p, exp_avg, exp_avg_sq read and written, fp32) / HIP-event "
+                                "time of 10 eager optimizer steps"}
     # PMC traffic of the families (bytes per STEP at batch 8, from the committed summary: only meaningful for this batch)
     tr_w, src_w = train_traffic(("wgrad",)) if b == 8 else (None, None)
     tr_sb, src_sb = train_traffic(("ss2d_scan_bwd",)) if b == 8 else (None, None)
@@ -560,7 +584,8 @@ def bench_train(args, world, rank, dtype, sync_all, publish=None):
                 "parallelism": f"dp{world}" + ((", RCCL all-reduce (ncclAvg)" if args.backend == "nccl" else ", gloo all-reduce")
                                                 + " of gradient buckets from autograd hooks" if world > 1 else ", no collective"),
                 "stochastic_depth": "on (0.6 enc / 0.2 dec)", "dtype": args.dtype + " activations, fp32 master weights",
-                "roofline": roof, "roofline_wgrad": roof_w, "roofline_scan_bwd": roof_sb, "eager": eager, "graphed": graphed,
+                "roofline": roof, "roofline_wgrad": roof_w, "roofline_scan_bwd": roof_sb, "roofline_adam": roof_adam, "eager": eager,
+                "graphed": graphed,
                 "step_ms_by_rank": dict(by_rank)}
 
     if world > 1 and (args.no_graph_dp or args.backend != "nccl"):

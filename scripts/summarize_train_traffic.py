@@ -49,6 +49,10 @@ for counter, d in (("FETCH_SIZE", "pmc_train_fetch"), ("WRITE_SIZE", "pmc_train_
             key = "layernorm forward / backward"
         elif "dwconv" in name:
             key = "depth-wise forward / backward / weight gradient"
+        elif "adam_kernel" in name or "adam_bump" in name:
+            key = "adam (optimizer step)"
+        elif "sod_loss" in name:
+            key = "sod_loss (deep-supervision loss forward + backward)"
         else:
             continue
         a = acc[key]

@@ -171,6 +171,28 @@ def test_reducer_single_process_semantics():
     assert model.decoder.weight.grad is not None and not red._armed
 
 
+@pytest.mark.parametrize("bucket_dtype", [None, torch.bfloat16])
+def test_bucket_views_start_on_16_byte_boundaries(bucket_dtype):
+    """the `.grad` views of a bucket are what the optimizer's kernel reads (its 16-byte path needs aligned tensors):
+    parameters of odd sizes are padded apart, the flags sit behind the padded payload, the reported bytes are the gradients'"""
+    from tramba_amd import parallel
+    model = nn.Sequential(nn.Linear(3, 5), nn.Linear(5, 7, bias=False), nn.Conv2d(1, 3, 3), nn.Linear(1, 1))
+    red = parallel.GradBucketReducer(model, bucket_mb=0.0001, bucket_dtype=bucket_dtype)
+    es = 4 if bucket_dtype is None else 2
+    seen = 0
+    for flat, bucket, views, flags in zip(red.flat, red.buckets, red._views, red._flags):
+        assert flat.data_ptr() % 16 == 0 and flags.numel() == len(bucket)
+        ends = []
+        for p, v in zip(bucket, views):
+            assert v.data_ptr() % 16 == 0 and v.shape == p.shape
+            ends.append((v.data_ptr() - flat.data_ptr()) // es + p.numel())
+            seen += p.numel()
+        assert (flags.data_ptr() - flat.data_ptr()) // es >= max(ends)          # no view overlaps the flags
+    assert seen == sum(p.numel() for p in model.parameters())
+    assert red.bytes_per_step() == seen * es
+    red.remove_hooks()
+
+
 def test_loss_matches_oracle_and_reference_known_answer(golden_meta):
     import synth
     from tramba_amd import train

@@ -76,14 +76,19 @@ class GradBucketReducer:
         self.flat, self._where, self._views, self._flags = [], {}, [], []
         for bi, bucket in enumerate(self.buckets):
             dtype = bucket[0].dtype if self.bucket_dtype is None else self.bucket_dtype
-            n = sum(p.numel() for p in bucket)
+            # every view starts on a 16-byte boundary (<= 12 bytes of zero padding per parameter): the `.grad` views are what
+            # the optimizer reads, and tramba_adam_step takes its 16-byte path only on aligned tensors
+            al = max(1, 16 // torch.empty((), dtype=dtype).element_size())
+            offs, n = [], 0
+            for p in bucket:
+                offs.append(n)
+                n += (p.numel() + al - 1) // al * al
             # the bucket's tail carries one "this rank produced a gradient" flag per parameter through the same collective
             flat = torch.zeros(n + len(bucket), dtype=dtype, device=bucket[0].device)
-            views, off = [], 0
-            for p in bucket:
+            views = []
+            for p, off in zip(bucket, offs):
                 self._where[p] = bi
                 views.append(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
             self.flat.append(flat)
             self._views.append(views)
             self._flags.append(flat[n:])
@@ -200,4 +205,4 @@ class GradBucketReducer:
 
     def bytes_per_step(self):
         """Bytes this rank hands to the collective per step (gradients; the per-parameter flags are ~3 KB)."""
-        return sum((f.numel() - len(b)) * f.element_size() for f, b in zip(self.flat, self.buckets))
+        return sum(sum(p.numel() for p in b) * f.element_size() for f, b in zip(self.flat, self.buckets))
