@@ -93,7 +93,7 @@ int tramba_tune_get(int knob);
                                         register-staged
                                         forms: 1 = 64x64, 2 = 128x128, 3 = 128x64, 4 = 96x64 where it saves a round of the chip,
                                         5 = 64x64 on a 4-stage ring; 13 / 14 = the LDS-DMA kernel on 2 stages everywhere / nowhere (default:
-                                        K <= 256 on grids of >= 1024 tiles).
+                                        K <= 256 on grids of >= 1024 tiles); 15 = 96x64 LDS-DMA tiles (3 compute waves + a loader wave) wherever M >= 96.
                                         weight-gradient TN GEMMs (tramba_wgrad_cl): 0 = token tiles staged by LDS-DMA on 3 stages, one
                                         workgroup per CU (the default); 8 = register-staged, one tile in flight; 9 = LDS-DMA on 4 stages;
                                         10 / 11 / 12 = 384 / 512 / 768 workgroups wanted by the token split */

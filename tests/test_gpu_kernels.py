@@ -231,6 +231,42 @@ def test_linear_cl_short_k_on_two_lds_stages(dtype, mnk):
         assert torch.equal(act, H.linear_cl(x, w, bias, None, 2)) and torch.equal(pre, H.linear_cl(x, w, bias, None, 0))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mnk", [(2304, 512, 1024), (2304, 2048, 512), (4608, 512, 2048), (2300, 520, 640), (100, 64, 576), (96, 72, 64),
+                                 (576, 1024, 2048)])
+def test_linear_cl_on_96_row_tiles(dtype, mnk):
+    """linear_dma96_kernel (96 x 64 tiles: 3 compute waves + a loader wave; a measurement form behind TRAMBA_TUNE_GEMM_TILE 15 --
+    it loses to the 64 x 64 form): fp64 on the same 16-bit inputs, ragged M / N and every K-loop tail
+    (K / 64 = 1, 8, 9, 10, 16, 32), and BIT-identical to the library's own form (the same products added in the same
+    order), for the plain and the dual-output launches."""
+    m, n, k = mnk
+    H = hip()
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) + torch.arange(k)[None, :] * 0.002).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dtype).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(m, n, generator=g).to(dtype).to(DEV)
+    want = F.gelu(x.double() @ w.double().T + bias.double()) + res.double()
+
+    def run():
+        out = [H.linear_cl(x, w, bias, res, 2), H.linear_cl(x, w, None, None, 0, out_dtype=torch.float32)]
+        if H.linear_dual_ok(x, w):
+            out += list(H.linear_dual_cl(x, w, bias, 2))
+        return out
+
+    own = run()
+    try:
+        H.tune_set(H.TUNE_GEMM_TILE, 15)
+        got96 = run()
+    finally:
+        H.tune_set(H.TUNE_GEMM_TILE, 0)
+    np.testing.assert_allclose(got96[0].cpu().double().numpy(), want.cpu().numpy(), rtol=2e-2,
+                               atol=2e-2 * max(1.0, float(want.abs().max())))
+    assert len(got96) == len(own) >= 2
+    for a, b in zip(got96, own):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("fam", ["raster", "helix", "window", "dilation"])
 @pytest.mark.parametrize("cfg", [(2, 12, 32, 2), (1, 24, 64, 4), (1, 16, 40, 3), (1, 48, 128, 8), (1, 12, 96, 40), (1, 24, 32, 64), (2, 96, 64, 8),

@@ -950,6 +950,149 @@ __global__ __launch_bounds__(256) void linear_dma_kernel(const T *__restrict__ x
 }
 #undef TRAMBA_DSR128_
 
+// The same staging on a 96 x 64 tile (r03) -- A MEASUREMENT FORM (TRAMBA_TUNE_GEMM_TILE 15), never the library's choice: 3 compute
+// waves of 32 rows x 64 columns each, the fourth wave only fetches and streams the epilogue (WaveLayout NWM = 3).  The idea: if
+// the K loop ran at the CU's L2 -> LDS fill rate (as the weight-gradient GEMM's does), what would count is bytes filled per
+// output row and K step -- 20 KB for 96 rows against 16 KB for 64 -- and the rounds of the chip: M = 2304 is 24 x 96, so the
+// 512-wide GEMMs of the 15-block stage make 192 workgroups = ONE round on 256 CUs where 64 x 64 tiles make 288 = two.
+// Measured (scripts/bench_gemm_tile96.py, profiles/r03h_gemm_tile96.txt): 17.6 against 13.2 us at M = 2304, N = 512, K = 2048,
+// slower on 17 of 21 shapes -- with one workgroup per CU and one wave per SIMD a K step is a serial chain (wait, barrier,
+// 12 LDS reads, 8 MFMAs) that nothing overlaps; the 64 x 64 form keeps 3 workgroups per CU in flight and they hide each other.
+//   * a stage = A 96 x 64 + B 64 x 64 16-bit = 20 KB = twenty 1 KB pieces (8 rows x 128 B); every wave fetches five: wave w the
+//     pieces 5w .. 5w + 4 (A pieces first, then B), so the vmcnt waits count in fives;
+//   * compute waves: 12 ds_read_b128 (A slice, two B slices per 16-deep k slice) and 8 MFMAs per K step.
+#define TRAMBA_DSR128I_(OUT, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(OUT) : "v"(ADDR), "i"(OFF) : "memory")
+
+template <typename T, typename TO, int NSTG, bool DUAL = false>
+__global__ __launch_bounds__(256) void linear_dma96_kernel(const T *__restrict__ x, const T *__restrict__ w,
+                                                          const float *__restrict__ bias, const T *__restrict__ res,
+                                                          TO *__restrict__ y, long M, int N, int K, int act,
+                                                          TO *__restrict__ y_pre = nullptr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // (vector-register asm in a kernel template: see ss2d_scan_dma_kernel)
+    constexpr int BM = 96, BN = 64;
+    constexpr int A_BYTES = BM * kBK * 2;                    // 12 KB
+    constexpr int TILE_BYTES = (BM + BN) * kBK * 2;          // 20 KB
+    constexpr int EPI_BYTES = BM * (BN + 4) * 4;
+    constexpr int LDS_BYTES = NSTG * TILE_BYTES > EPI_BYTES ? NSTG * TILE_BYTES : EPI_BYTES;
+    static_assert(NSTG == 2 || NSTG == 3, "stage offsets must fit the 16-bit offset field of ds_read");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    typedef __attribute__((address_space(3))) void lds_void;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hi = lane >> 5;
+    long m0;
+    int n0;
+    {   // XCD-aware tile order (see linear_tiled_kernel)
+        const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned q = nblk >> 3, r = nblk & 7, xcd = lin & 7, slot = lin >> 3;
+        const unsigned t = xcd * q + (xcd < r ? xcd : r) + slot;
+        m0 = (long)(t / gridDim.x) * BM;
+        n0 = (int)(t % gridDim.x) * BN;
+    }
+    const int nk = K / kBK;
+    const unsigned rowb = (unsigned)K * 2u;
+    const long mrows = M - m0 < BM ? M - m0 : BM;
+    const int nrows = N - n0 < BN ? N - n0 : BN;
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(x + m0 * K, (unsigned)mrows * rowb);
+    const __amdgpu_buffer_rsrc_t rsb = make_rsrc(w + (long)n0 * K, (unsigned)nrows * rowb);
+    // piece p = 5 wave + j: A rows 8p .. 8p + 7 for p < 12, B rows 8 (p - 12) .. after that
+    unsigned voff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int p = 5 * wave + j;
+        const int row = (p < 12 ? p : p - 12) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        voff[j] = (unsigned)row * rowb + (unsigned)c * 16u;
+    }
+    unsigned char *mine = lds + 5 * wave * 1024;             // my five pieces inside a stage (the B region follows A's 12 KB)
+    auto issue = [&](int kt, int stg) {
+        const unsigned so = (unsigned)kt * (kBK * 2);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (5 * wave + j < 12)                           // (wave-uniform)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_void *)(mine + stg * TILE_BYTES + j * 1024), 16, voff[j], so,
+                                                         0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_void *)(mine + stg * TILE_BYTES + j * 1024), 16, voff[j], so,
+                                                         0, 0);
+        }
+    };
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const bool computes = wave < 3;
+    unsigned aad[4], bad0[4], bad1[4];
+    {
+        const int ra_ = (computes ? wave : 0) * 32 + r32, rb0_ = r32, rb1_ = 32 + r32;
+        const unsigned a0 = lbase + (unsigned)(ra_ * 128 + ((hi ^ ((ra_ >> 1) & 7)) * 16));
+        const unsigned b0 = lbase + (unsigned)(A_BYTES + rb0_ * 128 + ((hi ^ ((rb0_ >> 1) & 7)) * 16));
+        const unsigned b1 = lbase + (unsigned)(A_BYTES + rb1_ * 128 + ((hi ^ ((rb1_ >> 1) & 7)) * 16));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            aad[kk] = a0 ^ (unsigned)(kk * 32);      // (rows are 128-byte aligned: the XOR stays inside the row)
+            bad0[kk] = b0 ^ (unsigned)(kk * 32);
+            bad1[kk] = b1 ^ (unsigned)(kk * 32);
+        }
+    }
+    acc16_t acc[1][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][1][r] = 0.f;
+
+    constexpr int DEPTH = NSTG - 1;                  // tiles in flight ahead of the one being multiplied
+#pragma unroll
+    for (int t = 0; t < DEPTH; ++t)
+        if (t < nk) issue(t, t);
+    auto kstep = [&](int kt, auto stg_c) {
+        constexpr int STG = decltype(stg_c)::value;
+        constexpr int S = STG * TILE_BYTES;
+        const int later = nk - 1 - kt;
+        if (later >= DEPTH - 1) {
+            if constexpr (DEPTH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (DEPTH 2: the last step)
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + DEPTH < nk) issue(kt + DEPTH, (STG + DEPTH) % NSTG);
+        if (computes) {
+            frag8_t a[4], b0[4], b1[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                TRAMBA_DSR128I_(a[kk], aad[kk], S);
+                TRAMBA_DSR128I_(b0[kk], bad0[kk], S);
+                TRAMBA_DSR128I_(b1[kk], bad1[kk], S);
+            }
+            asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(a[0]), "+v"(b0[0]), "+v"(b1[0]) : : "memory");
+            acc[0][0] = Mfma<T>::run(b0[0], a[0], acc[0][0]);
+            acc[0][1] = Mfma<T>::run(b1[0], a[0], acc[0][1]);
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[1]), "+v"(b0[1]), "+v"(b1[1]) : : "memory");
+            acc[0][0] = Mfma<T>::run(b0[1], a[1], acc[0][0]);
+            acc[0][1] = Mfma<T>::run(b1[1], a[1], acc[0][1]);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[2]), "+v"(b0[2]), "+v"(b1[2]) : : "memory");
+            acc[0][0] = Mfma<T>::run(b0[2], a[2], acc[0][0]);
+            acc[0][1] = Mfma<T>::run(b1[2], a[2], acc[0][1]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[3]), "+v"(b0[3]), "+v"(b1[3]) : : "memory");
+            acc[0][0] = Mfma<T>::run(b0[3], a[3], acc[0][0]);
+            acc[0][1] = Mfma<T>::run(b1[3], a[3], acc[0][1]);
+        }
+    };
+    int kt0 = 0;
+    for (; kt0 + NSTG <= nk; kt0 += NSTG) {
+        kstep(kt0, std::integral_constant<int, 0>{});
+        kstep(kt0 + 1, std::integral_constant<int, 1>{});
+        if constexpr (NSTG > 2) kstep(kt0 + 2, std::integral_constant<int, 2>{});
+    }
+    if (kt0 < nk) kstep(kt0, std::integral_constant<int, 0>{});
+    if constexpr (NSTG > 2) {
+        if (kt0 + 1 < nk) kstep(kt0 + 1, std::integral_constant<int, 1>{});
+    }
+    __syncthreads();                                       // every wave has read the last tile: the epilogue reuses the LDS
+    tile_epilogue<T, TO, BM, BN, 3>(acc, lds, bias, res, y, M, N, act, m0, n0, nullptr, nullptr, DUAL ? y_pre : nullptr);
+#endif
+}
+#undef TRAMBA_DSR128I_
+
 // Tile / staging choice: see launch_tiled.  tile96(): where a 96x64 tile (3 compute waves + 1 loader wave) lands at or
 // under a whole number of rounds of the 256 CUs and 64x64 tiles land just above it (M = 2304, N = 512: 288 -> 192
 // workgroups); a measurement form since r02 (tramba_tune_set(TRAMBA_TUNE_GEMM_TILE, 4)).
@@ -960,6 +1103,12 @@ static bool tile96(long m, int n, int k)
     // rounds of the chip: time ~ rounds x tile height
     const long r64 = (t64 + 255) / 256, r96 = (t96 + 255) / 256;
     return k >= 512 && t64 <= 1024 && r96 * 96 < r64 * 64;
+}
+
+// The 96 x 64 LDS-DMA tile (linear_dma96_kernel) is a measurement form: TRAMBA_TUNE_GEMM_TILE 15 runs it wherever it can.
+static bool tile96_dma(long m, int n, int k, int tile_tune)
+{
+    return tile_tune == 15 && m >= 96 && (m + 95) / 96 <= 65535;
 }
 
 // K up to which a grid of >= 1024 tiles runs linear_dma_kernel on 2 LDS stages (5 workgroups per CU instead of 3):
@@ -987,7 +1136,12 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
     //  there -- M = 576, N = 1024, K = 4096: 27 -> 22 us with operands that are not cache-resident; 8 stages = one block per
     //  CU by LDS, was measured slower on every shape and is not built)
     const bool dma_deep = tile_tune == 7 || (tile_tune == 0 && tiles64 <= 256 && k >= 1024);
-    if (!CONV && lean_ok && !x2 && (tile_tune == 0 || tile_tune == 6 || tile_tune == 7 || tile_tune == 13 || tile_tune == 14)) {
+    if (!CONV && lean_ok && !x2 && tile96_dma(m, n, k, tile_tune)) {
+        dim3 grid((n + 63) / 64, (unsigned)((m + 95) / 96)), block(256);
+        hipLaunchKernelGGL((linear_dma96_kernel<T, TO, 3>), grid, block, 0, s, (const T *)x, (const T *)w, bias, (const T *)res,
+                           (TO *)y, m, n, k, act);
+    } else if (!CONV && lean_ok && !x2 && (tile_tune == 0 || tile_tune == 6 || tile_tune == 7 || tile_tune == 13 || tile_tune == 14 ||
+                                           tile_tune == 15)) {
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
         // short K (<= 4 steps) on a grid of many tiles: the launch is prologue + epilogue, and what it needs is workgroups in
         // flight -- 2 stages = 32 KB of LDS = 5 per CU instead of 3 (TRAMBA_TUNE_GEMM_TILE 13 forces it, 14 forbids it)
@@ -1159,7 +1313,7 @@ extern "C" int tramba_linear_ln_cl(const void *x, const void *w_folded, const fl
     const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
     const int tile_tune = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE);
     const bool deep = tile_tune == 5;                    // 4-stage register ring: measurement only (see launch_tiled)
-    const bool dma = tile_tune == 0 || tile_tune == 6;   // the LDS-DMA staged kernel (default)
+    const bool dma = tile_tune == 0 || tile_tune == 6 || tile_tune == 15;   // the LDS-DMA staged kernel (default)
     dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
     const LnIn li{colsum, eps};
     const bool dma_short = dma && tile_tune == 0 && k <= DMA_SHORT_K && ((m + 63) / 64) * ((n + 63) / 64) >= 1024;   // (launch_tiled)
@@ -1275,18 +1429,23 @@ extern "C" int tramba_linear_dual_cl(const void *x, const void *w, const float *
     TRAMBA_CHECK(aligned16(x) && aligned16(w) && aligned16(y_pre) && aligned16(y_act), "linear_dual_cl: 16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(TRAMBA_PROF_GEMM, s, 2.0 * (double)m * n * k);
-    dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
+    const bool dma96 = tile96_dma(m, n, k, tramba_tune_get(TRAMBA_TUNE_GEMM_TILE));
+    dim3 grid((n + 63) / 64, (unsigned)(dma96 ? (m + 95) / 96 : (m + 63) / 64)), block(256);
     const bool dma_short = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE) == 0 && k <= DMA_SHORT_K &&
                            ((m + 63) / 64) * ((n + 63) / 64) >= 1024;   // (launch_tiled)
 #define DUAL_(T, S_)                                                                                                    \
     hipLaunchKernelGGL((linear_dma_kernel<T, T, S_, false, true>), grid, block, 0, s, (const T *)x, (const T *)w, bias,   \
                        (const T *)nullptr, (T *)y_act, m, n, k, act, LnIn{nullptr, 0.f}, (T *)y_pre)
+#define DUAL96_(T)                                                                                                      \
+    hipLaunchKernelGGL((linear_dma96_kernel<T, T, 3, true>), grid, block, 0, s, (const T *)x, (const T *)w, bias,         \
+                       (const T *)nullptr, (T *)y_act, m, n, k, act, (T *)y_pre)
     if (dtype == TRAMBA_BF16) {
-        if (dma_short) DUAL_(__hip_bfloat16, 2); else DUAL_(__hip_bfloat16, 3);
+        if (dma96) DUAL96_(__hip_bfloat16); else if (dma_short) DUAL_(__hip_bfloat16, 2); else DUAL_(__hip_bfloat16, 3);
     } else {
-        if (dma_short) DUAL_(__half, 2); else DUAL_(__half, 3);
+        if (dma96) DUAL96_(__half); else if (dma_short) DUAL_(__half, 2); else DUAL_(__half, 3);
     }
 #undef DUAL_
+#undef DUAL96_
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
