@@ -276,6 +276,13 @@ int tramba_rowdot_bwd_cl(const void *x, const float *gy, const float *w, void *g
  * into one 7x7 (and b3 + b5 + b7), so y = GELU(h + dw3(h) + dw5(h) + dw7(h)) is ONE dwconv pass. */
 int tramba_dw_pack(const float *w, const float *bias, const float *w3, const float *b3, const float *w5,
                    const float *b5, float *wt, float *bt, int c, int ks, void *stream);
+/* `count` such packs in ceil(count / 40) launches (every depth-wise stencil of a model after an optimizer step): item i packs
+ * w[i] (+ bias[i], and w3 / b3 / w5 / b5[i] for the folded multi-scale form; NULL entries as in tramba_dw_pack) into
+ * wt[i] / bt[i].  All ten arguments are HOST arrays (device pointers, channel counts, kernel sizes); the items travel to the
+ * kernel by value (hipGraph-capture safe). */
+int tramba_dw_pack_multi(const float *const *w, const float *const *bias, const float *const *w3, const float *const *b3,
+                         const float *const *w5, const float *const *b5, float *const *wt, float *const *bt, const int *c,
+                         const int *ks, int count, void *stream);
 /* Training path of the dense 3x3 convolutions of the VMamba stem / downsample layers (vmamba.py:454,481,486; the reference
  * gets their autograd from cuDNN through nn.Conv2d): the data movement around the library's GEMMs.
  *   im2col: x (B,H,W,C) dtype -> cols (B*Ho*Wo, CKp) dtype, column (ky*3 + kx)*C + ci (the k-major order of
@@ -303,6 +310,10 @@ int tramba_dwconv_dual_cl(const void *x, const float *wt, const float *bt, void 
  * (nb, C) or NULL = nb copies of the bias row. */
 int tramba_dw_unpack_grad(const float *gwt, float *g7, float *g5, float *g3, float *gb, int nb, int c, int ks,
                           void *stream);
+/* `count` such unpacks in ceil(count / 64) launches (the depth-wise parameter gradients of a whole backward pass: they are
+ * leaves, nothing reads them before the optimizer); HOST arrays, items by value as in tramba_dw_pack_multi. */
+int tramba_dw_unpack_grad_multi(const float *const *gwt, float *const *g7, float *const *g5, float *const *g3,
+                                float *const *gb, const int *nb, const int *c, const int *ks, int count, void *stream);
 /* Training: gradients of the same stencil w.r.t. its tap-major weights and bias (what autograd computes for
  * nn.Conv2d(groups=C), vmamba.py:301, 595-603).  part (P, ks*ks + 1, C) f32, P = tramba_dwconv_wgrad_parts(batch, h, wd,
  * ks): one partial row per workgroup (image, row band, column range), planes 0..ks*ks-1 = taps, last plane = bias; the

@@ -266,3 +266,91 @@ def test_dct_split_backward_against_the_oracle(n, c, dtype, which):
     assert xd.grad.dtype == dtype and xd.grad.shape == x.shape
     tol = {torch.float32: 2e-5, torch.float16: 2e-3, torch.bfloat16: 8e-3}[dtype]
     assert _rel_l2(xd.grad, want) < tol, _rel_l2(xd.grad, want)
+
+
+def test_depthwise_packs_and_gradient_unpacks_in_one_launch():
+    """tramba_dw_pack_multi / tramba_dw_unpack_grad_multi (every stencil of a model after the optimizer step; every depth-wise
+    parameter gradient of a backward pass at the flush of hip.deferred_sums()) against one tramba_dw_pack / tramba_dw_unpack_grad
+    per item: bit-identical, for plain 3x3 / 5x5 / 7x7 stencils with and without bias, the folded multi-scale form, and more
+    items than one launch carries; a deferred unpack may read the output of a deferred sum."""
+    from tramba_amd import hip
+    g = torch.Generator().manual_seed(5)
+    items, want, kinds = [], [], []
+    for i in range(45):
+        c = [64, 256, 72, 512][i % 4]
+        if i % 3 == 0:
+            srcs = (torch.randn(c, 1, 7, 7, generator=g), torch.randn(c, generator=g), torch.randn(c, 1, 3, 3, generator=g),
+                    torch.randn(c, generator=g), torch.randn(c, 1, 5, 5, generator=g), torch.randn(c, generator=g))
+            ks = 7
+        else:
+            ks = [3, 5, 7][i % 3]
+            srcs = (torch.randn(c, 1, ks, ks, generator=g), torch.randn(c, generator=g) if i % 2 else None, None, None, None, None)
+        srcs = tuple(None if t is None else t.to(DEV) for t in srcs)
+        wt0, bt0 = hip.dw_pack(*srcs)
+        items.append(srcs + (torch.full_like(wt0, float("nan")), torch.full_like(bt0, float("nan"))))
+        want.append((wt0, bt0))
+        kinds.append((c, ks, srcs[2] is not None))
+    hip.dw_pack_multi(items)
+    for it, (a, b) in zip(items, want):
+        assert torch.equal(it[6], a) and torch.equal(it[7], b)
+    with pytest.raises(hip.TrambaHipError):
+        hip.dw_pack_multi([items[0][:6] + (items[1][6], items[0][7])])          # an output of another stencil's shape
+    parts = [torch.randn(5, ks * ks + 1, c, generator=g).to(DEV) for c, ks, _ in kinds]
+    ref = [hip.dw_unpack_grad(hip.slab_sum(p), ks, ms, 3 if ms else 1) for p, (c, ks, ms) in zip(parts, kinds)]
+    hip._sumq.poison = True
+    try:
+        with hip.deferred_sums():
+            got = [hip.dw_unpack_grad(hip.slab_sum(p, defer=True), ks, ms, 3 if ms else 1, defer=True)
+                   for p, (c, ks, ms) in zip(parts, kinds)]
+            assert hip.pending_sums() == 2 * len(parts)
+            assert all(bool(torch.isnan(o[0]).all()) for o in got)                  # recorded, not run
+        assert hip.pending_sums() == 0
+    finally:
+        hip._sumq.poison = False
+    for a, b in zip(got, ref):
+        for u, v in zip(a, b):
+            assert (u is None and v is None) or torch.equal(u, v)
+
+
+def test_standing_depthwise_packs_follow_the_weights():
+    """The packed stencils of the training path are rebuilt once per step, after the optimizer (modules.refresh_dw_packs), and
+    a forward takes them only while the parameters' version counters say they are current: after an eager step, after a
+    hipGraph replay (which bumps the counters itself), and NOT after a change of the weights behind the step's back."""
+    import tramba_amd as ta
+    from tramba_amd import hip, train
+    from tramba_amd import modules as M
+    torch.manual_seed(3)
+    m = ta.bulid_model(use_pretrain=False, img_size=64).to(DEV).train()
+    m.compute_dtype = torch.bfloat16
+    x = torch.randn(2, 3, 64, 64, device=DEV)
+    y = (torch.rand(2, 1, 64, 64, device=DEV) > 0.6).float()
+
+    def check_current():
+        srcs = M._dw_pack_sources(m)
+        assert len(srcs) >= 10
+        for gsrc in srcs:
+            wt, bt = M._dw_packed(*gsrc)
+            assert wt is M._dw_pack_store[gsrc[0].data_ptr()][0]                    # the standing pack, no launch
+            f = hip.dw_pack(*[None if t is None else t.detach() for t in gsrc])
+            assert torch.equal(wt, f[0]) and torch.equal(bt, f[1])
+        return srcs
+
+    opt = train.get_opt(1e-3, m)
+    v0 = [p._version for p in m.parameters()]
+    before = [p.detach().clone() for p in m.parameters()]
+    train.train_step(m, opt, x, y)
+    assert all(p._version > v for p, v in zip(m.parameters(), v0) if p.grad is not None)   # the optimizer kernel bumps them
+    assert any(not torch.equal(p, b) for p, b in zip(m.parameters(), before))
+    srcs = check_current()
+    train.train_step(m, opt, x, y)
+    check_current()
+    with torch.no_grad():
+        srcs[0][0].mul_(1.5)                                                         # behind the step's back
+    wt, bt = M._dw_packed(*srcs[0])
+    assert wt is not M._dw_pack_store[srcs[0][0].data_ptr()][0]
+    f = hip.dw_pack(*[None if t is None else t.detach() for t in srcs[0]])
+    assert torch.equal(wt, f[0]) and torch.equal(bt, f[1])
+    step = ta.GraphedTrainStep(m, train.get_opt(1e-3, m, capturable=True))
+    for _ in range(3):
+        step(x, y)
+        check_current()

@@ -610,13 +610,11 @@ static int launch_rowdot(const void *x, const float *w, float bias, float *y, lo
 // (the reference's (C,1,ks,ks) layout would make each lane walk its own 49-float row).
 // dw_pack_kernel builds that layout once per weight version; for the multi-scale MLP it also folds
 // identity + 3x3 + 5x5 + 7x7 (and the three biases) into ONE 7x7 stencil.
-__global__ __launch_bounds__(256) void dw_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias,
-                                                     const float *__restrict__ w3, const float *__restrict__ b3,
-                                                     const float *__restrict__ w5, const float *__restrict__ b5,
-                                                     float *__restrict__ wt, float *__restrict__ bt, int C, int ks,
-                                                     int multiscale)
+__device__ __forceinline__ void dw_pack_body(const float *__restrict__ w, const float *__restrict__ bias,
+                                             const float *__restrict__ w3, const float *__restrict__ b3,
+                                             const float *__restrict__ w5, const float *__restrict__ b5,
+                                             float *__restrict__ wt, float *__restrict__ bt, int C, int ks, int multiscale, int c)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const int R = ks / 2;
     for (int dy = 0; dy < ks; ++dy)
@@ -633,6 +631,33 @@ __global__ __launch_bounds__(256) void dw_pack_kernel(const float *__restrict__ 
     float bv = bias ? bias[c] : 0.f;
     if (multiscale) bv += b3[c] + b5[c];
     bt[c] = bv;
+}
+
+__global__ __launch_bounds__(256) void dw_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                                     const float *__restrict__ w3, const float *__restrict__ b3,
+                                                     const float *__restrict__ w5, const float *__restrict__ b5,
+                                                     float *__restrict__ wt, float *__restrict__ bt, int C, int ks,
+                                                     int multiscale)
+{
+    dw_pack_body(w, bias, w3, b3, w5, b5, wt, bt, C, ks, multiscale, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// every depth-wise stencil of a model in one launch (after the optimizer step: the packs the NEXT forward reads); the
+// items travel by value (blockIdx.y = item)
+constexpr int kDwMulti = 40;
+struct DwPackItem {
+    const float *w, *bias, *w3, *b3, *w5, *b5;
+    float *wt, *bt;
+    int c, ks, ms, pad;
+};
+struct DwPackArgs {
+    DwPackItem it[kDwMulti];
+};
+static_assert(sizeof(DwPackArgs) <= 4096, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(256) void dw_pack_multi_kernel(DwPackArgs a)
+{
+    const DwPackItem it = a.it[blockIdx.y];
+    dw_pack_body(it.w, it.bias, it.w3, it.b3, it.w5, it.b5, it.wt, it.bt, it.c, it.ks, it.ms, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // thread = V channels x TW consecutive output columns of one row.
@@ -1210,6 +1235,31 @@ extern "C" int tramba_dw_pack(const float *w, const float *bias, const float *w3
     hipLaunchKernelGGL(dw_pack_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, bias, w3, b3, w5, b5,
                        wt, bt, c, ks, ms);
     TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_dw_pack_multi(const float *const *w, const float *const *bias, const float *const *w3,
+                                    const float *const *b3, const float *const *w5, const float *const *b5, float *const *wt,
+                                    float *const *bt, const int *c, const int *ks, int count, void *stream)
+{
+    TRAMBA_CHECK(w && bias && w3 && b3 && w5 && b5 && wt && bt && c && ks && count > 0, "dw_pack_multi: empty input");
+    for (int base = 0; base < count; base += kDwMulti) {
+        DwPackArgs a;
+        const int n = count - base < kDwMulti ? count - base : kDwMulti;
+        int cmax = 0;
+        for (int i = 0; i < kDwMulti; ++i) {
+            const int j = base + (i < n ? i : 0);        // (unused slots repeat the first item; their blocks are never launched)
+            TRAMBA_CHECK(w[j] && wt[j] && bt[j] && c[j] > 0, "dw_pack_multi: item %d: null tensor", j);
+            TRAMBA_CHECK(ks[j] == 3 || ks[j] == 5 || ks[j] == 7, "dw_pack_multi: item %d: kernel size %d unsupported (3,5,7)", j, ks[j]);
+            const int ms = (w3[j] || w5[j]) ? 1 : 0;
+            TRAMBA_CHECK(!ms || (ks[j] == 7 && w3[j] && b3[j] && w5[j] && b5[j] && bias[j]),
+                         "dw_pack_multi: item %d: multi-scale needs ks=7 and all six tensors", j);
+            a.it[i] = DwPackItem{w[j], bias[j], w3[j], b3[j], w5[j], b5[j], wt[j], bt[j], c[j], ks[j], ms, 0};
+            if (i < n && c[j] > cmax) cmax = c[j];
+        }
+        hipLaunchKernelGGL(dw_pack_multi_kernel, dim3((cmax + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, a);
+        TRAMBA_LAUNCH_CHECK();
+    }
     return TRAMBA_OK;
 }
 

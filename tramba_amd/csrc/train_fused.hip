@@ -278,11 +278,9 @@ __global__ __launch_bounds__(256) void ss2d_bwd_assemble_kernel(const float *__r
 // gwt (ks*ks + 1, C) f32 = tap-major weight gradient + bias row (tramba_dwconv_wgrad_cl + tramba_slab_sum).
 // single stencil:  g7 (C, ks*ks) = transpose of the taps;  gb7 (C) = bias row
 // multi-scale (ks = 7, g5 / g3 given): the folded stencil's gradient restricted to each parameter's support
-__global__ __launch_bounds__(256) void dw_unpack_grad_kernel(const float *__restrict__ gwt, float *__restrict__ g7,
-                                                            float *__restrict__ g5, float *__restrict__ g3,
-                                                            float *__restrict__ gb, int nb, int C, int ks)
+__device__ __forceinline__ void dw_unpack_body(const float *__restrict__ gwt, float *__restrict__ g7, float *__restrict__ g5,
+                                               float *__restrict__ g3, float *__restrict__ gb, int nb, int C, int ks, int c)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     for (int dy = 0; dy < ks; ++dy)
         for (int dx = 0; dx < ks; ++dx) {
@@ -296,6 +294,31 @@ __global__ __launch_bounds__(256) void dw_unpack_grad_kernel(const float *__rest
         }
     if (gb)   // nb copies of the bias gradient: the folded stencil's bias is the SUM of the three parameters' biases
         for (int q = 0; q < nb; ++q) gb[(long)q * C + c] = gwt[(long)ks * ks * C + c];
+}
+
+__global__ __launch_bounds__(256) void dw_unpack_grad_kernel(const float *__restrict__ gwt, float *__restrict__ g7,
+                                                            float *__restrict__ g5, float *__restrict__ g3,
+                                                            float *__restrict__ gb, int nb, int C, int ks)
+{
+    dw_unpack_body(gwt, g7, g5, g3, gb, nb, C, ks, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// the unpacks of a whole backward pass in one launch (the gradients are leaves: nothing reads them before the optimizer);
+// items by value, blockIdx.y = item
+constexpr int kDwUnpackMulti = 64;
+struct DwUnpackItem {
+    const float *gwt;
+    float *g7, *g5, *g3, *gb;
+    int nb, c, ks, pad;
+};
+struct DwUnpackArgs {
+    DwUnpackItem it[kDwUnpackMulti];
+};
+static_assert(sizeof(DwUnpackArgs) <= 4096, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(256) void dw_unpack_multi_kernel(DwUnpackArgs a)
+{
+    const DwUnpackItem it = a.it[blockIdx.y];
+    dw_unpack_body(it.gwt, it.g7, it.g5, it.g3, it.gb, it.nb, it.c, it.ks, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 
@@ -431,6 +454,29 @@ extern "C" int tramba_dw_unpack_grad(const float *gwt, float *g7, float *g5, flo
     hipLaunchKernelGGL(dw_unpack_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gwt, g7, g5, g3, gb,
                        nb, c, ks);
     TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+extern "C" int tramba_dw_unpack_grad_multi(const float *const *gwt, float *const *g7, float *const *g5, float *const *g3,
+                                           float *const *gb, const int *nb, const int *c, const int *ks, int count, void *stream)
+{
+    TRAMBA_CHECK(gwt && g7 && g5 && g3 && gb && nb && c && ks && count > 0, "dw_unpack_grad_multi: empty input");
+    for (int base = 0; base < count; base += kDwUnpackMulti) {
+        DwUnpackArgs a;
+        const int n = count - base < kDwUnpackMulti ? count - base : kDwUnpackMulti;
+        int cmax = 0;
+        for (int i = 0; i < kDwUnpackMulti; ++i) {
+            const int j = base + (i < n ? i : 0);
+            TRAMBA_CHECK(gwt[j] && g7[j] && c[j] > 0, "dw_unpack_grad_multi: item %d: null tensor", j);
+            TRAMBA_CHECK(ks[j] == 3 || ks[j] == 5 || ks[j] == 7, "dw_unpack_grad_multi: item %d: kernel size %d unsupported", j, ks[j]);
+            TRAMBA_CHECK((g5[j] == nullptr) == (g3[j] == nullptr) && (!g5[j] || ks[j] == 7),
+                         "dw_unpack_grad_multi: item %d: multi-scale needs ks = 7, g5 and g3", j);
+            a.it[i] = DwUnpackItem{gwt[j], g7[j], g5[j], g3[j], gb[j], nb[j], c[j], ks[j], 0};
+            if (i < n && c[j] > cmax) cmax = c[j];
+        }
+        hipLaunchKernelGGL(dw_unpack_multi_kernel, dim3((cmax + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, a);
+        TRAMBA_LAUNCH_CHECK();
+    }
     return TRAMBA_OK;
 }
 

@@ -99,7 +99,7 @@ class GraphedTrainStep:
         return saved, [(b, b.detach().clone()) for b in self.model.buffers()]     # buffers: BatchNorm running statistics
 
     def _restore(self, snapshot):
-        from .modules import refresh_lowp_shadows
+        from .modules import refresh_dw_packs, refresh_lowp_shadows
         saved, buffers = snapshot
         with torch.no_grad():
             for b, value in buffers:
@@ -113,6 +113,8 @@ class GraphedTrainStep:
                         else:
                             v.zero_()                    # state created by the warm-up: back to "never stepped"
         refresh_lowp_shadows(self.model, getattr(self.model, "compute_dtype", None))
+        if any(p.is_cuda for p in self.model.parameters()):
+            refresh_dw_packs(self.model)
 
     def _touched(self):
         """Every tensor a replay rewrites in place behind autograd's back: parameters, optimizer state, buffers."""

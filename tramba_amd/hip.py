@@ -70,6 +70,8 @@ SIGNATURES = {
     "tramba_dwconv_cl": (c_int, [c_vp] * 4 + [c_int] * 7 + [c_vp]),
     "tramba_dwconv_dual_cl": (c_int, [c_vp] * 5 + [c_int] * 8 + [c_vp]),
     "tramba_dw_unpack_grad": (c_int, [c_vp] * 5 + [c_int] * 3 + [c_vp]),
+    "tramba_dw_pack_multi": (c_int, [c_vp] * 10 + [c_int, c_vp]),
+    "tramba_dw_unpack_grad_multi": (c_int, [c_vp] * 8 + [c_int, c_vp]),
     "tramba_im2col3x3_cl": (c_int, [c_vp] * 2 + [c_int] * 8 + [c_vp]),
     "tramba_upsample_bilinear_bwd": (c_int, [c_vp] * 2 + [c_int] * 5 + [c_vp]),
     "tramba_col2im3x3_cl": (c_int, [c_vp] * 2 + [c_int] * 8 + [c_vp]),
@@ -672,6 +674,41 @@ def dw_pack(w, bias=None, w3=None, b3=None, w5=None, b5=None):
     return wt, bt
 
 
+def dw_pack_multi_check(items):
+    for it in items:
+        _dev(*it)
+        if any(t is not None and t.dtype != torch.float32 for t in it):
+            raise TrambaHipError("dw_pack_multi: fp32 tensors only")
+        c, ks = it[0].shape[0], it[0].shape[-1]
+        if tuple(it[6].shape) != (ks * ks, c) or it[7].numel() != c:
+            raise TrambaHipError("dw_pack_multi: output shapes do not match the weights")
+
+
+def dw_pack_multi(items):
+    """items: [(w, bias, w3, b3, w5, b5, wt, bt)] -- `dw_pack` of every item into its (preallocated) wt (ks*ks, C) / bt (C) f32,
+    all in one launch per 40 items (tramba_dw_pack_multi); fp32 device tensors, None where dw_pack takes none."""
+    if len(items) == 0:
+        return
+    dw_pack_multi_check(items)
+    dw_pack_multi_run(dw_pack_multi_prepare(items, _checked=True))
+
+
+def dw_pack_multi_prepare(items, _checked=False):
+    """the host arrays of one dw_pack_multi call, built once for a fixed set of tensors (`dw_pack_multi_run` launches them)"""
+    if not _checked:
+        dw_pack_multi_check(items)
+    n = len(items)
+    cols = [(ctypes.c_void_p * n)(*[_ptr(it[k]) for it in items]) for k in range(8)]
+    cs = (ctypes.c_int * n)(*[it[0].shape[0] for it in items])
+    kss = (ctypes.c_int * n)(*[it[0].shape[-1] for it in items])
+    return (cols, cs, kss, n, tuple(items))        # (the tensors stay referenced)
+
+
+def dw_pack_multi_run(prepared):
+    cols, cs, kss, n, _ = prepared
+    _check(lib().tramba_dw_pack_multi(*cols, cs, kss, n, _stream()), "dw_pack_multi")
+
+
 def dwconv_cl(x, wt, bt, act=ACT_NONE):
     """x: (B, H, W, C); wt: (ks*ks, C) f32 tap-major, bt: (C) f32 (see dw_pack)."""
     _dev(x, wt, bt)
@@ -700,14 +737,30 @@ def dwconv_dual_cl(x, wt, bt, act=ACT_NONE, want_pre=True, flip=False):
     return pre, y
 
 
-def dw_unpack_grad(gwt, ks, multiscale=False, nbias=0):
-    """gwt (ks*ks + 1, C) f32 tap-major taps + bias row -> (g7 (C,1,ks,ks), g5, g3 (multi-scale fold, else None), gb (nbias, C))"""
+def dw_unpack_grad(gwt, ks, multiscale=False, nbias=0, defer=False):
+    """gwt (ks*ks + 1, C) f32 tap-major taps + bias row -> (g7 (C,1,ks,ks), g5, g3 (multi-scale fold, else None), gb (nbias, C)).
+    defer: inside `deferred_sums()` the unpack is recorded and runs at `flush_sums()`, after the recorded sums (gwt may be
+    the output of one), all unpacks of the pass in one launch -- for results that go straight to autograd as leaf gradients."""
     _dev(gwt)
     c = gwt.shape[1]
     g7 = torch.empty((c, 1, ks, ks), dtype=torch.float32, device=gwt.device)
     g5 = torch.empty((c, 1, 5, 5), dtype=torch.float32, device=gwt.device) if multiscale else None
     g3 = torch.empty((c, 1, 3, 3), dtype=torch.float32, device=gwt.device) if multiscale else None
     gb = torch.empty((nbias, c), dtype=torch.float32, device=gwt.device) if nbias else None
+    if defer and _sumq.enabled:
+        if gwt.dtype != torch.float32 or tuple(gwt.shape) != (ks * ks + 1, c):
+            raise TrambaHipError("dw_unpack_grad: gradient table of another shape")
+        if _sumq.poison:
+            for t in (g7, g5, g3, gb):
+                if t is not None:
+                    t.fill_(float("nan"))
+        with _sumq.lock:
+            _sumq.unpacks.append((_ptr(gwt), _ptr(g7), _ptr(g5), _ptr(g3), _ptr(gb), int(nbias), int(c), int(ks), _stream(),
+                                  (gwt, g7, g5, g3, gb)))
+        # VIEWS go out, the queue keeps the bases: autograd hands a leaf the incoming gradient as it is (no copy) only when
+        # nobody else references that tensor object -- a copy would read the buffer before the flush has filled it
+        # (tests/test_gpu_grad.py NaN-fills deferred outputs to catch exactly that)
+        return tuple(None if t is None else t.view(t.shape) for t in (g7, g5, g3, gb))
     _check(lib().tramba_dw_unpack_grad(_ptr(gwt), _ptr(g7), _ptr(g5), _ptr(g3), _ptr(gb), nbias, c, ks, _stream()),
            "dw_unpack_grad")
     return g7, g5, g3, gb
@@ -844,8 +897,9 @@ def dwconv_wgrad_cl(x, gy, ks):
     return s[:ks * ks], s[ks * ks]
 
 
-def dwconv_wgrad_table(x, gy, ks):
-    """the same as one (ks*ks + 1, C) f32 table (taps, then the bias row): the input of dw_unpack_grad"""
+def dwconv_wgrad_table(x, gy, ks, defer=False):
+    """the same as one (ks*ks + 1, C) f32 table (taps, then the bias row): the input of dw_unpack_grad (defer: the slab sum is
+    recorded inside `deferred_sums()` -- only for a table that nothing but a deferred unpack reads)"""
     _dev(x, gy)
     bb, h, wd, c = x.shape
     if gy.shape != x.shape or gy.dtype != x.dtype:
@@ -853,7 +907,7 @@ def dwconv_wgrad_table(x, gy, ks):
     part = torch.empty((lib().tramba_dwconv_wgrad_parts(bb, h, wd, ks), ks * ks + 1, c), dtype=torch.float32, device=x.device)
     _check(lib().tramba_dwconv_wgrad_cl(_ptr(x), _ptr(gy), _ptr(part), bb, h, wd, c, ks, dt(x), _stream()),
            "dwconv_wgrad_cl")
-    return slab_sum(part)
+    return slab_sum(part, defer=defer)
 
 
 def dct_split_cl(x, wx, wy):
@@ -1038,6 +1092,7 @@ class _SumQueue:
         self.enabled = False
         self.poison = False         # tests: NaN-fill a deferred output, so that a premature reader cannot go unnoticed
         self.items = []
+        self.unpacks = []           # depth-wise gradient unpacks (tramba_dw_unpack_grad_multi), run after the sums
         self.lock = threading.Lock()
 
 
@@ -1068,8 +1123,7 @@ def flush_sums():
     """Run every recorded reduction (one tramba_multi_sum call per stream they were recorded on)."""
     with _sumq.lock:
         items, _sumq.items = _sumq.items, []
-    if not items:
-        return
+        unpacks, _sumq.unpacks = _sumq.unpacks, []
     by_stream = {}
     for it in items:
         by_stream.setdefault(it[4], []).append(it)
@@ -1080,10 +1134,18 @@ def flush_sums():
         ns = (ctypes.c_int64 * cnt)(*[it[2] for it in its])
         nsl = (ctypes.c_int * cnt)(*[it[3] for it in its])
         _check(lib().tramba_multi_sum(parts, outs, ns, nsl, cnt, stream), "multi_sum")
+    by_stream = {}
+    for it in unpacks:          # (a table and its unpack are recorded on the same stream: the sums above come first)
+        by_stream.setdefault(it[8], []).append(it)
+    for stream, its in by_stream.items():
+        cnt = len(its)
+        cols = [(ctypes.c_void_p * cnt)(*[it[k] for it in its]) for k in range(5)]
+        ints = [(ctypes.c_int * cnt)(*[it[k] for it in its]) for k in (5, 6, 7)]
+        _check(lib().tramba_dw_unpack_grad_multi(*cols, *ints, cnt, stream), "dw_unpack_grad_multi")
 
 
 def pending_sums():
-    return len(_sumq.items)
+    return len(_sumq.items) + len(_sumq.unpacks)
 
 
 def slab_sum(part, defer=False):

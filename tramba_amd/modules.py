@@ -423,6 +423,7 @@ def restamp_lowp_shadows(model):
             ent = _lowp_shadow.get(id(p))
             if ent is not None and ent[2]() is p:
                 ent[1] = p._version
+    restamp_dw_packs(model)
 
 
 def _lowp(p, dtype):
@@ -1242,6 +1243,90 @@ def _add_ln(v, norm, act=hip.ACT_NONE):
     return _AddLayerNormCL.apply(v, None, None, norm.weight, norm.bias, norm.eps, act, True)
 
 
+# Packed depth-wise stencils of the TRAINING path.  The weights change once per step, at the optimizer: instead of one small
+# pack launch per stencil inside every forward (39 per step on Tramba-V, ~7 us each: a thread per channel walking 49 strided
+# taps), `refresh_dw_packs(model)` repacks all of them in ONE launch right after the optimizer step (train.train_step), into
+# buffers that live as long as the model; a forward finds its pack here when the sources' version counters still match.
+_dw_pack_store = {}       # data_ptr of the main weight -> [wt, bt, versions of the six sources, weakref to the main weight]
+_dw_plans = None          # model -> (signature, prepared launch, sources); weak keys, and not in the model's __dict__ (the
+                          # prepared launch holds ctypes pointer arrays, which copy.deepcopy(model) could not copy)
+
+
+def _dw_versions(srcs):
+    return tuple(-1 if t is None else t._version for t in srcs)
+
+
+def _dw_packed(w, b, w3=None, b3=None, w5=None, b5=None):
+    """(wt, bt) of hip.dw_pack for these parameters: the model's standing pack when it is current, a fresh one otherwise"""
+    ent = _dw_pack_store.get(w.data_ptr())
+    if ent is not None and ent[2] == _dw_versions((w, b, w3, b3, w5, b5)):
+        p = ent[3]()
+        if p is not None and p.data_ptr() == w.data_ptr() and p.shape == w.shape:
+            return ent[0], ent[1]
+    return hip.dw_pack(*[None if t is None else t.detach() for t in (w, b, w3, b3, w5, b5)])
+
+
+def _dw_pack_sources(model):
+    """the parameter groups (w, b, w3, b3, w5, b5) of every depth-wise stencil the fused training path packs"""
+    out, folded = [], set()
+    for m in model.modules():
+        if isinstance(m, DWMSMlp):
+            c3, c5, c7 = m.dwc3.dw_conv, m.dwc5.dw_conv, m.dwc7.dw_conv
+            if all(c.bias is not None for c in (c3, c5, c7)):
+                out.append((c7.weight, c7.bias, c3.weight, c3.bias, c5.weight, c5.bias))
+                folded.update(id(c) for c in (c3, c5, c7))
+    for m in model.modules():
+        if isinstance(m, SS2D) and getattr(m, "with_dconv", False):
+            out.append((m.conv2d.weight, m.conv2d.bias, None, None, None, None))
+    return [g for g in out if all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in g)]
+
+
+@torch.no_grad()
+def refresh_dw_packs(model):
+    """Repack every depth-wise stencil of `model` (one launch) and declare the packs current.  Call after the optimizer step."""
+    import weakref
+    global _dw_plans
+    if _dw_plans is None:
+        _dw_plans = weakref.WeakKeyDictionary()
+    plan = _dw_plans.get(model)
+    srcs = plan[2] if plan is not None else _dw_pack_sources(model)
+    if not srcs:
+        return 0
+    sig = tuple(g[0].data_ptr() for g in srcs)
+    if plan is None or plan[0] != sig:
+        srcs = _dw_pack_sources(model)
+        sig = tuple(g[0].data_ptr() for g in srcs)
+        for key in [k for k, ent in _dw_pack_store.items() if ent[3]() is None]:      # models that no longer exist
+            del _dw_pack_store[key]
+        items = []
+        for g in srcs:
+            w = g[0]
+            c, ks = w.shape[0], w.shape[-1]
+            ent = _dw_pack_store.get(w.data_ptr())
+            if ent is None or ent[3]() is not w or tuple(ent[0].shape) != (ks * ks, c) or ent[0].device != w.device:
+                ent = [torch.empty((ks * ks, c), dtype=torch.float32, device=w.device),
+                       torch.empty((c,), dtype=torch.float32, device=w.device), None, weakref.ref(w)]
+                _dw_pack_store[w.data_ptr()] = ent
+            items.append(tuple(None if t is None else t.detach() for t in g) + (ent[0], ent[1]))
+        plan = (sig, hip.dw_pack_multi_prepare(items), srcs)
+        _dw_plans[model] = plan
+    hip.dw_pack_multi_run(plan[1])
+    restamp_dw_packs(model)
+    return len(srcs)
+
+
+def restamp_dw_packs(model):
+    """Declare the standing packs of `model` current (after a hipGraph replay that repacked them itself and a version bump of
+    the parameters: tramba_amd.graph.GraphedTrainStep)."""
+    plan = None if _dw_plans is None else _dw_plans.get(model)
+    if plan is None:
+        return
+    for g in plan[2]:
+        ent = _dw_pack_store.get(g[0].data_ptr())
+        if ent is not None and ent[3]() is g[0]:
+            ent[2] = _dw_versions(g)
+
+
 class _DwConvActCL(torch.autograd.Function):
     """(z, act(z)) with z = depth-wise conv(x) + bias from one launch (tramba_dwconv_dual_cl): SS2D's conv2d + SiLU
     (vmamba.py:283-285) on the training path.  z carries the gradient; act(z) is handed to the consumer, which owns the
@@ -1251,7 +1336,7 @@ class _DwConvActCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, act):
         x = x.contiguous()
-        wt, bt = hip.dw_pack(w.detach(), None if b is None else b.detach())
+        wt, bt = _dw_packed(w, b)
         z, a = hip.dwconv_dual_cl(x, wt, bt, act)
         ctx.save_for_backward(x, wt)
         ctx.ks, ctx.has_bias, ctx.wdtype = w.shape[-1], b is not None, w.dtype
@@ -1272,7 +1357,9 @@ class _DwConvActCL(torch.autograd.Function):
             gx = hip.dwconv_dual_cl(gz, wt, _zeros_const((wt.shape[1],), torch.float32, wt.device), hip.ACT_NONE,
                                     want_pre=False, flip=True)[1]
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            g7, _, _, gbs = hip.dw_unpack_grad(hip.dwconv_wgrad_table(x, gz, ctx.ks), ctx.ks, False, 1 if ctx.has_bias else 0)
+            defer = ctx.wdtype == torch.float32      # (leaf gradients, handed on as they are: nothing reads them before the optimizer)
+            g7, _, _, gbs = hip.dw_unpack_grad(hip.dwconv_wgrad_table(x, gz, ctx.ks, defer=defer), ctx.ks, False,
+                                               1 if ctx.has_bias else 0, defer=defer)
             gw = g7.to(ctx.wdtype)
             gb = gbs[0] if ctx.has_bias else None
         return gx, gw, gb, None
@@ -1285,7 +1372,7 @@ class _DwmsActCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w3, b3, w5, b5, w7, b7):
         h = h.contiguous()
-        wt, bt = hip.dw_pack(w7.detach(), b7.detach(), w3.detach(), b3.detach(), w5.detach(), b5.detach())
+        wt, bt = _dw_packed(w7, b7, w3, b3, w5, b5)
         g, a = hip.dwconv_dual_cl(h, wt, bt, hip.ACT_GELU)
         ctx.save_for_backward(h, wt)
         ctx.wdtype = w7.dtype
@@ -1305,7 +1392,8 @@ class _DwmsActCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gh = hip.dwconv_dual_cl(gg, wt, _zeros_const((wt.shape[1],), torch.float32, wt.device), hip.ACT_NONE,
                                     want_pre=False, flip=True)[1]
-        g7, g5, g3, gbs = hip.dw_unpack_grad(hip.dwconv_wgrad_table(h, gg, 7), 7, True, 3)
+        defer = ctx.wdtype == torch.float32
+        g7, g5, g3, gbs = hip.dw_unpack_grad(hip.dwconv_wgrad_table(h, gg, 7, defer=defer), 7, True, 3, defer=defer)
         t = ctx.wdtype
         return gh, g3.to(t), gbs[0], g5.to(t), gbs[1], g7.to(t), gbs[2]
 

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import hip
-from .modules import refresh_lowp_shadows
+from .modules import refresh_dw_packs, refresh_lowp_shadows
 
 
 def iou_loss(pred, mask):
@@ -161,6 +161,9 @@ class Adam(torch.optim.Adam):
             b1, b2 = group["betas"]
             hip.adam_step_raw(plan[1], hip.pointer_array(grads), plan[2], plan[3], plan[4], plan[5], len(ps), group["lr"], b1, b2,
                               group["eps"], group["weight_decay"])
+            # the kernel writes through raw pointers: bump the version counters as an in-place torch op would (every
+            # derived-weight cache of the inference path is keyed on them)
+            torch.autograd.graph.increment_version(ps)
         return loss
 
 
@@ -207,6 +210,8 @@ def train_step(model, opt, images, label, reducer=None):
         reducer.finish()
     opt.step()
     refresh_lowp_shadows(model, getattr(model, "compute_dtype", None))   # next forward's bf16 weights: one fused cast
+    if images.is_cuda:
+        refresh_dw_packs(model)                                          # ... and its packed depth-wise stencils: one launch
     return loss.detach()
 
 
