@@ -384,9 +384,14 @@ int tramba_shadow_cast_multi(const void *table, int ntensors, int64_t total_tile
 /* out[i] = sum over s < nslab of part[s*n + i], i < n, summed in slab order (deterministic): the per-workgroup partial sums
  * of the LayerNorm / depth-wise / scan parameter gradients.  n % 4 == 0, 16-byte aligned. */
 int tramba_slab_sum(const float *part, float *out, int64_t n, int nslab, void *stream);
-/* `count` such sums in ceil(count / 32) launches: outs[i][j] = sum over s < nslab[i] of parts[i][s*n[i] + j], the same
+/* `count` such sums in ceil(count / 64) launches: outs[i][j] = sum over s < nslab[i] of parts[i][s*n[i] + j], the same
  * summation order as tramba_slab_sum / the slab sums of tramba_wgrad_cl.  parts / outs / n / nslab are HOST arrays of device
- * pointers and sizes (they travel to the kernel by value: nothing is copied to the device, hipGraph-capture safe). */
+ * pointers and sizes (they travel to the kernel by value: nothing is copied to the device, hipGraph-capture safe).
+ * _strided: slab s of table i starts stride[i] floats after slab s - 1 (>= n[i], a multiple of 4; NULL = dense) -- a row range
+ * of a wider table summed straight into its place in another layout (the x_proj weight gradient leaves the GEMM in the scan
+ * kernels' padded layout and lands in the parameter's own, vmamba.py:236: no concatenation kernel). */
+int tramba_multi_sum_strided(const float *const *parts, float *const *outs, const int64_t *n, const int64_t *stride,
+                             const int *nslab, int count, void *stream);
 int tramba_multi_sum(const float *const *parts, float *const *outs, const int64_t *n, const int *nslab, int count,
                      void *stream);
 

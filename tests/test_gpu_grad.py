@@ -181,11 +181,11 @@ def test_helix_scan_at_the_benchmarked_launch():
 
 
 @pytest.mark.parametrize("tables", [[(3, 1024)], [(9, 33024), (144, 33024), (40, 256), (1, 4096)],
-                                    [(6, 1050624), (32, 8), (31, 2052), (200, 12288)] + [(5, 512)] * 40])
+                                    [(6, 1050624), (32, 8), (31, 2052), (200, 12288)] + [(5, 512)] * 70])
 def test_batched_partial_sums_equal_the_single_ones(tables):
     """tramba_multi_sum (the deferred partial-sum reductions of a training step, hip._SumQueue) against one
     tramba_slab_sum per table: bit-identical -- same bodies, same summation order -- for few and many slabs, more than
-    32 tables (several launches), sizes that are not multiples of a workgroup's share."""
+    64 tables (several launches), sizes that are not multiples of a workgroup's share."""
     from tramba_amd import hip
     g = torch.Generator().manual_seed(len(tables))
     parts = [torch.randn(s, n, generator=g).to(DEV) for s, n in tables]
@@ -209,6 +209,23 @@ def test_batched_partial_sums_equal_the_single_ones(tables):
     with hip.deferred_sums():
         gw1, gb1 = hip.wgrad_cl(gy, x, True, defer=True)
     assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1)
+    # row ranges of a gradient summed from the slabs straight into another row order (the x_proj weight: padded -> parameter layout)
+    for mm, nn, kk in ((4608, 48, 512), (73728, 96, 128), (300, 24, 64)):
+        segs = [s_ for q in range(nn // 12) for s_ in ((12 * q, 6), (12 * q + 8, 2))]
+        xr = torch.randn(mm, kk, generator=g).to(DEV, torch.bfloat16)
+        gr = torch.randn(mm, nn, generator=g).to(DEV, torch.bfloat16)
+        full = hip.wgrad_cl(gr, xr)[0]
+        want_rows = torch.cat([full[a:a + c] for a, c in segs])
+        assert torch.equal(hip.wgrad_rows_cl(gr, xr, segs), want_rows)
+        hip._sumq.poison = True
+        try:
+            with hip.deferred_sums():
+                rows = hip.wgrad_rows_cl(gr, xr, segs, defer=True)
+        finally:
+            hip._sumq.poison = False
+        assert rows.shape == want_rows.shape and torch.equal(rows, want_rows)
+    with pytest.raises(hip.TrambaHipError):
+        hip.wgrad_rows_cl(gr, xr, [(20, 8)])                                   # rows 20..27 of a 24-row gradient
 
 
 def test_deferred_sums_leave_the_training_step_unchanged(tramba_v_grad_oracle):

@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradArgs a)
 // out[i] = sum over slabs s of part[s][i], i < n (fixed order); 4 floats per thread, EIGHT slab rows requested before
 // the first is added (r03: four were not enough to cover the memory latency -- 29 MB in 18.6 us = 1.6 TB/s on the widest
 // layers of a training step, as much as the TN kernel in front of it).  `blk`: index of the 1024-float block.
-__device__ __forceinline__ void slab_sum_body(const float *__restrict__ part, float *__restrict__ out, long n, int nslab, long blk)
+__device__ __forceinline__ void slab_sum_body(const float *__restrict__ part, float *__restrict__ out, long n, int nslab, long blk,
+                                              long stride)   // stride: floats between consecutive slabs (= n for a dense table)
 {
     const long i4 = (blk * 256 + threadIdx.x) * 4;
     if (i4 >= n) return;
@@ -449,7 +450,7 @@ __device__ __forceinline__ void slab_sum_body(const float *__restrict__ part, fl
         for (; s + 8 <= nslab; s += 8) {
             float4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(p + (long)(s + j) * n);
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(p + (long)(s + j) * stride);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
@@ -460,7 +461,7 @@ __device__ __forceinline__ void slab_sum_body(const float *__restrict__ part, fl
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const int sj = s + j < nslab ? s + j : nslab - 1;
-                v[j] = *reinterpret_cast<const float4 *>(p + (long)sj * n);
+                v[j] = *reinterpret_cast<const float4 *>(p + (long)sj * stride);
             }
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
@@ -473,7 +474,7 @@ __device__ __forceinline__ void slab_sum_body(const float *__restrict__ part, fl
     } else {
         for (long i = i4; i < n; ++i) {
             float sacc = 0.f;
-            for (int s = 0; s < nslab; ++s) sacc += part[(long)s * n + i];
+            for (int s = 0; s < nslab; ++s) sacc += part[(long)s * stride + i];
             out[i] = sacc;
         }
     }
@@ -482,7 +483,7 @@ __device__ __forceinline__ void slab_sum_body(const float *__restrict__ part, fl
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__ part, float *__restrict__ out, long n,
                                                       int nslab)
 {
-    slab_sum_body(part + (long)blockIdx.y * nslab * n, out + (long)blockIdx.y * n, n, nslab, blockIdx.x);
+    slab_sum_body(part + (long)blockIdx.y * nslab * n, out + (long)blockIdx.y * n, n, nslab, blockIdx.x, n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const T *__restrict__ x,
 // slab) and spreads the slabs over 32 row lanes, eight loads in flight per thread; the row lanes are folded through LDS in a
 // fixed order.  ~200 launches per training step of Tramba-V: about half the time of a general-purpose reduction each.
 __device__ __forceinline__ void col_sum_body(const float *__restrict__ part, float *__restrict__ out, long n, int nslab,
-                                             long blk, float4 (*red)[8])
+                                             long blk, float4 (*red)[8], long stride)
 {
     const int q = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const long i4 = (blk * 8 + q) * 4;
@@ -576,14 +577,14 @@ __device__ __forceinline__ void col_sum_body(const float *__restrict__ part, flo
         for (; s + 7 * 32 < nslab; s += 8 * 32) {
             float4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(p + (long)(s + 32 * j) * n);
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(p + (long)(s + 32 * j) * stride);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
             }
         }
         for (; s < nslab; s += 32) {
-            const float4 v = *reinterpret_cast<const float4 *>(p + (long)s * n);
+            const float4 v = *reinterpret_cast<const float4 *>(p + (long)s * stride);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ 
                                                      int nslab)
 {
     __shared__ float4 red[32][8];
-    col_sum_body(part, out, n, nslab, blockIdx.x, red);
+    col_sum_body(part, out, n, nslab, blockIdx.x, red, n);
 }
 
 // Up to kMultiSum partial-sum tables reduced by ONE launch (r03: the deferred sums of a training step -- the slab sums
@@ -613,15 +614,18 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ 
 // hipGraph-capture safe); a workgroup finds its table by its block index; tables of >= 32 slabs take the row-lane form
 // (32 floats per workgroup), the others the slab-order form (1024 floats per workgroup) -- the same bodies, hence the same
 // summation order, as the single-table launches.
-constexpr int kMultiSum = 32;
+constexpr int kMultiSum = 64;
 struct MultiSumArgs {
     const float *part[kMultiSum];
     float *out[kMultiSum];
     long n[kMultiSum];
+    long stride[kMultiSum];     // floats between consecutive slabs: n for a dense table, more for a row range of a wider one
     int nslab[kMultiSum];
     int first[kMultiSum + 1];   // first workgroup of every table (ascending), first[count] = grid size
     int count;
 };
+
+static_assert(sizeof(MultiSumArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
 __global__ __launch_bounds__(256) void multi_sum_kernel(MultiSumArgs a)
 {
@@ -632,8 +636,8 @@ __global__ __launch_bounds__(256) void multi_sum_kernel(MultiSumArgs a)
     for (int i = 1; i < a.count; ++i)
         if (a.first[i] <= blk) t = i;          // (block-uniform; first[] is ascending)
     const long local = blk - a.first[t];
-    if (a.nslab[t] >= 32) col_sum_body(a.part[t], a.out[t], a.n[t], a.nslab[t], local, red);
-    else slab_sum_body(a.part[t], a.out[t], a.n[t], a.nslab[t], local);
+    if (a.nslab[t] >= 32) col_sum_body(a.part[t], a.out[t], a.n[t], a.nslab[t], local, red, a.stride[t]);
+    else slab_sum_body(a.part[t], a.out[t], a.n[t], a.nslab[t], local, a.stride[t]);
 }
 
 // ---- multi-tensor cast (+ transpose) of fp32 matrices: table[t] = {src, dst, dst_t, rows, cols, first_tile, dst_ld,
@@ -870,8 +874,8 @@ extern "C" int tramba_slab_sum(const float *part, float *out, int64_t n, int nsl
     return TRAMBA_OK;
 }
 
-extern "C" int tramba_multi_sum(const float *const *parts, float *const *outs, const int64_t *n, const int *nslab, int count,
-                                void *stream)
+extern "C" int tramba_multi_sum_strided(const float *const *parts, float *const *outs, const int64_t *n, const int64_t *stride,
+                                        const int *nslab, int count, void *stream)
 {
     TRAMBA_CHECK(parts && outs && n && nslab && count > 0, "multi_sum: empty input");
     hipStream_t s = (hipStream_t)stream;
@@ -883,9 +887,11 @@ extern "C" int tramba_multi_sum(const float *const *parts, float *const *outs, c
             const int j = base + i;
             TRAMBA_CHECK(parts[j] && outs[j] && n[j] > 0 && nslab[j] > 0 && n[j] % 4 == 0 && aligned16(parts[j]) && aligned16(outs[j]),
                          "multi_sum: table %d must hold whole, 16-byte aligned float4 rows", j);
+            TRAMBA_CHECK(!stride || (stride[j] >= n[j] && stride[j] % 4 == 0), "multi_sum: table %d: slab stride %ld under the row length or not a multiple of 4", j, (long)(stride ? stride[j] : 0));
             a.part[i] = parts[j];
             a.out[i] = outs[j];
             a.n[i] = n[j];
+            a.stride[i] = stride ? stride[j] : n[j];
             a.nslab[i] = nslab[j];
             a.first[i] = (int)blocks;
             blocks += nslab[j] >= 32 ? (n[j] / 4 + 7) / 8 : (n[j] + 1023) / 1024;
@@ -893,10 +899,16 @@ extern "C" int tramba_multi_sum(const float *const *parts, float *const *outs, c
         }
         for (int i = a.count; i <= kMultiSum; ++i) a.first[i] = (int)blocks;
         for (int i = a.count; i < kMultiSum; ++i) {
-            a.part[i] = nullptr; a.out[i] = nullptr; a.n[i] = 0; a.nslab[i] = 0;
+            a.part[i] = nullptr; a.out[i] = nullptr; a.n[i] = 0; a.stride[i] = 0; a.nslab[i] = 0;
         }
         hipLaunchKernelGGL(multi_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
         TRAMBA_LAUNCH_CHECK();
     }
     return TRAMBA_OK;
+}
+
+extern "C" int tramba_multi_sum(const float *const *parts, float *const *outs, const int64_t *n, const int *nslab, int count,
+                                void *stream)
+{
+    return tramba_multi_sum_strided(parts, outs, n, nullptr, nslab, count, stream);
 }

@@ -89,6 +89,7 @@ SIGNATURES = {
     "tramba_shadow_cast_multi": (c_int, [c_vp, c_int, c_i64, c_int, c_vp]),
     "tramba_slab_sum": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     "tramba_multi_sum": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "tramba_multi_sum_strided": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "tramba_wgrad_parts_cl": (c_int, [c_vp] * 4 + [ctypes.c_size_t, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_int, c_i64,
                                                    c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     "tramba_expand_norm_head_cl": (c_int, [c_vp] * 5 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
@@ -1017,14 +1018,50 @@ def wgrad_cl(gy, x, want_bias=False, defer=False):
     return _wgrad(gy2, x2, m, n, k, 1, 1, 0, 0, gy2.stride(0), 0, 0, x2.stride(0), want_bias, defer)
 
 
-def wgrad_grouped_cl(gy, x):
-    """gy (B, G, L, N), x (B, G, L, K) 16-bit contiguous -> (G, N, K) f32: per group g, sum over b and l of gy^T x."""
+def wgrad_rows_cl(gy, x, segments, defer=False):
+    """Rows of the weight gradient gy^T x (gy (M, N), x (M, K) 16-bit) in another row order: segments = [(first row, rows)],
+    the result holds those row ranges one after the other ((sum of rows, K) f32).  Inside `deferred_sums()` (defer=True) every
+    range is summed from the GEMM's partial slabs straight into its place at `flush_sums()` -- no full-size sum, no
+    concatenation; otherwise the ranges are cut out of the finished gradient."""
+    _dev(gy, x)
+    m, n = gy.shape
+    k = x.shape[-1]
+    if x.shape[0] != m or gy.dtype != x.dtype:
+        raise TrambaHipError("wgrad_rows_cl: gy / x mismatch")
+    if any(a < 0 or c <= 0 or a + c > n for a, c in segments):
+        raise TrambaHipError("wgrad_rows_cl: a row range outside the gradient")
+    total = sum(c for _, c in segments)
+    if defer and _sumq.enabled:
+        ws_bytes = lib().tramba_wgrad_workspace(m, n, k, 1, 1)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=gy.device)
+        full = torch.empty((1, n * k + n), dtype=torch.float32, device=gy.device)
+        nslab = ctypes.c_int(0)
+        _check(lib().tramba_wgrad_parts_cl(_ptr(gy), _ptr(x), _ptr(full), _ptr(ws), ws_bytes, m, n, k, 1, 1, 0, 0, n, 0, 0, k, 0,
+                                           dt(gy), _stream(), ctypes.byref(nslab)), "wgrad_parts_cl")
+        if nslab.value > 0:
+            out = torch.empty((total, k), dtype=torch.float32, device=gy.device)
+            if _sumq.poison:
+                out.fill_(float("nan"))
+            row = 0
+            for a, c in segments:
+                _enqueue_sum(_ptr(ws) + a * k * 4, _ptr(out) + row * k * 4, c * k, nslab.value, (ws, out), stride=n * k + n)
+                row += c
+            return out.view(total, k)       # (a view goes out, the queue keeps the base: see dw_unpack_grad)
+        gw = full[0, :n * k].view(n, k)     # a single slab: the gradient is already there
+    else:
+        gw = wgrad_cl(gy, x)[0]
+    return torch.cat([gw[a:a + c] for a, c in segments], dim=0)
+
+
+def wgrad_grouped_cl(gy, x, defer=False):
+    """gy (B, G, L, N), x (B, G, L, K) 16-bit contiguous -> (G, N, K) f32: per group g, sum over b and l of gy^T x.
+    defer: see wgrad_cl (inside `deferred_sums()` the slab sums are recorded; for results handed to autograd as they are)."""
     _dev(gy, x)
     b, g, l, n = gy.shape
     k = x.shape[-1]
     if x.shape[:3] != gy.shape[:3] or gy.dtype != x.dtype:
         raise TrambaHipError("wgrad_grouped_cl: gy / x mismatch")
-    out, _ = _wgrad(gy, x, l, n, k, g, b, g * l * n, l * n, n, g * l * k, l * k, k, False)
+    out, _ = _wgrad(gy, x, l, n, k, g, b, g * l * n, l * n, n, g * l * k, l * k, k, False, defer)
     return out
 
 
@@ -1054,9 +1091,20 @@ def _wgrad(gy, x, m, n, k, groups, nbatch, gy_bs, gy_gs, gy_ld, x_bs, x_gs, x_ld
                                            gy_gs, gy_ld, x_bs, x_gs, x_ld, int(want_bias), dt(gy), _stream(),
                                            ctypes.byref(nslab)), "wgrad_parts_cl")
         if nslab.value > 0:          # (0: a single slab, already in `out`)
+            slab = n * k + n
+            if groups > 1 and not want_bias:
+                # per-group gradients without the bias slot between them: summed into a DENSE (groups, N, K) tensor -- a leaf
+                # takes an incoming gradient as it is only when its strides are the parameter's own (a copy would read the
+                # buffer before the flush has filled it)
+                dense = torch.empty((groups, n, k), dtype=torch.float32, device=gy.device)
+                if _sumq.poison:
+                    dense.fill_(float("nan"))
+                for g in range(groups):
+                    _enqueue_sum(_ptr(ws) + g * nslab.value * slab * 4, _ptr(dense) + g * n * k * 4, n * k, nslab.value,
+                                 (ws, dense), stride=slab)
+                return dense.view(groups, n, k), None
             if _sumq.poison:
                 out.fill_(float("nan"))
-            slab = n * k + n
             for g in range(groups):
                 _enqueue_sum(_ptr(ws) + g * nslab.value * slab * 4, _ptr(out) + g * slab * 4, slab, nslab.value, (ws, out))
     else:
@@ -1114,9 +1162,9 @@ class deferred_sums:
         return False
 
 
-def _enqueue_sum(part_ptr, out_ptr, n, nslab, keep):
+def _enqueue_sum(part_ptr, out_ptr, n, nslab, keep, stride=None):
     with _sumq.lock:
-        _sumq.items.append((part_ptr, out_ptr, int(n), int(nslab), _stream(), keep))
+        _sumq.items.append((part_ptr, out_ptr, int(n), int(nslab), _stream(), keep, int(n if stride is None else stride)))
 
 
 def flush_sums():
@@ -1133,7 +1181,8 @@ def flush_sums():
         outs = (ctypes.c_void_p * cnt)(*[it[1] for it in its])
         ns = (ctypes.c_int64 * cnt)(*[it[2] for it in its])
         nsl = (ctypes.c_int * cnt)(*[it[3] for it in its])
-        _check(lib().tramba_multi_sum(parts, outs, ns, nsl, cnt, stream), "multi_sum")
+        strides = (ctypes.c_int64 * cnt)(*[it[6] for it in its])
+        _check(lib().tramba_multi_sum_strided(parts, outs, ns, strides, nsl, cnt, stream), "multi_sum")
     by_stream = {}
     for it in unpacks:          # (a table and its unpack are recorded on the same stream: the sums above come first)
         by_stream.setdefault(it[8], []).append(it)

@@ -1465,7 +1465,9 @@ class _SS2DInnerCL(torch.autograd.Function):
         #   d(dt_projs_weight)[k] = sum_{b,l} graw^T ranks   (TN, tramba_wgrad_cl with groups = K, batches = B)
         #   d(ranks)              = graw @ dt_w[k]           (tramba_rows_gemm_cl into the first R floats of every gseq row)
         if xs.dtype != torch.float32:
-            g_dtw = hip.wgrad_grouped_cl(graw, ranks)                                              # (K, D, R8)
+            # (K, D, R8); a leaf's gradient, handed on as it is when no columns are cut and no cast follows: its slab sums
+            # join the step's batched ones
+            g_dtw = hip.wgrad_grouped_cl(graw, ranks, defer=ranks.shape[-1] == r and dtwdtype == torch.float32)
             dtw_t = ctx.dtw_t            # (K, R, D): the shadow written after the optimizer step, when current
             if dtw_t is None:
                 dtw_t = torch.empty((k, r, d), dtype=cd, device=xs.device).copy_(dtw.transpose(1, 2))   # transpose + cast
@@ -1489,9 +1491,16 @@ class _SS2DInnerCL(torch.autograd.Function):
             gz = hip.ss2d_merge_grad_cl(gu, order, t, z)                                   # (merge(gu) + t) * silu'(z)
         gxw = None
         if ctx.needs_input_grad[2]:
-            gp_ = _wgrad(g_xd, xs.view(b * l, d))[0].view(k, rg, d)
-            gxw = torch.cat((gp_[:, :r], gp_[:, r8:r8 + 2]), dim=1).to(xwdtype)
-        gp = hip.slab_sum(gpar)                                                            # (3,K,D): contiguous planes
+            if xs.dtype != torch.float32:
+                # the GEMM's rows are in the scan kernels' padded layout (K x RG rows: R ranks, pad, B, C, pad); the parameter
+                # keeps (K, R + 2, D): its row ranges are summed from the partial slabs straight into place
+                segs = [s_ for g in range(k) for s_ in ((g * rg, r), (g * rg + r8, 2))]
+                gxw = hip.wgrad_rows_cl(g_xd, xs.view(b * l, d), segs, defer=xwdtype == torch.float32).view(k, r + 2, d)
+                gxw = gxw.to(xwdtype)
+            else:
+                gp_ = _wgrad(g_xd, xs.view(b * l, d))[0].view(k, rg, d)
+                gxw = torch.cat((gp_[:, :r], gp_[:, r8:r8 + 2]), dim=1).to(xwdtype)
+        gp = hip.slab_sum(gpar, defer=True)                                                # (3,K,D): contiguous planes, leaf gradients
         return (gz, None, gxw, g_dtw.to(dtwdtype), gp[2].reshape(dtbshape), gp[0].reshape(alshape), gp[1].reshape(-1), None)
 
 
