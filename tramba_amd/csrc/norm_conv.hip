@@ -1300,6 +1300,7 @@ extern "C" int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *part
 // stem and downsample layers, vmamba.py:454,481,486): the GEMMs around them are the library's own, these two kernels are
 // the data movement.  cols (B*Ho*Wo, CKp): row = output pixel, column (ky*3 + kx)*C + ci -- the k-major order of
 // tramba_conv3x3s2_cl's weight -- zero in the padding taps and in the CKp - 9C alignment columns.
+namespace tramba {   // (kernel names carry the namespace: the profile summaries tell the library's launches by it)
 template <typename T, int V>
 __global__ __launch_bounds__(256) void im2col3x3_cl_kernel(const T *__restrict__ x, T *__restrict__ cols, int H, int W,
                                                           int C, int Ho, int Wo, int stride, int pad, int CKp, long total)
@@ -1399,6 +1400,7 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float 
     acc = wave_sum(acc);                          // fixed order: the result does not depend on the launch
     if (lane == 0) gin[i] = acc;
 }
+}  // namespace tramba
 
 extern "C" int tramba_upsample_bilinear_bwd(const float *gout, float *gin, int planes, int h, int w, int hout, int wout,
                                             void *stream)
