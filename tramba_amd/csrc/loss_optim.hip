@@ -14,6 +14,9 @@
 // Both are HBM-streaming kernels: the loss moves 8 B per label pixel and output, Adam 28 B per parameter.
 #include "common.h"
 
+#include <algorithm>
+#include <vector>
+
 namespace tramba {
 
 // ------------------------------------------------------------------------------------------------- loss
@@ -464,18 +467,28 @@ extern "C" int tramba_adam_step(float *const *params, const float *const *grads,
         hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(kBumpTensors), 0, s, b);
         TRAMBA_LAUNCH_CHECK();
     }
-    for (int base = 0; base < count;) {
+    // Launches of equal weight: the tensors are dealt to ceil(count / 72) launches largest first, in snake order (a launch of
+    // 72 bias vectors alone would put 72 workgroups on 256 CUs; the order of the updates does not matter, they are independent).
+    const int nlaunch = (count + kAdamTensors - 1) / kAdamTensors;
+    std::vector<int> order(count);
+    for (int i = 0; i < count; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return numel[x] > numel[y]; });
+    std::vector<std::vector<int>> bins(nlaunch);
+    for (int i = 0; i < count; ++i) {
+        const int round = i / nlaunch, pos = i % nlaunch;
+        bins[(round & 1) ? nlaunch - 1 - pos : pos].push_back(order[i]);
+    }
+    for (int l = 0; l < nlaunch; ++l) {
         AdamArgs a;
         long blocks = 0;
-        int c = 0;
-        while (c < kAdamTensors && base + c < count) {
-            const int j = base + c;
+        const int c = (int)bins[l].size();           // <= kAdamTensors by construction
+        for (int i = 0; i < c; ++i) {
+            const int j = bins[l][i];
             const long nb = (numel[j] + kAdamChunk - 1) / kAdamChunk;
             TRAMBA_CHECK(blocks + nb < 2147483647L, "adam_step: too many workgroups");
-            a.t[c] = AdamTensor{params[j], grads[j], exp_avg[j], exp_avg_sq[j], steps[j], (long)numel[j]};
-            a.first[c] = (int)blocks;
+            a.t[i] = AdamTensor{params[j], grads[j], exp_avg[j], exp_avg_sq[j], steps[j], (long)numel[j]};
+            a.first[i] = (int)blocks;
             blocks += nb;
-            ++c;
         }
         a.count = c;
         for (int i = c; i <= kAdamTensors; ++i) a.first[i] = (int)blocks;
@@ -483,7 +496,6 @@ extern "C" int tramba_adam_step(float *const *params, const float *const *grads,
         a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
         hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kAdamThreads), 0, s, a);
         TRAMBA_LAUNCH_CHECK();
-        base += c;
     }
     return TRAMBA_OK;
 }
