@@ -259,6 +259,14 @@ int tramba_shuffle_norm_cl(const void *x, const float *w, const float *b, void *
 int tramba_shuffle_norm_head_cl(const void *x, const float *w, const float *b, const float *head_w, float head_b,
                                 float *y, int batch, int h, int wd, int c, int p, float eps, int dtype,
                                 void *stream);
+/* Training: backward of tramba_shuffle_norm_head_cl in one pass over x (the normalised (B, H*P, W*P, C) map and its gradient
+ * never exist).  g (B, H*P, W*P) f32 = d loss / d logits; dx (B, H, W, P*P*C) dtype; part (P, C + 4) f32 receives
+ * P = tramba_shuffle_norm_head_bwd_parts() partial rows of A_c = sum over rows of g * xhat_c (slots 0..C) and G = sum g
+ * (slot C); summed over the rows (tramba_slab_sum) they give d ln_w = head_w A, d ln_b = head_w G,
+ * d head_w = ln_w A + ln_b G, d head_b = G.  C % 8 == 0 (4 for f32), C <= 512 (256). */
+int64_t tramba_shuffle_norm_head_bwd_parts(int batch, int h, int wd, int c, int p, int dtype);
+int tramba_shuffle_norm_head_bwd_cl(const void *x, const float *g, const float *ln_w, const float *head_w, void *dx,
+                                    float *part, int batch, int h, int wd, int c, int p, float eps, int dtype, void *stream);
 /* y[row] = <x[row, :], w> + bias: nn.Conv2d(C, 1, 1) on a channels-last map (decoder seg_layers,
  * Trambav6.py:62,67).  x (rows, C) dtype, w (C) f32, y (rows) f32. */
 int tramba_rowdot_cl(const void *x, const float *w, float bias, float *y, int64_t rows, int c, int dtype,

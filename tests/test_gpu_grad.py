@@ -371,3 +371,53 @@ def test_standing_depthwise_packs_follow_the_weights():
     for _ in range(3):
         step(x, y)
         check_current()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(2, 6, 5, 128, 4), (1, 3, 3, 72, 2), (2, 24, 24, 128, 4), (1, 4, 4, 512, 1), (3, 2, 7, 16, 2)])
+def test_shuffle_norm_head_training_pair(dtype, cfg):
+    """The last decoder stage under autograd (FinalPatchExpand_X4's LayerNorm + the C -> 1 head, Trambav6.py:132-137) as one op
+    each way: logits against an fp64 evaluation (the normalised values rounded to the activation dtype, as the kernel's
+    contract says), and the input / LayerNorm / head gradients against fp64 autograd of the same composition -- ragged row
+    counts, C that fills 2 .. 64 lanes, several row groups per wave, bitwise run to run."""
+    from tramba_amd.modules import _ShuffleNormHeadCL
+    b, h, w, c, p = cfg
+    g = torch.Generator().manual_seed(b * 1000 + h * 10 + c)
+    x = (torch.randn(b, h, w, p * p * c, generator=g) * 1.5 + 0.3).to(dtype)
+    ln_w, ln_b = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    hw = torch.randn(1, c, 1, 1, generator=g) * c ** -0.5
+    gl = torch.randn(b, h * p, w * p, generator=g)
+    eps = 1e-5
+
+    def compose(x64, lw, lb, hd, rounded):
+        rows = x64.view(b, h, w, p, p, c)
+        yn = torch.nn.functional.layer_norm(rows, (c,), lw, lb, eps)
+        if rounded:
+            yn = yn.to(dtype).double()
+        lg = (yn * hd.view(-1)).sum(-1)                                        # (b, h, w, p1, p2)
+        return lg.permute(0, 1, 3, 2, 4).reshape(b, h * p, w * p)
+
+    from tramba_amd import hip
+    if not hip.shuffle_norm_head_ok(x.to(DEV), c):                               # fp32 rows of more than 256 channels
+        with pytest.raises(hip.TrambaHipError):
+            _ShuffleNormHeadCL.apply(x.to(DEV), ln_w.to(DEV), ln_b.to(DEV), hw.to(DEV), p, eps)
+        return
+    x64, lw64, lb64, hw64 = (t.double().requires_grad_() for t in (x, ln_w, ln_b, hw))
+    want = compose(x64.detach(), lw64.detach(), lb64.detach(), hw64.detach(), True)
+    (compose(x64, lw64, lb64, hw64, False) * gl.double()).sum().backward()
+    outs = []
+    for _ in range(2):
+        xd = x.to(DEV).requires_grad_()
+        pd = [t.to(DEV).requires_grad_() for t in (ln_w, ln_b, hw)]
+        got = _ShuffleNormHeadCL.apply(xd, pd[0], pd[1], pd[2], p, eps)
+        (got * gl.to(DEV)).sum().backward()
+        outs.append([got.detach(), xd.grad] + [t.grad for t in pd])
+    assert all(torch.equal(u, v) for u, v in zip(*outs))
+    got, gx, glw, glb, ghw = outs[0]
+    tol = {torch.float32: 2e-5, torch.float16: 2e-3, torch.bfloat16: 1.5e-2}[dtype]
+    # (16-bit: a normalised value that sits on a rounding boundary may round the other way in fp32 than in the fp64 restatement)
+    assert _rel_l2(got, want) < {torch.float32: 1e-5, torch.float16: 2e-4, torch.bfloat16: 1e-3}[dtype]
+    assert gx.dtype == dtype and gx.shape == x.shape and ghw.shape == hw.shape
+    assert _rel_l2(gx, x64.grad) < tol, _rel_l2(gx, x64.grad)
+    for a, r in ((glw, lw64.grad), (glb, lb64.grad), (ghw, hw64.grad)):
+        assert _rel_l2(a, r) < max(tol, 1e-4), _rel_l2(a, r)

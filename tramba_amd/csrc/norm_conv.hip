@@ -136,6 +136,118 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const T *__restrict
     store_pack<T, V>(y + orow * C + c0, o);
 }
 
+// Backward of layernorm_rows_kernel's fused head (training path of the last decoder stage, Trambav6.py:132-137: pixel-shuffle
+// + LayerNorm over C + the C -> 1 head): with logit = sum_c (xhat_c gamma_c + beta_c) hw_c + hb and q = hw * gamma,
+//   dx_c = rstd g (q_c - mean(q) - xhat_c mean(q xhat)),      g = d loss / d logit of the row's output pixel,
+// and every parameter gradient follows from two sums over the rows, A_c = sum g xhat_c and G = sum g:
+//   d gamma = hw A,  d beta = hw G,  d hw = gamma A + beta G,  d hb = G.
+// One pass: x rows in (16-byte accesses, 64 / LPR rows of a wave in flight, a wave walks `passes` consecutive groups), dx rows
+// out -- the normalised (B, 4H, 4W, C) map (302 MB at batch 8) and its gradient never exist.  part[workgroup][C + 4]: the
+// workgroup's share of A (C floats) and of G (slot C), waves folded in a fixed order.
+template <typename T, int V, int LPR>
+__global__ __launch_bounds__(256) void norm_head_bwd_rows_kernel(const T *__restrict__ x, const float *__restrict__ g,
+                                                                const float *__restrict__ ln_w,
+                                                                const float *__restrict__ head_w, T *__restrict__ dx,
+                                                                float *__restrict__ part, long rows, int C, float eps, int P,
+                                                                int H, int W, int passes)
+{
+    constexpr int RPW = kWave / LPR;
+    __shared__ float red[4][kWave * V + 1];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int sub = lane % LPR;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wv;
+    const int c0 = sub * V;
+    const bool cok = c0 + V <= C;
+    float q[V], accA[V], accG = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) q[i] = accA[i] = 0.f;
+    if (cok) {
+        float gam[V], hw[V];
+        load_pack<float, V>(ln_w + c0, gam);
+        load_pack<float, V>(head_w + c0, hw);
+#pragma unroll
+        for (int i = 0; i < V; ++i) q[i] = gam[i] * hw[i];
+    }
+    float qs = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) qs += q[i];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) qs += __shfl_xor(qs, o, LPR);
+    const float qbar = qs / (float)C;
+    for (int ps = 0; ps < passes; ++ps) {
+        const long row = (wave * passes + ps) * RPW + lane / LPR;
+        const bool rok = row < rows;
+        float v[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = 0.f;
+        if (rok && cok) load_pack<T, V>(x + row * C + c0, v);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) s += v[i];
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, LPR);
+        const float mean = s / (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float t = cok ? v[i] - mean : 0.f;
+            var = fmaf(t, t, var);
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) var += __shfl_xor(var, o, LPR);
+        const float rstd = rsqrtf(var / (float)C + eps);
+        float xh[V], sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            xh[i] = cok ? (v[i] - mean) * rstd : 0.f;
+            sq = fmaf(q[i], xh[i], sq);
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, LPR);
+        sq /= (float)C;
+        float gi = 0.f;
+        if (rok) {
+            long orow = row;
+            if (P > 1) {   // (32-bit index arithmetic, rows < 2^31 host-checked: see layernorm_rows_kernel)
+                const unsigned r32u = (unsigned)row, pp2 = (unsigned)(P * P);
+                const unsigned pp = r32u % pp2, pix = r32u / pp2;
+                const unsigned wi = pix % (unsigned)W, bh = pix / (unsigned)W;
+                const unsigned hi = bh % (unsigned)H, b = bh / (unsigned)H;
+                orow = ((long)b * (H * P) + (long)(hi * P + pp / P)) * (long)(W * P) + (long)(wi * P + pp % P);
+            }
+            gi = g[orow];
+        }
+        if (rok && cok) {
+            float o[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                o[i] = rstd * gi * (q[i] - qbar - xh[i] * sq);
+                accA[i] = fmaf(gi, xh[i], accA[i]);
+            }
+            store_pack<T, V>(dx + row * C + c0, o);
+        }
+        if (sub == 0) accG += gi;
+    }
+    // the wave's RPW row groups, then the four waves in order (fixed: reproducible)
+#pragma unroll
+    for (int o = kWave / 2; o >= LPR; o >>= 1) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) accA[i] += __shfl_xor(accA[i], o, kWave);
+        accG += __shfl_xor(accG, o, kWave);
+    }
+    if (lane < LPR) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) red[wv][c0 + i] = accA[i];
+        if (sub == 0) red[wv][kWave * V] = accG;
+    }
+    __syncthreads();
+    float *pr = part + (long)blockIdx.x * (C + 4);
+    for (int c = threadIdx.x; c < C + 4; c += blockDim.x) {
+        const int src = c < C ? c : kWave * V;
+        pr[c] = c <= C ? ((red[0][src] + red[1][src]) + red[2][src]) + red[3][src] : 0.f;
+    }
+}
+
 // y[row] = <x[row, :], w> + b   (a 1x1 convolution to ONE channel: the decoder's deep-supervision heads)
 template <typename T, int V, int LPR>
 __global__ __launch_bounds__(256) void rowdot_rows_kernel(const T *__restrict__ x, const float *__restrict__ w, float b,
@@ -1211,6 +1323,65 @@ extern "C" int tramba_shuffle_norm_head_cl(const void *x, const float *w, const 
     TRAMBA_DISPATCH_DTYPE(dtype, T,
         return launch_layernorm<T>(x, w, b, nullptr, rows, c, eps, TRAMBA_ACT_NONE, p, h, wd, (hipStream_t)stream,
                                    head_w, head_b, y));
+    return TRAMBA_OK;
+}
+
+// row groups a wave of the fused norm + head backward walks: ~2048 workgroups (= partial rows) for the 1.18 M rows of a batch of 8
+static int norm_head_bwd_passes(long rows, int lpr)
+{
+    const long per_block = 4L * (kWave / lpr);
+    long passes = (rows + per_block * 2048 - 1) / (per_block * 2048);
+    return (int)(passes < 1 ? 1 : passes > 64 ? 64 : passes);
+}
+
+extern "C" int64_t tramba_shuffle_norm_head_bwd_parts(int batch, int h, int wd, int c, int p, int dtype)
+{
+    const int vm = dtype == TRAMBA_F32 ? 4 : 8;
+    if (batch <= 0 || h <= 0 || wd <= 0 || c <= 0 || p < 1 || c % vm != 0 || c / vm > kWave) return 0;
+    int lpr = 1;
+    while (lpr < c / vm) lpr <<= 1;
+    const long rows = (long)batch * h * wd * p * p;
+    const long per_block = 4L * (kWave / lpr) * norm_head_bwd_passes(rows, lpr);
+    return (rows + per_block - 1) / per_block;
+}
+
+extern "C" int tramba_shuffle_norm_head_bwd_cl(const void *x, const float *g, const float *ln_w, const float *head_w, void *dx,
+                                               float *part, int batch, int h, int wd, int c, int p, float eps, int dtype,
+                                               void *stream)
+{
+    TRAMBA_CHECK(x && g && ln_w && head_w && dx && part, "shuffle_norm_head_bwd_cl: null tensor");
+    TRAMBA_CHECK(batch > 0 && h > 0 && wd > 0 && c > 0 && p >= 1, "shuffle_norm_head_bwd_cl: empty shape");
+    TRAMBA_CHECK(aligned16(x) && aligned16(dx) && aligned16(ln_w) && aligned16(head_w), "shuffle_norm_head_bwd_cl: tensors must be 16-byte aligned");
+    const long nparts = tramba_shuffle_norm_head_bwd_parts(batch, h, wd, c, p, dtype);
+    TRAMBA_CHECK(nparts > 0, "shuffle_norm_head_bwd_cl: C=%d needs C %% %d == 0 and C <= %d", c, dtype == TRAMBA_F32 ? 4 : 8,
+                 kWave * (dtype == TRAMBA_F32 ? 4 : 8));
+    const long rows = (long)batch * h * wd * p * p;
+    TRAMBA_CHECK(rows < 2147483647L && nparts < 2147483647L, "shuffle_norm_head_bwd_cl: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+#define GOB_(T, VM, L_)                                                                                                  \
+    hipLaunchKernelGGL((norm_head_bwd_rows_kernel<T, VM, L_>), dim3((unsigned)nparts), dim3(256), 0, s, (const T *)x, g, ln_w, \
+                       head_w, (T *)dx, part, rows, c, eps, p, h, wd, norm_head_bwd_passes(rows, L_))
+#define GOBL_(T, VM)                                                                                                     \
+    {                                                                                                                    \
+        int lpr = 1;                                                                                                     \
+        while (lpr < c / VM) lpr <<= 1;                                                                                  \
+        switch (lpr) {                                                                                                   \
+        case 1: GOB_(T, VM, 1); break;                                                                                   \
+        case 2: GOB_(T, VM, 2); break;                                                                                   \
+        case 4: GOB_(T, VM, 4); break;                                                                                   \
+        case 8: GOB_(T, VM, 8); break;                                                                                   \
+        case 16: GOB_(T, VM, 16); break;                                                                                 \
+        case 32: GOB_(T, VM, 32); break;                                                                                 \
+        default: GOB_(T, VM, 64); break;                                                                                 \
+        }                                                                                                                \
+    }
+    if (dtype == TRAMBA_F32) GOBL_(float, 4)
+    else if (dtype == TRAMBA_F16) GOBL_(__half, 8)
+    else if (dtype == TRAMBA_BF16) GOBL_(__hip_bfloat16, 8)
+    else TRAMBA_CHECK(false, "bad dtype %d", dtype);
+#undef GOBL_
+#undef GOB_
+    TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
 

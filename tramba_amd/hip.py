@@ -62,6 +62,8 @@ SIGNATURES = {
     "tramba_add_layernorm_cl": (c_int, [c_vp] * 3 + [c_i64] + [c_vp] * 5 + [c_i64, c_int, c_f, c_int, c_int, c_vp]),
     "tramba_shuffle_norm_cl": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_shuffle_norm_head_cl": (c_int, [c_vp] * 4 + [c_f, c_vp] + [c_int] * 5 + [c_f, c_int, c_vp]),
+    "tramba_shuffle_norm_head_bwd_parts": (c_i64, [c_int] * 6),
+    "tramba_shuffle_norm_head_bwd_cl": (c_int, [c_vp] * 6 + [c_int] * 5 + [c_f, c_int, c_vp]),
     "tramba_rowdot_cl": (c_int, [c_vp, c_vp, c_f, c_vp, c_i64, c_int, c_int, c_vp]),
     "tramba_rowdot_bwd_parts": (c_i64, [c_i64, c_int, c_int]),
     "tramba_rowdot_bwd_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_vp]),
@@ -598,6 +600,33 @@ def shuffle_norm_head_cl(x, w, b, head_w, head_b: float, p, eps=1e-5):
     _check(lib().tramba_shuffle_norm_head_cl(_ptr(x), _ptr(w), _ptr(b), _ptr(head_w), float(head_b), _ptr(y), bb, h, wd,
                                              c, p, eps, dt(x), _stream()), "shuffle_norm_head_cl")
     return y
+
+
+def shuffle_norm_head_bwd_cl(x, g, ln_w, head_w, p, eps=1e-5):
+    """Backward of shuffle_norm_head_cl in one pass over x (B, H, W, P*P*C): g (B, H*P, W*P) f32 -> (dx like x, part (S, C + 4)
+    f32): the rows of `part` sum to A_c = sum g xhat_c (slots 0..C) and G = sum g (slot C), from which every parameter gradient
+    follows (tramba_shuffle_norm_head_bwd_cl)."""
+    _dev(x, g, ln_w, head_w)
+    bb, h, wd, cc = x.shape
+    c = cc // (p * p)
+    if g.dtype != torch.float32 or g.numel() != bb * h * wd * p * p or ln_w.dtype != torch.float32 or head_w.dtype != torch.float32:
+        raise TrambaHipError("shuffle_norm_head_bwd_cl: fp32 logit gradients / parameters of the forward's shapes")
+    if ln_w.numel() != c or head_w.numel() != c:
+        raise TrambaHipError("shuffle_norm_head_bwd_cl: parameter vectors of another length than C")
+    nparts = lib().tramba_shuffle_norm_head_bwd_parts(bb, h, wd, c, p, dt(x))
+    if nparts <= 0:
+        raise TrambaHipError(f"shuffle_norm_head_bwd_cl: C = {c} is not served by the rows kernel")
+    dx = torch.empty_like(x)
+    part = torch.empty((nparts, c + 4), dtype=torch.float32, device=x.device)
+    _check(lib().tramba_shuffle_norm_head_bwd_cl(_ptr(x), _ptr(g), _ptr(ln_w), _ptr(head_w), _ptr(dx), _ptr(part), bb, h, wd, c, p,
+                                                 eps, dt(x), _stream()), "shuffle_norm_head_bwd_cl")
+    return dx, part
+
+
+def shuffle_norm_head_ok(x, c):
+    """shapes the fused norm + head pair serves: C a multiple of 8 (4 for f32) on at most 64 lanes"""
+    vm = 4 if x.dtype == torch.float32 else 8
+    return x.is_cuda and c % vm == 0 and c // vm <= 64
 
 
 def expand_norm_head_cl(x, w, ln_w, ln_b, head_w, head_b: float, p, eps=1e-5):

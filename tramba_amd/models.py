@@ -113,10 +113,16 @@ class VSSMDecoder(nn.Module):
             # and the C -> 1 head is a dot product per group: both run on the UN-shuffled (M * P * P, C) view, and only the
             # scalar logits are rearranged -- the (B, 4H, 4W, C) map (302 MB at batch 8) is never permuted, forward or
             # backward.  'b (p1 p2 c) h w -> b c (h p1) (w p2)' (modules.py:246-250): group g = p1 * P + p2.
-            from .modules import _RowDotCL
+            from .modules import _RowDotCL, _ShuffleNormHeadCL
             b, h, w, _ = x_low.shape
             p, c = fin.scale, fin.output_dim
             xe = fin.expand._forward_cl(x_low)                               # (B, H, W, P*P*C)
+            if hip.shuffle_norm_head_ok(xe, c) and conv.weight.numel() == c:
+                # norm + head as ONE op each way: the normalised map is not stored, its gradient never formed
+                lg = _ShuffleNormHeadCL.apply(xe, fin.norm.weight, fin.norm.bias, conv.weight, p, fin.norm.eps)
+                if conv.bias is not None:
+                    lg = lg + conv.bias.float().view(1, 1, 1)
+                return lg.unsqueeze(1)
             yn = fin.norm._forward_cl(xe.view(b, h, w * p * p, c))           # LayerNorm per C-group
             lg = _RowDotCL.apply(yn, conv.weight, conv.bias)                 # (B, H, W*P*P) f32
             lg = lg.view(b, h, w, p, p).permute(0, 1, 3, 2, 4).reshape(b, h * p, w * p)

@@ -576,6 +576,32 @@ class _Linear2TrainCL(torch.autograd.Function):
         return g1, g2, gw, gb
 
 
+class _ShuffleNormHeadCL(torch.autograd.Function):
+    """logits (B, H*P, W*P) f32 = head(LayerNorm_C(pixel_shuffle_P(x))) without its bias, x (B, H, W, P*P*C): the last decoder
+    stage of the training path (FinalPatchExpand_X4's norm + seg_layers[-1], Trambav6.py:132-137).  Forward: the inference
+    kernel (tramba_shuffle_norm_head_cl); backward: one pass over x (tramba_shuffle_norm_head_bwd_cl) -- the normalised
+    (B, 4H, 4W, C) map, 302 MB at batch 8, exists neither way.  Parameter gradients from the two row sums A, G."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, head_w, p, eps):
+        x = x.contiguous()
+        y = hip.shuffle_norm_head_cl(x, hip._f32(ln_w), hip._f32(ln_b), hip._f32(head_w).reshape(-1), 0.0, p, eps)
+        ctx.save_for_backward(x, ln_w, ln_b, head_w)
+        ctx.p, ctx.eps = p, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ln_w, ln_b, head_w = ctx.saved_tensors
+        gam, bet, hw = ln_w.detach().float(), ln_b.detach().float(), head_w.detach().float().reshape(-1)
+        dx, part = hip.shuffle_norm_head_bwd_cl(x, g.contiguous().float(), gam, hw, ctx.p, ctx.eps)
+        s_ = hip.slab_sum(part)
+        c = gam.numel()
+        a, gs = s_[:c], s_[c]
+        return (dx if ctx.needs_input_grad[0] else None, (hw * a).to(ln_w.dtype), (hw * gs).to(ln_b.dtype),
+                (gam * a + bet * gs).reshape(head_w.shape).to(head_w.dtype), None, None)
+
+
 class _RowDotCL(torch.autograd.Function):
     """A C -> 1 segmentation head (nn.Conv2d(C, 1, 1), Trambav6.py:82,130) on a channels-last map with autograd:
     forward tramba_rowdot_cl (fp32 logits), weight gradient on tramba_wgrad_cl (the one output channel padded to the
