@@ -60,7 +60,9 @@ extern "C" const char *tramba_last_error(void) { return g_err; }
 // 3: layernorm_bwd_parts(rows, c, dtype), shadow / slab-sum entries
 // 4: fused training entries (add_layernorm, layernorm_bwd_res, dwconv_dual, merge_grad, ss2d_bwd_prep / assemble,
 //    dw_unpack_grad); a_log / flags arguments of the fused scan forward / backward
-extern "C" int tramba_abi_version(void) { return 4; }
+// 5: the step's ends and batched launches (sod_loss_*, adam_step, multi_sum / multi_sum_strided, wgrad_parts_cl,
+//    dw_pack_multi / dw_unpack_grad_multi, shuffle_norm_head_bwd_cl)
+extern "C" int tramba_abi_version(void) { return 5; }
 
 static int g_tune[TRAMBA_TUNE_COUNT] = {0};
 extern "C" int tramba_tune_set(int knob, int value)
