@@ -168,3 +168,23 @@ def test_load_pretrained_base_follows_the_reference_rules(tmp_path, capsys):
     torch.save({"model": bad}, path)
     with pytest.raises(AssertionError):
         load_pretrained_Base(dst, ckpt_path=path)
+
+
+def test_optimizer_choice_and_no_cpu_fallback():
+    """train.get_opt hands a host model the reference's own optimizer (host logic / gloo tests), a device model the library's;
+    the library's Adam refuses host tensors instead of falling back (reference train.py:266-280)."""
+    import torch
+    from tramba_amd import hip, train
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3))
+    opt = train.get_opt(1e-3, m)
+    assert type(opt) is torch.optim.Adam and [g["lr"] for g in opt.param_groups] == [1e-4, 1e-3]
+    assert issubclass(train.Adam, torch.optim.Adam)
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    lib_opt = train.Adam([p], 1e-3)
+    assert lib_opt.state_dict()["param_groups"][0]["betas"] == (0.9, 0.999)
+    with pytest.raises(hip.TrambaHipError):
+        lib_opt.step()
+    assert float(p.abs().sum()) == 0.0                     # nothing moved
+    with pytest.raises(hip.TrambaHipError):
+        hip.sod_loss([torch.zeros(1, 1, 4, 4)], torch.zeros(1, 1, 4, 4))
