@@ -100,6 +100,29 @@ def tramba_loss(outputs, label):
     return total
 
 
+def adam_steps(params, grads_per_step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """The optimizer of train.py:266-280 -- `torch.optim.Adam(param_groups, lr)`, all defaults -- restated from its update rule
+    (torch/optim/adam.py, _single_tensor_adam: amsgrad off, maximize off), in fp64: for step t = 1, 2, ... and every tensor
+      g += weight_decay p;  m = m + (1 - b1)(g - m);  v = b2 v + (1 - b2) g g;
+      p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+    params: tensors; grads_per_step: one list of gradients per step.  Returns (params, exp_avg, exp_avg_sq) after the steps.
+    Pinned against torch.optim.Adam itself on the CPU (tests/test_oracle.py)."""
+    b1, b2 = betas
+    p = [x.detach().double().clone() for x in params]
+    m = [torch.zeros_like(x) for x in p]
+    v = [torch.zeros_like(x) for x in p]
+    for t, grads in enumerate(grads_per_step, 1):
+        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+        for i, g in enumerate(grads):
+            g = g.detach().double()
+            if weight_decay:
+                g = g + weight_decay * p[i]
+            m[i] = m[i] + (1 - b1) * (g - m[i])
+            v[i] = b2 * v[i] + (1 - b2) * g * g
+            p[i] = p[i] - (lr / bc1) * m[i] / (v[i].sqrt() / math.sqrt(bc2) + eps)
+    return p, m, v
+
+
 def mae_metric(pred: np.ndarray, gt: np.ndarray) -> float:
     """Evaluation/metrics.py:13-19, 88-104: min-max normalise pred, gt -> bool, mean |pred-gt|."""
     gt = gt.astype(bool)

@@ -97,22 +97,9 @@ def test_loss_rejects_what_the_kernels_cannot_take():
 
 # ------------------------------------------------------------------------------------------------------- Adam
 def _adam_reference(ps, grads_per_step, lr, betas, eps, wd):
-    """torch.optim.Adam's single-tensor arithmetic (torch/optim/adam.py _single_tensor_adam; what the reference's
-    `torch.optim.Adam(params, lr)` runs), in fp64"""
-    b1, b2 = betas
-    p = [x.double().clone() for x in ps]
-    m = [torch.zeros_like(x) for x in p]
-    v = [torch.zeros_like(x) for x in p]
-    for t, grads in enumerate(grads_per_step, 1):
-        for i, g in enumerate(grads):
-            g = g.double()
-            if wd:
-                g = g + wd * p[i]
-            m[i].lerp_(g, 1 - b1)
-            v[i].mul_(b2).addcmul_(g, g, value=1 - b2)
-            bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
-            p[i].addcdiv_(m[i], (v[i].sqrt() / bc2 ** 0.5).add_(eps), value=-lr / bc1)
-    return p, m, v
+    """the oracle's restatement of the reference's optimizer (oracle/ops.py adam_steps, pinned against torch.optim.Adam on the
+    CPU in tests/test_oracle.py), fp64"""
+    return oo.adam_steps(ps, grads_per_step, lr, betas, eps, wd)
 
 
 ADAM_SHAPES = [(1,), (3,), (4,), (5,), (8191,), (8192,), (8193,), (3, 7, 11), (100003,), (64, 1, 7, 7), (1024, 512), (2, 16389)]

@@ -300,3 +300,27 @@ def test_scan_backward_matches_autograd_of_numpy_form():
     got = oss.selective_scan_bwd(a["u"], a["delta"], a["A"], a["B"], a["C"], a["D"], a["delta_bias"], g, True)
     for name, t in zip(("u", "delta", "A", "B", "C", "D", "delta_bias"), got):
         assert (t - ins[name].grad).abs().max() < 1e-10, name
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.02])
+def test_adam_restatement_equals_torch_optim_adam(wd):
+    """oracle.ops.adam_steps (the update rule of train.py:266-280's optimizer written out) against torch.optim.Adam itself, fp64
+    on the CPU, single-tensor and foreach forms, five steps of gradients on several scales: the pin of the reference the HIP
+    optimizer kernel is tested against (tests/test_gpu_step_ends.py)."""
+    g = torch.Generator().manual_seed(13)
+    shapes = [(7,), (3, 5), (2, 3, 3, 3), (1,)]
+    init = [torch.randn(s, generator=g, dtype=torch.float64) for s in shapes]
+    steps = [[torch.randn(s, generator=g, dtype=torch.float64) * 10.0 ** (i - 2) for i, s in enumerate(shapes)] for _ in range(5)]
+    want_p, want_m, want_v = oo.adam_steps(init, steps, 3e-3, (0.9, 0.999), 1e-8, wd)
+    for foreach in (False, True):
+        params = [torch.nn.Parameter(p.clone()) for p in init]
+        opt = torch.optim.Adam(params, 3e-3, weight_decay=wd, foreach=foreach)
+        for grads in steps:
+            for p, gr in zip(params, grads):
+                p.grad = gr.clone()
+            opt.step()
+        for i, p in enumerate(params):
+            st = opt.state[p]
+            assert torch.allclose(p.detach(), want_p[i], rtol=1e-12, atol=1e-14)
+            assert torch.allclose(st["exp_avg"], want_m[i], rtol=1e-12, atol=1e-14)
+            assert torch.allclose(st["exp_avg_sq"], want_v[i], rtol=1e-12, atol=1e-16)
