@@ -254,6 +254,78 @@ def test_deferred_sums_leave_the_training_step_unchanged(tramba_v_grad_oracle):
     m.compute_dtype = None
 
 
+class _TinyStep(torch.nn.Module):
+    """a Helix decoder block + a Dual-Frequency block behind train_step's interface (a list of logit maps)"""
+
+    def __init__(self):
+        super().__init__()
+        import tramba_amd as ta
+        torch.manual_seed(3)
+        self.encoder = ta.MultiScaleDecoderBlock(hidden_dim=32, drop_path=0.0, channel_first=True)
+        self.guide = ta.FreqBlockv6(dim=32, input_resolution=(24, 24))
+        self.compute_dtype = None
+
+    def forward(self, z):
+        return [self.guide(self.encoder(z)).mean(dim=1, keepdim=True)]
+
+
+def test_deferred_sums_with_16_bit_parameters():
+    """a deferred sum is filled AFTER backward returns, so a call site may defer only when autograd stores its result
+    as it is -- an fp32 leaf.  With bf16 parameters every site must sum at once (its `.to(dtype)` would read the unfilled
+    buffer): NaN-poisoned deferred outputs, gradients equal to a plain backward bit for bit."""
+    from tramba_amd import hip, train
+    m = _TinyStep().to(DEV).train()
+    for p in m.parameters():           # (parameters only: the DCT tables are fp32 buffers)
+        p.data = p.data.to(torch.bfloat16)
+    x = torch.randn(2, 32, 24, 24, device=DEV, dtype=torch.bfloat16)
+    y = (torch.rand(2, 1, 24, 24, device=DEV) > 0.5).float()
+    train.tramba_loss(m(x), y).backward()
+    want = {n: p.grad.clone() for n, p in m.named_parameters()}
+    assert all(torch.isfinite(g).all() for g in want.values())
+    m.zero_grad(set_to_none=True)
+    hip._sumq.poison = True
+    try:
+        loss = train.tramba_loss(m(x), y)
+        with hip.deferred_sums():
+            loss.backward()
+    finally:
+        hip._sumq.poison = False
+    bad = [n for n, p in m.named_parameters() if p.grad.dtype != p.dtype or not torch.equal(p.grad, want[n])]
+    assert not bad, (len(bad), bad[:8])
+
+
+def test_train_step_accumulating_into_standing_gradients():
+    """with .grad already set (gradient accumulation, zero_grad(set_to_none=False)) autograd ADDS the incoming
+    gradient, i.e. reads it, before the deferred sums have run; train_step must then sum at once.  An optimizer whose
+    zero_grad keeps the gradients and whose step does nothing: the second step leaves exactly twice the first's gradients,
+    with the deferred outputs NaN-poisoned."""
+    from tramba_amd import hip, train
+
+    class KeepGrads(torch.optim.SGD):
+        def zero_grad(self, set_to_none=True):
+            pass
+
+        def step(self, closure=None):
+            pass
+
+    m = _TinyStep().to(DEV).train()
+    opt = KeepGrads(m.parameters(), lr=0.0)
+    x = torch.randn(2, 32, 24, 24, device=DEV)
+    y = (torch.rand(2, 1, 24, 24, device=DEV) > 0.5).float()
+    hip._sumq.poison = True
+    try:
+        train.train_step(m, opt, x, y)            # .grad None: the sums are deferred
+        first = {n: p.grad.clone() for n, p in m.named_parameters()}
+        assert all(torch.isfinite(g).all() for g in first.values())
+        train.train_step(m, opt, x, y)            # .grad set: accumulated into
+    finally:
+        hip._sumq.poison = False
+    for n, p in m.named_parameters():
+        assert torch.isfinite(p.grad).all(), n
+        # (the scan backward's parameter sums are bitwise reproducible, so the sum of two equal passes is exactly 2 g)
+        torch.testing.assert_close(p.grad, 2 * first[n], rtol=1e-6, atol=1e-30, msg=n)
+
+
 @pytest.mark.parametrize("n,c,dtype", [(24, 64, torch.bfloat16), (48, 32, torch.bfloat16), (96, 16, torch.bfloat16),
                                        (24, 32, torch.float32), (48, 16, torch.float16)])
 @pytest.mark.parametrize("which", ["both", "low", "high"])

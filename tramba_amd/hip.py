@@ -516,8 +516,9 @@ def layernorm_cl(x, w, b, eps=1e-5, act=ACT_NONE):
     return y
 
 
-def layernorm_bwd_cl(x, dy, w, eps=1e-5):
-    """x, dy: (..., C) contiguous -> (dx like x, dw (C) f32, db (C) f32)."""
+def layernorm_bwd_cl(x, dy, w, eps=1e-5, defer=False):
+    """x, dy: (..., C) contiguous -> (dx like x, dw (C) f32, db (C) f32).  defer: dw / db go to autograd as the gradients of
+    fp32 leaves as they are (see _SumQueue); anything that reads or casts them must pass False."""
     _dev(x, dy, w)
     c = x.shape[-1]
     rows = x.numel() // c
@@ -525,7 +526,7 @@ def layernorm_bwd_cl(x, dy, w, eps=1e-5):
     part = torch.empty((lib().tramba_layernorm_bwd_parts(rows, c, dt(x)), 2, c), dtype=torch.float32, device=x.device)
     _check(lib().tramba_layernorm_bwd_cl(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(part), rows, c, eps, dt(x), _stream()),
            "layernorm_bwd_cl")
-    s = slab_sum(part, defer=True)
+    s = slab_sum(part, defer=defer)
     return dx, s[0], s[1]
 
 
@@ -547,7 +548,7 @@ def add_layernorm_cl(x, y, mask, w, b, eps=1e-5, act=ACT_NONE, dual=False):
     return xsum, n, na
 
 
-def layernorm_bwd_res_cl(x, dy, w, eps=1e-5, gres=None, mask=None, want_masked=False):
+def layernorm_bwd_res_cl(x, dy, w, eps=1e-5, gres=None, mask=None, want_masked=False, defer=False):
     """LayerNorm backward on the residual stream: (dx + gres, that * mask[sample] or None, dw, db)"""
     _dev(x, dy, w, gres, mask)
     c = x.shape[-1]
@@ -560,7 +561,7 @@ def layernorm_bwd_res_cl(x, dy, w, eps=1e-5, gres=None, mask=None, want_masked=F
     _check(lib().tramba_layernorm_bwd_res_cl(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(part), _ptr(gres), _ptr(mask),
                                              rows // x.shape[0], _ptr(dxm), rows, c, eps, dt(x), _stream()),
            "layernorm_bwd_res_cl")
-    s = slab_sum(part, defer=True)
+    s = slab_sum(part, defer=defer)
     return dx, dxm, s[0], s[1]
 
 
@@ -575,7 +576,7 @@ def shuffle_norm_cl(x, w, b, p, eps=1e-5):
     return y
 
 
-def shuffle_norm_bwd_cl(x, dy, w, p, eps=1e-5):
+def shuffle_norm_bwd_cl(x, dy, w, p, eps=1e-5, defer=False):
     """backward of shuffle_norm_cl: x (B,H,W,P*P*C), dy (B,H*P,W*P,C) -> (dx like x, dw (C), db (C))"""
     _dev(x, dy, w)
     bb, h, wd, cc = x.shape
@@ -587,7 +588,7 @@ def shuffle_norm_bwd_cl(x, dy, w, p, eps=1e-5):
     part = torch.empty((lib().tramba_layernorm_bwd_parts(rows, c, dt(x)), 2, c), dtype=torch.float32, device=x.device)
     _check(lib().tramba_shuffle_norm_bwd_cl(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(part), bb, h, wd, c, p, eps, dt(x),
                                             _stream()), "shuffle_norm_bwd_cl")
-    s = slab_sum(part, defer=True)
+    s = slab_sum(part, defer=defer)
     return dx, s[0], s[1]
 
 

@@ -470,7 +470,7 @@ class _LinearTrainCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _dgrad(gy2, wa, ctx.wa_t).view(ctx.xshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _wgrad(gy2, x2, ctx.has_bias, defer=True)
+            gw, gb = _wgrad(gy2, x2, ctx.has_bias, defer=ctx.wdtype == torch.float32)   # (a cast below would READ the sum)
             gw = gw.to(ctx.wdtype)
         return gx, gw, gb
 
@@ -504,7 +504,7 @@ class _GeluLinearTrainCL(torch.autograd.Function):
             wt = wa.t().contiguous() if ctx.wa_t is None else ctx.wa_t
             gh = hip.linear_cl(gy2, wt, None, h2, hip.ACT_GELU_GRAD_MUL).view(ctx.hshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _wgrad(gy2, a2, ctx.has_bias, defer=True)
+            gw, gb = _wgrad(gy2, a2, ctx.has_bias, defer=ctx.wdtype == torch.float32)
             gw = gw.to(ctx.wdtype)
         return gh, gw, gb, None
 
@@ -539,7 +539,7 @@ class _LinearGeluPairTrainCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _dgrad(gy2, wa, ctx.wa_t).view(ctx.xshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _wgrad(gy2, x2, ctx.has_bias, defer=True)
+            gw, gb = _wgrad(gy2, x2, ctx.has_bias, defer=ctx.wdtype == torch.float32)   # (a cast below would READ the sum)
             gw = gw.to(ctx.wdtype)
         return gx, gw, gb
 
@@ -723,12 +723,13 @@ class _LayerNormCL(torch.autograd.Function):
         wf = w.detach().float().contiguous()
         ctx.save_for_backward(x, wf)
         ctx.eps = eps
+        ctx.defer = w.dtype == torch.float32 and b.dtype == torch.float32   # (an fp32 leaf takes the f32 sums as they are)
         return hip.layernorm_cl(x, wf, b.detach().float().contiguous(), eps, hip.ACT_NONE)
 
     @staticmethod
     def backward(ctx, gy):
         x, wf = ctx.saved_tensors
-        dx, dw, db = hip.layernorm_bwd_cl(x, gy.contiguous().to(x.dtype), wf, ctx.eps)
+        dx, dw, db = hip.layernorm_bwd_cl(x, gy.contiguous().to(x.dtype), wf, ctx.eps, defer=ctx.defer)
         return dx, dw, db, None
 
 
@@ -800,6 +801,7 @@ class _ShuffleNormCL(torch.autograd.Function):
         wf = w.detach().float().contiguous()
         ctx.save_for_backward(xe, wf)
         ctx.p, ctx.eps = p, eps
+        ctx.defer = w.dtype == torch.float32 and b.dtype == torch.float32
         return hip.shuffle_norm_cl(xe, wf, b.detach().float().contiguous(), p, eps)
 
     @staticmethod
@@ -808,7 +810,7 @@ class _ShuffleNormCL(torch.autograd.Function):
         gy = gy.contiguous()
         if gy.dtype != xe.dtype:
             gy = gy.to(xe.dtype)
-        dx, dw, db = hip.shuffle_norm_bwd_cl(xe, gy, wf, ctx.p, ctx.eps)
+        dx, dw, db = hip.shuffle_norm_bwd_cl(xe, gy, wf, ctx.p, ctx.eps, defer=ctx.defer)
         return dx, dw, db, None, None
 
 
@@ -1233,6 +1235,7 @@ class _AddLayerNormCL(torch.autograd.Function):
                                          eps, act, dual=act != hip.ACT_NONE)
         ctx.save_for_backward(x if xs is None else xs, wf, mask)
         ctx.eps, ctx.has_y = eps, y is not None
+        ctx.defer = w.dtype == torch.float32 and b.dtype == torch.float32
         if na is not None:
             ctx.mark_non_differentiable(na)
         ctx.set_materialize_grads(False)
@@ -1257,7 +1260,7 @@ class _AddLayerNormCL(torch.autograd.Function):
                 g_xs = g_xs.to(xs.dtype)
         want_m = ctx.has_y and mask is not None and ctx.needs_input_grad[1]
         dx, dxm, dw, db = hip.layernorm_bwd_res_cl(xs, g_n, wf, ctx.eps, gres=g_xs, mask=mask if want_m else None,
-                                                   want_masked=want_m)
+                                                   want_masked=want_m, defer=ctx.defer)
         gy = (dxm if want_m else dx) if ctx.has_y else None
         return dx, gy, None, dw, db, None, None, None
 
@@ -1469,6 +1472,7 @@ class _SS2DInnerCL(torch.autograd.Function):
         ctx.dtw_t = ent[3] if (ent is not None and ent[1] == dt_w._version and ent[2]() is dt_w
                                and ent[3] is not None and ent[3].dtype == xs.dtype) else None
         ctx.meta = (xw.dtype, xw.shape, dt_w.dtype, dt_b.shape, a_logs.shape)
+        ctx.par_f32 = dt_b.dtype == a_logs.dtype == ds.dtype == torch.float32    # (deferred sums go to fp32 leaves only)
         return hip.ss2d_merge_sum_cl(ys, order, xs.dtype)
 
     @staticmethod
@@ -1526,7 +1530,7 @@ class _SS2DInnerCL(torch.autograd.Function):
             else:
                 gp_ = _wgrad(g_xd, xs.view(b * l, d))[0].view(k, rg, d)
                 gxw = torch.cat((gp_[:, :r], gp_[:, r8:r8 + 2]), dim=1).to(xwdtype)
-        gp = hip.slab_sum(gpar, defer=True)                                                # (3,K,D): contiguous planes, leaf gradients
+        gp = hip.slab_sum(gpar, defer=ctx.par_f32)                                             # (3,K,D): contiguous planes, leaf gradients
         return (gz, None, gxw, g_dtw.to(dtwdtype), gp[2].reshape(dtbshape), gp[0].reshape(alshape), gp[1].reshape(-1), None)
 
 

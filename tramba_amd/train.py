@@ -192,6 +192,15 @@ def adjust_learning_rate(optimizer, epoch, decay_epochs, base_lr, decay_factors)
 DEFER_SUMS = True   # (scripts/graph_train.py times the step both ways)
 
 
+def _has_standing_grads(opt):
+    """any parameter of the optimizer whose .grad is set (backward would accumulate into it)"""
+    for g in opt.param_groups:
+        for p in g["params"]:
+            if p.grad is not None:
+                return True
+    return False
+
+
 def train_step(model, opt, images, label, reducer=None):
     """One optimisation step (train.py:74-89).  `reducer` (tramba_amd.parallel.GradBucketReducer)
     averages gradients across data-parallel ranks; its all-reduces overlap the backward."""
@@ -201,7 +210,10 @@ def train_step(model, opt, images, label, reducer=None):
         reducer.prepare()
     else:
         opt.zero_grad(set_to_none=True)
-    if DEFER_SUMS:
+    # Deferred partial sums hand autograd gradient tensors that are FILLED at the exit of the context: safe only where the engine
+    # stores them as they are -- an fp32 leaf whose .grad is None (the call sites defer for fp32 parameters only; a gradient that is
+    # already set would be accumulated into, i.e. read, before the flush: gradient accumulation, zero_grad(set_to_none=False))
+    if DEFER_SUMS and not _has_standing_grads(opt):
         with hip.deferred_sums():  # the parameter-gradient partial sums of the pass run as a few batched launches at the exit
             loss.backward()
     else:
