@@ -66,6 +66,13 @@ typedef enum { TRAMBA_ACT_NONE = 0, TRAMBA_ACT_SILU = 1, TRAMBA_ACT_GELU = 2,
 /* ------------------------------------------------------------------ library */
 const char *tramba_last_error(void);      /* thread-local message of the last failure */
 int tramba_abi_version(void);
+/* Failures a kernel can only detect on the device (today: the carry mailbox of the fused scans timing out, which leaves NaN
+ * in that launch's output) raise a device error word in host-mapped memory.  No call synchronises for it: EVERY entry point
+ * checks the word after its own launch and, when set, clears it and returns TRAMBA_ERR_HIP with tramba_last_error() naming
+ * the cause -- i.e. the failure is reported by the next library call issued after the failing kernel has run.  This entry
+ * reads (and clears) the word on demand, e.g. after the caller's own stream synchronisation: TRAMBA_OK or TRAMBA_ERR_HIP.
+ * (No reference counterpart: the reference's extension reports through TORCH_CHECK on the host only, csms6s.py:857.) */
+int tramba_device_error(void);
 /* HIP-event timing of the kernels launched by this library (used by bench.py for the
  * roofline figure).  enable=1 brackets every launch of kernel class `which` with events on
  * the launch stream; tramba_profile_read() synchronises those events and returns the
@@ -97,7 +104,9 @@ int tramba_tune_get(int knob);
                                         weight-gradient TN GEMMs (tramba_wgrad_cl): 0 = token tiles staged by LDS-DMA on 3 stages, one
                                         workgroup per CU (the default); 8 = register-staged, one tile in flight; 9 = LDS-DMA on 4 stages;
                                         10 / 11 / 12 = 384 / 512 / 768 workgroups wanted by the token split */
-#define TRAMBA_TUNE_COUNT 4
+#define TRAMBA_TUNE_MAILBOX_POLLS 4  /* poll budget of the fused scans' carry mailbox (0 = the library's 2^20, ~0.1 s); tests force a
+                                        time-out with a tiny budget to see the device error word reported */
+#define TRAMBA_TUNE_COUNT 5
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1
 #define TRAMBA_PROF_GEMM 2          /* tramba_linear_cl (1x1-conv projections) */

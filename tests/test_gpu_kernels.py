@@ -338,6 +338,49 @@ def test_ss2d_lds_dma_scan_at_the_benchmarked_launches(dtype, fam, b, h, d, r):
                                           (-torch.exp(a_logs)).reshape(-1).to(dev), ds.to(dev), dtype))   # run-to-run bitwise
 
 
+@pytest.mark.parametrize("form", [0, 1])      # the library's choice for this shape (chained on LDS-DMA) / the register ring: both carry by mailbox
+def test_scan_mailbox_timeout_is_reported_not_returned_as_a_result(form):
+    """a starved carry-mailbox poll used to end the launch with NaN in `ys` and rc 0.  With the poll budget
+    forced to 1 (TRAMBA_TUNE_MAILBOX_POLLS) the waves that find their predecessor's mailbox empty give up at once: the launch
+    still ends, its output holds NaN, and the device error word makes the next library call after it return TRAMBA_ERR_HIP
+    with the cause in tramba_last_error(); the word is cleared by the report and the same launch at the default budget is
+    clean."""
+    H = hip()
+    dev = torch.device(DEV)
+    b, h, d, r, k, dtype = 4, 96, 256, 8, 8, torch.bfloat16     # the Helix launch of BASELINE configs[1]
+    g = torch.Generator().manual_seed(77)
+    order = H.scan_order("helix", h, h, dev)
+    xc = torch.randn(b, h * h, d, generator=g).to(dtype).to(dev)
+    wx = (torch.randn(k, r + 2, d, generator=g) * d ** -0.5).to(dtype)
+    xdbl = H.linear_cl(xc, H.pad_x_proj_weight(wx.to(dev)), out_dtype=torch.float32)
+    args = (xc, xdbl, order, (torch.randn(k, d, r, generator=g) * r ** -0.5).to(dev),
+            (torch.randn(k * d, generator=g) * 0.5 - 2.0).to(dev), (-0.5 - torch.rand(k * d, generator=g)).to(dev),
+            torch.ones(k * d).to(dev), dtype)
+    H.tune_set(H.TUNE_SCAN_FORM, form)
+    try:
+        good = H.ss2d_scan_cl(*args)
+        torch.cuda.synchronize()
+        H.device_error()                                   # nothing pending
+        assert torch.isfinite(good).all()
+        H.tune_set(H.TUNE_MAILBOX_POLLS, 1)
+        try:
+            bad = H.ss2d_scan_cl(*args)                    # the launch itself is issued without complaint ...
+            torch.cuda.synchronize()
+        finally:
+            H.tune_set(H.TUNE_MAILBOX_POLLS, 0)
+        assert not torch.isfinite(bad).all()               # ... its output is poisoned, not plausible ...
+        with pytest.raises(H.TrambaHipError, match="mailbox"):
+            H.layernorm_cl(xc, torch.ones(d, device=dev), torch.zeros(d, device=dev))   # ... and the NEXT call says so
+        H.device_error()                                   # reported once, then cleared
+        again = H.ss2d_scan_cl(*args)
+        torch.cuda.synchronize()
+        H.device_error()
+        assert torch.equal(again, good)
+    finally:
+        H.tune_set(H.TUNE_SCAN_FORM, 0)
+        H.tune_set(H.TUNE_MAILBOX_POLLS, 0)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [(2, 12, 64, 40), (1, 24, 128, 256), (1, 13, 64, 64), (1, 48, 256, 130)])
 def test_conv3x3s2_cl(dtype, cfg):
@@ -696,6 +739,72 @@ def test_ss2d_core_training_gradients(dtype, fam, h, d, r, b):
     close(dl[3].grad, leaves[3].grad, "gbias", 5e-4 if f32 else 5e-2)
     close(dl[4].grad, leaves[4].grad, "gA", 5e-4 if f32 else 5e-2)
     close(dl[5].grad, leaves[5].grad, "gD", 5e-4 if f32 else 5e-2)
+
+
+@pytest.mark.parametrize("fam,b,h,d,r", [("helix", 8, 96, 256, 8), ("raster", 8, 96, 256, 8), ("helix", 8, 48, 512, 16),
+                                         ("window", 8, 48, 512, 16)])
+def test_ss2d_scan_backward_at_the_benchmarked_launches(fam, b, h, d, r):
+    """VERDICT r3 'missing' #3: the backward launches of a BASELINE configs[2] training step -- ss2d_scan_bwd_cl_kernel at B = 8,
+    bf16, as _SS2DInnerCL issues it (states saved by the forward launch, A_logs in, dB / dC as per-channel-tile partials):
+    96x96 K = 8 D = 256 (bench.py's `roofline_scan_bwd.helix_top_stage`), its K = 4 sibling and the 48x48 rank-16 launches --
+    every output against the fp64 oracle of the op it replaces DIRECTLY (csms6s.py:914-923: selective_scan_cuda_oflex.bwd on the
+    gathered operands, oracle/selective_scan_ref.c), image by image so that the oracle's fp64 tensors stay at 150 MB each."""
+    from oracle import selective_scan as oss
+    H = hip()
+    dev = torch.device(DEV)
+    dtype = torch.bfloat16
+    order = H.scan_order(fam, h, h, dev)
+    k, l = order.k, h * h
+    rg = H.ss2d_group_stride(r)
+    g = torch.Generator().manual_seed(h * d + r + k)
+    x = torch.randn(b, l, d, generator=g).to(dtype)
+    xdbl = torch.zeros(b, l, k, rg)
+    xdbl[..., :r] = 0.5 * torch.randn(b, l, k, r, generator=g)
+    xdbl[..., rg - 4:rg - 2] = torch.randn(b, l, k, 2, generator=g)
+    xdbl = xdbl.view(b, l, k * rg)
+    dt_w = torch.randn(k, d, r, generator=g) * r ** -0.5
+    dt_b = torch.randn(k, d, generator=g) * 0.5 - 1.0
+    a_logs = torch.log(torch.rand(k, d, generator=g) * 0.8 + 0.2)
+    ds = 1 + 0.1 * torch.randn(k, d, generator=g)
+    gym = torch.randn(b, l, d, generator=g).to(dtype)          # the merged map's gradient arrives in the activation dtype
+    xd, xdd, gd = x.to(dev), xdbl.to(dev), gym.to(dev)
+    par = (dt_w.to(dev), dt_b.reshape(-1).to(dev), a_logs.reshape(-1).to(dev), ds.reshape(-1).to(dev))
+    states = H.ss2d_scan_states(xd, order)
+    H.ss2d_scan_cl(xd, xdd, order, *par, dtype, states=states, a_log=True)
+    gu, graw, gB, gC, gpar = H.ss2d_scan_bwd_cl(xd, xdd, order, *par, gd, states=states, a_log=True, bc_partials=True)
+    torch.cuda.synchronize()
+    H.device_error()
+    gu, graw = gu.cpu(), graw.cpu()
+    gB, gC, gpar = gB.sum(dim=2).cpu().double(), gC.sum(dim=2).cpu().double(), gpar.cpu().double()
+    tbl = order.table.cpu().long()                                # (K, L)
+    a_neg = -torch.exp(a_logs.double()).reshape(k * d, 1)
+    worst = {}
+
+    def close(got, want, name, rel, rms):
+        got, want = got.double().reshape(want.shape), want.double()
+        e_max = float((got - want).abs().max()) / (float(want.abs().max()) + 1e-30)
+        e_rms = float((got - want).pow(2).mean().sqrt()) / (float(want.pow(2).mean().sqrt()) + 1e-30)
+        worst[name] = max(worst.get(name, (0, 0)), (e_max, e_rms))
+        assert e_max <= rel and e_rms <= rms, (fam, name, e_max, e_rms)
+
+    for i in range(b):
+        xi, ri = x[i].double(), xdbl[i].double().view(l, k, rg)
+        u = torch.stack([xi[tbl[j]].t() for j in range(k)]).reshape(1, k * d, l)                # (1, KD, L)
+        rows = torch.stack([ri[tbl[j], j] for j in range(k)])                                    # (K, L, RG)
+        delta = torch.einsum("klr,kdr->kdl", rows[..., :r], dt_w.double()).reshape(1, k * d, l)
+        Bm, Cm = rows[..., rg - 4].reshape(1, k, 1, l), rows[..., rg - 3].reshape(1, k, 1, l)
+        dout = torch.stack([gym[i].double()[tbl[j]].t() for j in range(k)]).reshape(1, k * d, l)
+        du, dd, dA, dB, dC, dD, dbias = oss.selective_scan_bwd(u, delta.contiguous(), a_neg, Bm.contiguous(), Cm.contiguous(),
+                                                               ds.double().reshape(-1), dt_b.double().reshape(-1), dout)
+        # 16-bit outputs: 2^-9 relative rounding on top of the kernel's fp32 arithmetic on bf16-rounded rank rows
+        close(gu[i].permute(0, 2, 1), du.reshape(k, d, l), "gu", 3e-2, 8e-3)
+        close(graw[i].permute(0, 2, 1), dd.reshape(k, d, l), "graw", 3e-2, 8e-3)
+        close(gB[i], dB.reshape(k, l), "gB", 3e-2, 8e-3)
+        close(gC[i], dC.reshape(k, l), "gC", 3e-2, 8e-3)
+        close(gpar[i, 0], (dA.reshape(k, d) * a_neg.reshape(k, d)), "gA_log", 3e-2, 8e-3)
+        close(gpar[i, 1], dD.reshape(k, d), "gD", 3e-2, 8e-3)
+        close(gpar[i, 2], dbias.reshape(k, d), "gbias", 3e-2, 8e-3)
+    print("scan backward vs fp64 oracle (max / rms relative):", fam, h, {n: (round(a, 5), round(c, 5)) for n, (a, c) in worst.items()})
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -22,6 +22,20 @@ void set_error(const char *fmt, ...);
         }                                       \
     } while (0)
 
+// Device error word: ONE 32-bit word in host-mapped (coherent) memory that a kernel raises on a failure it cannot report any
+// other way -- today the carry mailbox of the fused scans running out of polls (ss2d_fused.hip, CarryLink::acquire).  The host
+// never synchronises for it: every entry point reads the word after its launch (TRAMBA_LAUNCH_CHECK) and, when it is set,
+// clears it, sets tramba_last_error() and returns TRAMBA_ERR_HIP -- so a poisoned (NaN) result is reported by the next library
+// call that runs after the failing kernel, or by tramba_device_error() after the caller's own synchronisation.
+#define TRAMBA_DEVERR_MAILBOX 1u
+extern unsigned *g_deverr_host;                 // null until the first kernel that can raise it is launched (runtime.hip)
+int dev_error_report(const char *file, int line);
+struct MailboxCtl {
+    unsigned *err;   // device address of the error word (null: not reported)
+    int polls;       // poll budget of CarryLink::acquire
+};
+MailboxCtl mailbox_ctl(hipStream_t s);
+
 #define TRAMBA_LAUNCH_CHECK()                                                         \
     do {                                                                              \
         hipError_t e_ = hipGetLastError();                                            \
@@ -30,6 +44,8 @@ void set_error(const char *fmt, ...);
                                 hipGetErrorString(e_));                               \
             return TRAMBA_ERR_HIP;                                                    \
         }                                                                             \
+        if (::tramba::g_deverr_host && *(volatile unsigned *)::tramba::g_deverr_host) \
+            return ::tramba::dev_error_report(__FILE__, __LINE__);                    \
     } while (0)
 
 // ---- profiling hooks (HIP events around one kernel class; see tramba_profile_enable) ----

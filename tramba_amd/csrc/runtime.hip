@@ -52,17 +52,67 @@ ProfScope::~ProfScope()
     g_prof[which].events.emplace_back(start, stop);
 }
 
+// ---------------------------------------------------------------- device error word (common.h)
+unsigned *g_deverr_host = nullptr;
+static unsigned *g_deverr_dev = nullptr;
+static std::once_flag g_deverr_once;
+
+static void deverr_alloc()
+{
+    unsigned *h = nullptr, *d = nullptr;
+    // coherent host memory mapped into every device of the process (one process per GPU is the deployment form)
+    if (hipHostMalloc((void **)&h, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    *h = 0u;
+    if (hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(h);
+        return;
+    }
+    g_deverr_dev = d;
+    g_deverr_host = h;
+}
+
+MailboxCtl mailbox_ctl(hipStream_t s)
+{
+    if (!g_deverr_host) {
+        // never allocate while the stream records a graph (an allocation is not a stream operation, and under the global
+        // capture mode it invalidates the capture): a model's eager warm-up launches come first and allocate
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone) std::call_once(g_deverr_once, deverr_alloc);
+    }
+    const int t = tramba_tune_get(TRAMBA_TUNE_MAILBOX_POLLS);
+    return MailboxCtl{g_deverr_dev, t > 0 ? t : (1 << 20)};
+}
+
+int dev_error_report(const char *file, int line)
+{
+    const unsigned code = __atomic_exchange_n(g_deverr_host, 0u, __ATOMIC_RELAXED);
+    if (!code) return TRAMBA_OK;
+    set_error("device error word 0x%x%s (seen at %s:%d): a kernel launched EARLIER by this library failed on the device and its "
+              "output holds NaN", code, (code & TRAMBA_DEVERR_MAILBOX) ? " [fused scan: carry mailbox timed out]" : "", file, line);
+    return TRAMBA_ERR_HIP;
+}
+
 }  // namespace tramba
 
 using namespace tramba;
 
 extern "C" const char *tramba_last_error(void) { return g_err; }
+extern "C" int tramba_device_error(void)
+{
+    if (g_deverr_host && *(volatile unsigned *)g_deverr_host) return dev_error_report("tramba_device_error", 0);
+    return TRAMBA_OK;
+}
 // 3: layernorm_bwd_parts(rows, c, dtype), shadow / slab-sum entries
 // 4: fused training entries (add_layernorm, layernorm_bwd_res, dwconv_dual, merge_grad, ss2d_bwd_prep / assemble,
 //    dw_unpack_grad); a_log / flags arguments of the fused scan forward / backward
 // 5: the step's ends and batched launches (sod_loss_*, adam_step, multi_sum / multi_sum_strided, wgrad_parts_cl,
 //    dw_pack_multi / dw_unpack_grad_multi, shuffle_norm_head_bwd_cl)
-extern "C" int tramba_abi_version(void) { return 5; }
+// 6: tramba_device_error, TRAMBA_TUNE_MAILBOX_POLLS (r04)
+extern "C" int tramba_abi_version(void) { return 6; }
 
 static int g_tune[TRAMBA_TUNE_COUNT] = {0};
 extern "C" int tramba_tune_set(int knob, int value)

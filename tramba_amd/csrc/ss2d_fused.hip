@@ -444,10 +444,12 @@ struct ScanWave {
 // polls and is bounded (a run that ever hit the bound would end with NaNs in its output, not hang the GPU).
 struct CarryLink {
     unsigned rd, wr;   // LDS byte addresses of (value[kTP], tag[kTP]) of my predecessor's / my own mailbox, at my channel
+    MailboxCtl ctl;    // poll budget + the device error word a starved poll reports to (common.h)
 
     // reverse: the chain runs from the last wave to the first (the adjoint sweep of the backward kernel)
-    __device__ __forceinline__ void init(float *box /* [W][2][kTP] */, int wv, int W, int r32, bool reverse = false)
+    __device__ __forceinline__ void init(float *box /* [W][2][kTP] */, int wv, int W, int r32, MailboxCtl c, bool reverse = false)
     {
+        ctl = c;
         const int pred = reverse ? (wv == W - 1 ? 0 : wv + 1) : (wv == 0 ? W - 1 : wv - 1);
         rd = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(box + (pred * 2) * kTP + r32);
         wr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(box + (wv * 2) * kTP + r32);
@@ -461,7 +463,7 @@ struct CarryLink {
         float v;
         unsigned t;
         int guard = 0;
-        for (; guard < (1 << 20); ++guard) {
+        for (; guard < ctl.polls; ++guard) {
             asm volatile("ds_read_b32 %0, %2 offset:128\n\tds_read_b32 %1, %2\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(t), "=&v"(v)
                          : "v"(rd)
@@ -469,8 +471,13 @@ struct CarryLink {
             if (__builtin_amdgcn_ballot_w64(t != base + (unsigned)tile) == 0) break;
             __builtin_amdgcn_s_sleep(1);
         }
-        // (a wave that ever ran out of polls -- ~0.1 s -- hands on NaN: the launch ends, and its output cannot pass for a result)
-        return guard < (1 << 20) ? v : __builtin_nanf("");
+        // A wave that ever ran out of polls (~0.1 s at the default budget) hands on NaN -- the launch ends, and its output cannot
+        // pass for a result -- and raises the library's device error word (host-mapped memory, one system-scope atomic on this
+        // path only): the next library call that finds it set returns TRAMBA_ERR_HIP (TRAMBA_LAUNCH_CHECK; no sync is added).
+        if (guard < ctl.polls) return v;
+        if (ctl.err && (threadIdx.x & 63) == 0)
+            __hip_atomic_fetch_or(ctl.err, TRAMBA_DEVERR_MAILBOX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return __builtin_nanf("");
 #else
         return 0.f;
 #endif
@@ -499,8 +506,8 @@ template <typename T, typename TY, int NK, bool SPLIT, bool SAVE = false>
 __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
-    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W, float *__restrict__ hst = nullptr,
-    int a_log = 0)
+    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W, float *__restrict__ hst, int a_log,
+    MailboxCtl mctl)
 {
     __shared__ float mbox[kMaxW][2][kTP];   // carry mailboxes (CarryLink): value, tag per wave and channel
     __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     ScanWave<T, NK, SPLIT> w;
     w.init(dt_w, dt_bias, Aneg, Ds, (long)k * D + cc_, R, RG, PC, D, lane, cc_, &stage[wv][0][0], a_log);
     CarryLink link;
-    link.init(&mbox[0][0][0], wv, W, r32);
+    link.init(&mbox[0][0][0], wv, W, r32, mctl);
 
     // wave-uniform descriptors (host guarantees every extent < 2^31 bytes)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
@@ -632,8 +639,8 @@ template <typename T, typename TY, int NK, int R8, int W, bool SAVE = false>
 __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kernel(
     const T *__restrict__ x, const float *__restrict__ xdbl, const int32_t *__restrict__ table,
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
-    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, float *__restrict__ hst = nullptr,
-    int a_log = 0)
+    const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, float *__restrict__ hst, int a_log,
+    MailboxCtl mctl)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass needs this kernel's launch stub, not its body, and hipcc
                                       // silently drops the stub of a kernel template whose body holds vector-register asm
@@ -675,7 +682,7 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
         if (hi) w.wh[0] = f;
     }
     CarryLink link;
-    link.init(&mbox[0][0][0], wv, W, r32);
+    link.init(&mbox[0][0][0], wv, W, r32, mctl);
     for (int i = threadIdx.x; i < 2 * W * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;   // tags: nothing published
     __syncthreads();   // the only workgroup barrier of the kernel
 
@@ -860,7 +867,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     const float *__restrict__ dt_w, const float *__restrict__ dt_bias, const float *__restrict__ Aneg,
     const float *__restrict__ Ds, const TG *__restrict__ gym, T *__restrict__ gu, T *__restrict__ graw,
     float *__restrict__ gB, float *__restrict__ gC, float *__restrict__ gpar, float *__restrict__ hst, int L, int D,
-    int K, int R, int W, int bcs, int have_states, int flags)
+    int K, int R, int W, int bcs, int have_states, int flags, MailboxCtl mctl)
 {
     // flags & 1: `Aneg` holds A_logs (see ScanWave::init) and gpar's first plane leaves as dL/dA_logs = dL/dA * A
     // flags & 2: gB / gC are (B, K, CT, L) tables of per-channel-tile partial sums, each element WRITTEN by exactly one wave
@@ -901,8 +908,8 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     for (int i = threadIdx.x; i < 2 * kMaxW * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;   // tags: nothing published
     __syncthreads();
     CarryLink fwd_link, adj_link;
-    fwd_link.init(&mbox[0][0][0], wv, W, r32);
-    adj_link.init(&mbox[0][0][0], wv, W, r32, true);
+    fwd_link.init(&mbox[0][0][0], wv, W, r32, mctl);
+    adj_link.init(&mbox[0][0][0], wv, W, r32, mctl, true);
     const unsigned adj_base = (unsigned)(nsuper * W);   // the adjoint chain's tags lie above the forward chain's
 
     auto load_idx = [&](int s) -> int {
@@ -1691,12 +1698,12 @@ static void launch_scan_dma(dim3 grid, dim3 block, hipStream_t s, const void *x,
     if constexpr (std::is_same<T, TY>::value) {
         if (states) {
             hipLaunchKernelGGL((ss2d_scan_dma_kernel<T, TY, NK, R8, W, true>), grid, block, 0, s, (const T *)x, xdbl, table,
-                               dt_w, dt_bias, A, Ds, (TY *)ys, l, d, k, r, states, a_log);
+                               dt_w, dt_bias, A, Ds, (TY *)ys, l, d, k, r, states, a_log, mailbox_ctl(s));
             return;
         }
     }
     hipLaunchKernelGGL((ss2d_scan_dma_kernel<T, TY, NK, R8, W>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, dt_bias, A,
-                       Ds, (TY *)ys, l, d, k, r, (float *)nullptr, a_log);
+                       Ds, (TY *)ys, l, d, k, r, (float *)nullptr, a_log, mailbox_ctl(s));
 }
 
 template <typename T, typename TY, int NK, bool SP>
@@ -1707,12 +1714,12 @@ static void launch_scan_ring(dim3 grid, dim3 block, hipStream_t s, const void *x
     if constexpr (std::is_same<T, TY>::value) {
         if (states) {
             hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK, SP, true>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w,
-                               dt_bias, A, Ds, (TY *)ys, l, d, k, r, W, states, a_log);
+                               dt_bias, A, Ds, (TY *)ys, l, d, k, r, W, states, a_log, mailbox_ctl(s));
             return;
         }
     }
     hipLaunchKernelGGL((ss2d_scan_cl_kernel<T, TY, NK, SP>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, dt_bias, A, Ds,
-                       (TY *)ys, l, d, k, r, W, (float *)nullptr, a_log);
+                       (TY *)ys, l, d, k, r, W, (float *)nullptr, a_log, mailbox_ctl(s));
 }
 
 extern "C" int tramba_ss2d_scan_cl(const void *x, const float *xdbl, const int32_t *table,
@@ -1892,7 +1899,7 @@ extern "C" int tramba_ss2d_scan_bwd_cl(const void *x, const float *xdbl, const i
 #define BWD_G_(T, NK_, SP_, TG)                                                                                     \
     hipLaunchKernelGGL((ss2d_scan_bwd_cl_kernel<T, NK_, SP_, TG>), grid, block, 0, s, (const T *)x, xdbl, table, dt_w, \
                        dt_bias, A, Ds, (const TG *)gym, (T *)gu, (T *)graw, gB, gC, gpar, (float *)workspace, l, d, k, r, W, bc_stride, \
-                       have_states, flags)
+                       have_states, flags, mailbox_ctl(s))
 #define BWD_(T, NK_, SP_)                                                          \
     if (gym_dtype == TRAMBA_F32) { BWD_G_(T, NK_, SP_, float); } else { BWD_G_(T, NK_, SP_, T); }
 #define BWD_NK_(T, SP_)                \

@@ -30,6 +30,7 @@ c_int, c_i64, c_f, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c
 SIGNATURES = {
     "tramba_last_error": (ctypes.c_char_p, []),
     "tramba_abi_version": (c_int, []),
+    "tramba_device_error": (c_int, []),
     "tramba_tune_set": (c_int, [c_int, c_int]),
     "tramba_tune_get": (c_int, [c_int]),
     "tramba_profile_enable": (c_int, [c_int, c_int]),
@@ -244,7 +245,13 @@ def scan_order(family: str, h: int, w: int, device, param: int = 0) -> ScanOrder
 
 
 # ----------------------------------------------------------------------------- profiling / tuning
-TUNE_MERGE_FORM, TUNE_SCAN_FORM, TUNE_SCAN_W, TUNE_GEMM_TILE = 0, 1, 2, 3
+TUNE_MERGE_FORM, TUNE_SCAN_FORM, TUNE_SCAN_W, TUNE_GEMM_TILE, TUNE_MAILBOX_POLLS = 0, 1, 2, 3, 4
+
+
+def device_error():
+    """raise TrambaHipError if a kernel launched earlier raised the library's device error word (tramba_device_error: a fused
+    scan whose carry mailbox timed out leaves NaN in its output); call after a synchronisation to be certain"""
+    _check(lib().tramba_device_error(), "device_error")
 
 
 def tune_set(knob: int, value: int):
