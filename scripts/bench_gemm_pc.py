@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""The model's GEMM shapes at batch 4 and 8, hipGraph-timed (20 launches per replay, interleaved forms), per TRAMBA_TUNE_GEMM_TILE
+form: 18 = the LDS-DMA kernel as in r03 (no producer / consumer form), 16 / 17 = linear_pc_kernel on 3 / 4 stages, 0 = the library's
+choice.  Plain (bias + residual), LayerNorm-folded and dual-output (GELU) entry points; results must be bit-identical across forms
+(`DIFF` otherwise).  Output: profiles/r04_gemm_pc.txt."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tramba_amd import hip
+dev = torch.device("cuda")
+FORMS = [int(v) for v in sys.argv[1:]] or [18, 16, 17, 0]
+SHAPES = [(2304, 512, 1024), (2304, 512, 2048), (2304, 1024, 512), (2304, 2048, 512), (2304, 136, 1024), (576, 1024, 2048),
+          (576, 1024, 4096), (576, 4096, 1024), (576, 2048, 1024), (9216, 256, 512), (9216, 256, 1024), (9216, 1024, 256),
+          (9216, 512, 256), (36864, 128, 512), (36864, 512, 128), (36864, 256, 128), (36864, 128, 256),
+          (4608, 512, 1024), (4608, 512, 2048), (4608, 1024, 512), (4608, 2048, 512), (1152, 1024, 2048),
+          (1152, 4096, 1024), (18432, 256, 1024), (18432, 512, 256), (73728, 512, 128), (73728, 128, 512)]
+
+
+def timed(fns):
+    """every fn captured as a graph of 20 launches; replayed alternately, 3 rounds: min us per launch"""
+    graphs, outs = [], []
+    for fn in fns:
+        for _ in range(3):
+            y = fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                keep = fn()
+        g.replay()
+        torch.cuda.synchronize()
+        graphs.append(g)
+        outs.append(y)
+    best = [1e9] * len(fns)
+    for _ in range(3):
+        for i, g in enumerate(graphs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); g.replay(); g.replay(); e1.record(); torch.cuda.synchronize()
+            best[i] = min(best[i], e0.elapsed_time(e1) / 40 * 1e3)
+    return best, outs
+
+
+def with_form(form, fn):
+    def run():
+        hip.tune_set(hip.TUNE_GEMM_TILE, form)
+        try:
+            return fn()
+        finally:
+            hip.tune_set(hip.TUNE_GEMM_TILE, 0)
+    return run
+
+
+tot = {f: 0.0 for f in FORMS}
+for m, n, k in SHAPES:
+    x = torch.randn(m, k, device=dev).bfloat16()
+    w = (torch.randn(n, k, device=dev) * k ** -0.5).bfloat16()
+    b = torch.randn(n, device=dev)
+    r = torch.randn(m, n, device=dev).bfloat16()
+    cs = w.float().sum(dim=1).contiguous()
+    line = f"M={m:6d} N={n:5d} K={k:5d} tiles {-(-m // 64) * -(-n // 64):5d} |"
+    kinds = [("plain", lambda: hip.linear_cl(x, w, b, r, 0))]
+    if k <= 2048 and n % 8 == 0:
+        kinds.append(("ln", lambda: hip.linear_ln_cl(x, w, cs, b, 1e-5, None, 2)))
+    if n % 8 == 0 and n >= 512:
+        kinds.append(("dual", lambda: hip.linear_dual_cl(x, w, b, hip.ACT_GELU)[1]))
+    for name, fn in kinds:
+        us, ys = timed([with_form(f, fn) for f in FORMS])
+        line += f"  {name}:"
+        for f, u, y in zip(FORMS, us, ys):
+            line += f" f{f} {u:5.1f}{'' if torch.equal(y, ys[0]) else ' DIFF'}"
+            if name == "plain":
+                tot[f] += u
+    print(line, flush=True)
+print("sum of the plain launches, us:", {f: round(v, 1) for f, v in tot.items()})

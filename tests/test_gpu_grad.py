@@ -98,12 +98,26 @@ def tramba_v_grad_oracle():
     return m, x, label, gp
 
 
+# the bf16 parameter gradients that sit outside (cosine >= 0.999, norm ratio within 2 %) and inside the hard bound (0.998, 4 %),
+# measured on MI355X in r03 (scripts/exp_grad_noise.py) and again in r04 (profiles/r04_parity_measurements.txt):
+#   layers.2.blocks.3.op.x_proj_weight   cos 0.99923  ratio 1.0208   (small gradient deep in the 15-block stage: rounding noise adds
+#   layers.3.blocks.0.op.x_proj_weight   cos 0.99989  ratio 1.0212    to its norm)
+#   guide_layers.0.attn.l_ssm.dt_projs_weight   cos 0.99872  ratio 1.0055   (24x24 Dual-Frequency block)
+#   guide_layers.0.attn.h_ssm.dt_projs_weight   cos 0.99893  ratio 1.0087
+BF16_GRAD_OUTLIERS = {
+    "vssm_encoder.layers.2.blocks.3.op.x_proj_weight",
+    "vssm_encoder.layers.3.blocks.0.op.x_proj_weight",
+    "decoder.guide_layers.0.attn.l_ssm.dt_projs_weight",
+    "decoder.guide_layers.0.attn.h_ssm.dt_projs_weight",
+}
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_tramba_v_parameter_gradients_against_oracle_autograd(tramba_v_grad_oracle, dtype):
     """the full training graph (train.py:74-89: forward, deep-supervision loss, backward) on Tramba-V: EVERY parameter's
     gradient against the oracle's.  fp32: relative L2 error per tensor <= 1e-3.  bf16 activations (fp32 master weights and
     accumulators): norm ratio within 4 % and cosine >= 0.998 for every one of the 673 tensors, within 2 % and >= 0.999 for
-    all but at most 4 of them (measured, scripts/exp_grad_noise.py: 670 of 673; the cosines below are dt_projs_weight of the
+    all but the four NAMED in BF16_GRAD_OUTLIERS (measured, scripts/exp_grad_noise.py: 670 of 673; the cosines below are dt_projs_weight of the
     24x24 Dual-Frequency block, 0.9987; the largest norm ratios are x_proj_weight / A_logs of the 15-block stage, 1.015-1.025.
     The worst of them, layers.2.blocks.3.op.x_proj_weight, read 1.0185 / 1.0207 / 1.0251 on three builds that differ only in
     the ORDER of fp32 sums -- an fp32 or bf16 intermediate in the DCT backward, the K-split dt-rank projection: the rounding
@@ -137,7 +151,9 @@ def test_tramba_v_parameter_gradients_against_oracle_autograd(tramba_v_grad_orac
                 bad[n] = (round(cos, 5), round(ratio, 4))
     if dtype != torch.float32:
         print("bf16 gradient tensors outside 2 % / 0.999:", bad)
-        assert len(bad) <= 4, (len(bad), dict(list(bad.items())[:12]))
+        # only THESE tensors may sit between the two bounds (name them, do not count them); a fifth one fails
+        stray = sorted(set(bad) - BF16_GRAD_OUTLIERS)
+        assert not stray, (stray, {n: bad[n] for n in stray})
         bad = {n: v for n, v in bad.items() if v[0] < 0.998 or abs(v[1] - 1.0) > 0.04}
     assert not bad, (len(bad), dict(list(bad.items())[:12]))
     m.compute_dtype = None

@@ -232,6 +232,53 @@ def test_linear_cl_short_k_on_two_lds_stages(dtype, mnk):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("form", [16, 17])
+@pytest.mark.parametrize("mnk", [(2304, 512, 1024), (2304, 512, 2048), (2304, 2048, 512), (4608, 512, 2048), (2300, 520, 640),
+                                 (100, 64, 576), (96, 72, 64), (576, 1024, 2048), (36864, 512, 128), (9216, 256, 192)])
+def test_linear_cl_producer_consumer_form(dtype, form, mnk):
+    """linear_pc_kernel (r04: 512-thread workgroups, waves 0-3 multiply, waves 4-7 fetch by LDS-DMA; 3 / 4 LDS stages =
+    TRAMBA_TUNE_GEMM_TILE 16 / 17): fp64 on the same 16-bit inputs, ragged M / N and every K-loop tail (K / 64 = 1, 2, 3, 8, 9,
+    10, 16, 32), and BIT-identical to the r03 kernel (form 18: the same products added in the same order) for the plain, fp32-out,
+    LayerNorm-folded and dual-output launches; run twice (bitwise run to run)."""
+    m, n, k = mnk
+    H = hip()
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) + torch.arange(k)[None, :] * 0.002).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dtype).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(m, n, generator=g).to(dtype).to(DEV)
+    want = F.gelu(x.double() @ w.double().T + bias.double()) + res.double()
+    colsum = w.float().sum(dim=1).contiguous()
+
+    def run():
+        out = [H.linear_cl(x, w, bias, res, 2), H.linear_cl(x, w, None, None, 0, out_dtype=torch.float32)]
+        if n % 8 == 0:
+            out.append(H.linear_ln_cl(x, w, colsum, bias, 1e-5, res, 2))
+        if H.linear_dual_ok(x, w):
+            out += list(H.linear_dual_cl(x, w, bias, 2))
+        return out
+
+    try:
+        H.tune_set(H.TUNE_GEMM_TILE, 18)
+        old = run()
+        H.tune_set(H.TUNE_GEMM_TILE, form)
+        got = run()
+        again = run()
+    finally:
+        H.tune_set(H.TUNE_GEMM_TILE, 0)
+    np.testing.assert_allclose(got[0].cpu().double().numpy(), want.cpu().numpy(), rtol=2e-2,
+                               atol=2e-2 * max(1.0, float(want.abs().max())))
+    if n % 8 == 0:      # LayerNorm folded in: LN(x) W^T with gamma = 1, beta = 0
+        xn = torch.nn.functional.layer_norm(x.double(), (k,))
+        want_ln = F.gelu(xn @ w.double().T + bias.double()) + res.double()
+        np.testing.assert_allclose(got[2].cpu().double().numpy(), want_ln.cpu().numpy(), rtol=3e-2,
+                                   atol=3e-2 * max(1.0, float(want_ln.abs().max())))
+    assert len(got) == len(old) >= 2
+    for a, b, c in zip(got, old, again):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("mnk", [(2304, 512, 1024), (2304, 2048, 512), (4608, 512, 2048), (2300, 520, 640), (100, 64, 576), (96, 72, 64),
                                  (576, 1024, 2048)])
 def test_linear_cl_on_96_row_tiles(dtype, mnk):
@@ -796,14 +843,15 @@ def test_ss2d_scan_backward_at_the_benchmarked_launches(fam, b, h, d, r):
         dout = torch.stack([gym[i].double()[tbl[j]].t() for j in range(k)]).reshape(1, k * d, l)
         du, dd, dA, dB, dC, dD, dbias = oss.selective_scan_bwd(u, delta.contiguous(), a_neg, Bm.contiguous(), Cm.contiguous(),
                                                                ds.double().reshape(-1), dt_b.double().reshape(-1), dout)
-        # 16-bit outputs: 2^-9 relative rounding on top of the kernel's fp32 arithmetic on bf16-rounded rank rows
-        close(gu[i].permute(0, 2, 1), du.reshape(k, d, l), "gu", 3e-2, 8e-3)
-        close(graw[i].permute(0, 2, 1), dd.reshape(k, d, l), "graw", 3e-2, 8e-3)
-        close(gB[i], dB.reshape(k, l), "gB", 3e-2, 8e-3)
-        close(gC[i], dC.reshape(k, l), "gC", 3e-2, 8e-3)
-        close(gpar[i, 0], (dA.reshape(k, d) * a_neg.reshape(k, d)), "gA_log", 3e-2, 8e-3)
-        close(gpar[i, 1], dD.reshape(k, d), "gD", 3e-2, 8e-3)
-        close(gpar[i, 2], dbias.reshape(k, d), "gbias", 3e-2, 8e-3)
+        # 16-bit outputs: 2^-9 relative rounding on top of the kernel's fp32 arithmetic on bf16-rounded rank rows.  Measured on
+        # MI355X (r04): max 0.003-0.006 of the largest element, RMS 0.0018 (gu, graw) / 0.001 (the sums); bounds = ~2.5x that
+        close(gu[i].permute(0, 2, 1), du.reshape(k, d, l), "gu", 1.5e-2, 4.5e-3)
+        close(graw[i].permute(0, 2, 1), dd.reshape(k, d, l), "graw", 1.2e-2, 4.5e-3)
+        close(gB[i], dB.reshape(k, l), "gB", 8e-3, 2.5e-3)
+        close(gC[i], dC.reshape(k, l), "gC", 5e-3, 2.5e-3)
+        close(gpar[i, 0], (dA.reshape(k, d) * a_neg.reshape(k, d)), "gA_log", 5e-3, 2.5e-3)
+        close(gpar[i, 1], dD.reshape(k, d), "gD", 5e-3, 2.5e-3)
+        close(gpar[i, 2], dbias.reshape(k, d), "gbias", 5e-3, 2.5e-3)
     print("scan backward vs fp64 oracle (max / rms relative):", fam, h, {n: (round(a, 5), round(c, 5)) for n, (a, c) in worst.items()})
 
 

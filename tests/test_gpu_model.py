@@ -136,14 +136,16 @@ def test_tramba_v_fp32_matches_reference_golden(golden, golden_meta, tramba_v):
     assert round(oo.mae_metric(pred, gt), 4) == round(golden_meta["G5_tramba_v_mae"], 4)
 
 
-# north_star: "MAE metric unchanged to 4 d.p." -- i.e. |dMAE| < 5e-5.  Measured on MI355X (printed by the tests below, r04).
-MAE_TOL = {torch.bfloat16: 5e-4, torch.float16: 5e-4}
+# north_star: "MAE metric unchanged to 4 d.p." -- i.e. |dMAE| < 5e-5 -- holds in the 16-bit modes too.  Measured on MI355X (printed by
+# the tests below, r04; profiles/r04_parity_measurements.txt): 384x384 bf16 1.0e-5, fp16 3.0e-6; 768x768 fp16 1.1e-5, fp32 0.
+MAE_TOL = {torch.bfloat16: 5e-5, torch.float16: 5e-5}
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_tramba_v_low_precision_keeps_mae(golden_meta, dtype):
-    """bf16/fp16 inference keeps the MAE of the fp32 reference to 5e-4.  (A weak check by itself -- the golden map is at
-    chance level, MAE 0.516 -- the element-wise test below is the one that sees wrong logits.)"""
+    """bf16/fp16 inference keeps the MAE of the fp32 reference to 4 decimal places (north_star's contract; |dMAE| < 5e-5).  (A weak
+    check by itself -- the golden map is at chance level, MAE 0.516 -- the element-wise test below is the one that sees wrong
+    logits.)"""
     import tramba_amd as ta
     m = ta.bulid_model(deep_supervision=True, use_pretrain=False, img_size=384)
     m = ta.prepare_inference(_load_synth(m), dtype)
@@ -556,7 +558,8 @@ def c5_oracle():
 
 # fp16 at 768x768 (L up to 36 864), relative to the RMS of each reference map: (max-abs, RMS, decision flips); measured on
 # MI355X (printed by the test, r04), asserted with ~1.6x headroom like LOWP_TOL at 384x384
-LOWP_TOL_768 = {torch.float16: (0.04, 0.01, 0.012), torch.float32: (5e-4, 5e-5, 2e-4)}
+# measured (r04): max-abs 0.006-0.013, RMS 0.0014-0.0033, flips 0.0002-0.0005
+LOWP_TOL_768 = {torch.float16: (0.022, 0.0055, 0.001), torch.float32: (5e-4, 5e-5, 2e-4)}
 
 
 def test_tramba_v_768_fp16_long_sequence_against_oracle(c5_oracle):
