@@ -279,6 +279,66 @@ def test_linear_cl_producer_consumer_form(dtype, form, mnk):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mnk", [(36864, 512, 128), (36864, 256, 128), (36864, 128, 256), (9216, 1024, 256), (9216, 512, 256),
+                                 (4100, 256, 128), (9216, 384, 128), (33, 128, 256), (73728, 128, 128), (2304, 512, 256)])
+def test_linear_cl_weight_stationary_form(dtype, mnk):
+    """linear_ws_kernel (r04: persistent workgroups, the weights of a 128 NCW-column panel held in registers as MFMA fragments,
+    32-row activation tiles on an LDS-DMA ring, epilogue straight from the accumulators; TRAMBA_TUNE_GEMM_TILE 19 forces it
+    wherever it can run): fp64 on the same 16-bit inputs, NCW = 4 / 2 / 1, several panels, ragged M (4100 = 128 tiles + 4 rows,
+    33 = one tile + 1 row), work lists of 1 .. 5 tiles per workgroup.  The plain (bias + GELU + residual), SiLU, bias-free and
+    dual-output launches are BIT-identical to the r03 kernel (form 18: same products, same order, same epilogue formulas);
+    the LayerNorm-folded launch sums its row statistics in another order (from the MFMA fragments) and is held to fp64
+    within the GEMM tolerance and to the r03 kernel within 2 ulp of the output dtype; twice = bitwise run to run."""
+    m, n, k = mnk
+    H = hip()
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) + torch.arange(k)[None, :] * 0.002).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dtype).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(m, n, generator=g).to(dtype).to(DEV)
+    colsum = w.float().sum(dim=1).contiguous()
+
+    def run():
+        out = [H.linear_cl(x, w, bias, res, 2), H.linear_cl(x, w, bias, None, 1), H.linear_cl(x, w, None, None, 0),
+               H.linear_cl(x, w, bias, res, 0)]
+        if H.linear_dual_ok(x, w):
+            out += list(H.linear_dual_cl(x, w, bias, 2))
+        out.append(H.linear_ln_cl(x, w, colsum, bias, 1e-5, None, 2))
+        out.append(H.linear_ln_cl(x, w, colsum, bias, 1e-5, res, 0))
+        return out
+
+    try:
+        H.tune_set(H.TUNE_GEMM_TILE, 18)
+        old = run()
+        H.tune_set(H.TUNE_GEMM_TILE, 19)
+        got = run()
+        again = run()
+    finally:
+        H.tune_set(H.TUNE_GEMM_TILE, 0)
+    torch.cuda.synchronize()
+    H.device_error()
+    want = F.gelu(x.double() @ w.double().T + bias.double()) + res.double()
+    np.testing.assert_allclose(got[0].cpu().double().numpy(), want.cpu().numpy(), rtol=2e-2,
+                               atol=2e-2 * max(1.0, float(want.abs().max())))
+    xn = torch.nn.functional.layer_norm(x.double(), (k,))
+    want_ln = F.gelu(xn @ w.double().T + bias.double())
+    np.testing.assert_allclose(got[-2].cpu().double().numpy(), want_ln.cpu().numpy(), rtol=3e-2,
+                               atol=3e-2 * max(1.0, float(want_ln.abs().max())))
+    want_ln2 = xn @ w.double().T + bias.double() + res.double()
+    np.testing.assert_allclose(got[-1].cpu().double().numpy(), want_ln2.cpu().numpy(), rtol=3e-2,
+                               atol=3e-2 * max(1.0, float(want_ln2.abs().max())))
+    assert len(got) == len(old)
+    for i, (a, b, c) in enumerate(zip(got, old, again)):
+        assert torch.equal(a, c), i
+        if i < len(got) - 2:
+            assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+        else:       # LayerNorm folded in: statistics summed in another order
+            d = (a.float() - b.float()).abs()
+            ulp = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * b.float().abs().clamp_min(1.0)
+            assert bool((d <= 2 * ulp).all()), (i, float(d.max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("mnk", [(2304, 512, 1024), (2304, 2048, 512), (4608, 512, 2048), (2300, 520, 640), (100, 64, 576), (96, 72, 64),
                                  (576, 1024, 2048)])
 def test_linear_cl_on_96_row_tiles(dtype, mnk):

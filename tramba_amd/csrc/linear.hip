@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace tramba {
@@ -1032,7 +1034,9 @@ __global__ __launch_bounds__(512) void linear_pc_kernel(const T *__restrict__ x,
     acc16_t acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    // LNIN: loader thread lt adds the 16-byte pieces at chunk POSITION lt & 7 of rows lt >> 3 and (lt >> 3) + 32 at every K step
+    // LNIN: multiplier thread lt adds the 16-byte pieces at chunk POSITION lt & 7 of rows lt >> 3 and (lt >> 3) + 32 at every K
+    // step, two more ds_read_b128 issued in front of its eight fragment reads (as in linear_dma_kernel; read by the loader
+    // waves instead, the statistics sat between their DMA issue and the next barrier: 10-20 % slower on the many-tile shapes)
     const int lt = tid & 255;
     float rs1[2] = {0.f, 0.f}, rs2[2] = {0.f, 0.f};
     const unsigned sad = lbase + (unsigned)((lt >> 3) * 128 + (lt & 7) * 16);
@@ -1062,23 +1066,15 @@ __global__ __launch_bounds__(512) void linear_pc_kernel(const T *__restrict__ x,
         asm volatile("" ::: "memory");
         if (loader) {
             if (kt + DEPTH < nk) issue(kt + DEPTH, (STG + DEPTH) % NSTG);
+        } else {
+            frag8_t a[4], b[4];
+            v4u_t sv[2];
             if constexpr (LNIN) {
-                v4u_t sv[2];
                 if constexpr (STG == 0) { TRAMBA_DSR128_(sv[0], sad, 0); TRAMBA_DSR128_(sv[1], sad, 4096); }
                 else if constexpr (STG == 1) { TRAMBA_DSR128_(sv[0], sad, 16384); TRAMBA_DSR128_(sv[1], sad, 20480); }
                 else if constexpr (STG == 2) { TRAMBA_DSR128_(sv[0], sad, 32768); TRAMBA_DSR128_(sv[1], sad, 36864); }
                 else { TRAMBA_DSR128_(sv[0], sad, 49152); TRAMBA_DSR128_(sv[1], sad, 53248); }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sv[0]), "+v"(sv[1]) : : "memory");
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        rs1[i] = dot2_ones<T>(sv[i][e], rs1[i]);
-                        rs2[i] = dot2_self<T>(sv[i][e], rs2[i]);
-                    }
             }
-        } else {
-            frag8_t a[4], b[4];
 #define TRAMBA_RD_STG_(S)                                                                            \
     TRAMBA_DSR128_(a[0], aad[0], S); TRAMBA_DSR128_(b[0], bad[0], S); TRAMBA_DSR128_(a[1], aad[1], S); \
     TRAMBA_DSR128_(b[1], bad[1], S); TRAMBA_DSR128_(a[2], aad[2], S); TRAMBA_DSR128_(b[2], bad[2], S); \
@@ -1089,6 +1085,16 @@ __global__ __launch_bounds__(512) void linear_pc_kernel(const T *__restrict__ x,
             else { TRAMBA_RD_STG_(49152); }
 #undef TRAMBA_RD_STG_
             // counted waits: slice kk needs the first 2 (kk + 1) reads; every destination is named so that no MFMA moves above
+            if constexpr (LNIN) {   // (the two statistics reads were issued first: they are done once eight reads remain)
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(sv[0]), "+v"(sv[1]) : : "memory");
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        rs1[i] = dot2_ones<T>(sv[i][e], rs1[i]);
+                        rs2[i] = dot2_self<T>(sv[i][e], rs2[i]);
+                    }
+            }
             // (sched_barrier: without it hipcc sinks the first MFMA below the NEXT wait -- legal, the waits only grow stricter --
             //  and the four MFMAs start two reads later than they could)
             asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0]), "+v"(b[0]) : : "memory");
@@ -1119,7 +1125,7 @@ __global__ __launch_bounds__(512) void linear_pc_kernel(const T *__restrict__ x,
     __syncthreads();                                       // every wave has read the last tile: the epilogue reuses the LDS
     if constexpr (LNIN) {
         float2 *rowstat = reinterpret_cast<float2 *>(lds + LDS_BYTES);   // read by the epilogue behind its own barrier
-        if (loader) {
+        if (!loader) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float s1 = rs1[i], s2 = rs2[i];
@@ -1303,11 +1309,372 @@ static bool tile96_dma(long m, int n, int k, int tile_tune)
     return tile_tune == 15 && m >= 96 && (m + 95) / 96 <= 65535;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// r04: WEIGHT-STATIONARY form for the tall short-K layers (the 96 x 96 / 48 x 48 stages: M = 9216 .. 73728 rows, K = 128 / 256).
+// The tile kernels above treat such a layer as thousands of independent 64 x 64 tiles: every tile pays a prologue round trip,
+// re-fetches its 64 x K slice of W, drops its accumulators into an fp32 LDS tile and re-reads them for the store (r03: 51 VALU
+// instructions per MFMA, 25 us for M = 36864, N = 512, K = 128 against a 9 us HBM floor).  Here a workgroup is PERSISTENT and
+// the weights never move again:
+//   * 4 waves own a PANEL of 128 NCW columns (NCW = 4 / 2 / 1 column blocks of 32 per wave, NCW * K <= 512): every wave loads
+//     its NCW x K/16 MFMA B-fragments ONCE into registers (<= 128 VGPRs) and keeps them;
+//   * the workgroup then walks its list of 32-row tiles (tile = g + i * G: neighbouring workgroups stream neighbouring rows);
+//     the 32 x K activation tiles travel L2 -> LDS by `buffer_load ... lds` on a 4-stage ring, three tiles ahead, every wave
+//     fetching K/64 1 KB pieces per tile, the 16-byte chunk c of row r stored at position c ^ (r & 15) (applied on the
+//     global side, undone in the ds_read_b128 addresses: the 16 rows of a read group land on 16 different bank groups);
+//   * per tile: K/16 fragment reads (shared by the wave's NCW column blocks), NCW K/16 MFMAs with swapped operands (a lane
+//     then owns ONE output row and 4-column groups), and the epilogue STRAIGHT FROM THE ACCUMULATORS: bias / folded-LayerNorm
+//     terms from a panel-wide LDS table, activation, optional residual, two packed conversions per 4 columns,
+//     v_permlane32_swap pairs so that each lane holds 8 consecutive columns, one 16-byte store per lane -- no fp32 staging
+//     tile, no workgroup barrier inside the epilogue;
+//   * one s_barrier per tile (tile t is in LDS for everyone; everyone has read tile t - 1), vector-memory waits counted by
+//     hand: the stores of the epilogue, the residual loads and the DMA pieces retire in order on ONE counter, so the wait in
+//     front of the barrier is "everything but the ops issued after the pieces of tile t" (3 S + 2 RL + 2 PPW in steady
+//     state) -- a plain vmcnt(0) would wait for the stores just issued, every tile.
+// LayerNorm folded in: the statistics of a row are summed from the A fragments as they pass (a lane holds half of row
+// lane & 31: the two halves meet through one v_permlane32_swap), exact products, fp32 sums.
+template <typename T> __device__ __forceinline__ unsigned pack2_(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2_<__hip_bfloat16>(float a, float b)
+{
+    unsigned pk = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+#endif
+    return pk;
+}
+template <> __device__ __forceinline__ unsigned pack2_<__half>(float a, float b)
+{
+    unsigned pk = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+#endif
+    return pk;
+}
+template <typename T> __device__ __forceinline__ float unpack_lo_(unsigned v);
+template <typename T> __device__ __forceinline__ float unpack_hi_(unsigned v);
+template <> __device__ __forceinline__ float unpack_lo_<__hip_bfloat16>(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+template <> __device__ __forceinline__ float unpack_hi_<__hip_bfloat16>(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+template <> __device__ __forceinline__ float unpack_lo_<__half>(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)); }
+template <> __device__ __forceinline__ float unpack_hi_<__half>(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); }
+
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+#define TRAMBA_DSR128I_(OUT, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(OUT) : "v"(ADDR), "i"(OFF) : "memory")
+#define TRAMBA_VMCNT_(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+template <typename T, int K, int NCW, bool LNIN, bool DUAL, bool RES>
+__global__ __launch_bounds__(256, 2) void linear_ws_kernel(const T *__restrict__ x, const T *__restrict__ w,
+                                                          const float *__restrict__ bias, const T *__restrict__ res,
+                                                          T *__restrict__ y, long M, int N, int act, LnIn li,
+                                                          T *__restrict__ y_pre, int npanel, int gt)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // (vector-register asm in a kernel template: see ss2d_scan_dma_kernel)
+    static_assert(K == 128 || K == 256, "row = one or two 256-byte bank rows");
+    static_assert(NCW * K <= 512, "the wave's B fragments stay in <= 128 registers");
+    static_assert(!(DUAL && RES), "a dual-output launch has no residual");
+    static_assert(!RES || NCW <= 2, "residual rows are prefetched into registers");
+    constexpr int KB = K / 16;                 // MFMA k blocks
+    constexpr int RB = K * 2;                  // bytes per activation row
+    constexpr int TILE_BYTES = 32 * RB;
+    constexpr int NSTG = 4;
+    constexpr int PPW = K / 64;                // 1 KB DMA pieces per wave and tile
+    constexpr int PANEL = 128 * NCW;
+    constexpr int S = NCW * 2 * (DUAL ? 2 : 1);   // 16-byte stores per wave and tile
+    constexpr int RL = RES ? NCW * 4 : 0;         // 8-byte residual loads per wave and tile
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTG * TILE_BYTES + PANEL * 8];
+    typedef __attribute__((address_space(3))) void lds_void;
+    float *lbias = reinterpret_cast<float *>(lds + NSTG * TILE_BYTES);
+    float *lcs = lbias + PANEL;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int pn = blockIdx.x % npanel, g0 = blockIdx.x / npanel;
+    const int n0 = pn * PANEL, n0w = n0 + wv * (NCW * 32);
+    const long T32 = (M + 31) / 32;
+    const int nt = g0 < T32 ? (int)((T32 - g0 + gt - 1) / gt) : 0;
+
+    // ---- this wave's weights: NCW x KB fragments, loaded once
+    frag8_t bf[NCW][KB];
+#pragma unroll
+    for (int cb = 0; cb < NCW; ++cb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+            bf[cb][kb] = *reinterpret_cast<const frag8_t *>(w + (long)(n0w + cb * 32 + r32) * K + kb * 16 + hi * 8);
+    for (int i = tid; i < PANEL; i += 256) {
+        lbias[i] = bias ? bias[n0 + i] : 0.f;
+        lcs[i] = LNIN ? li.colsum[n0 + i] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- activation tiles by LDS-DMA
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(x, (unsigned)(M * RB));
+    unsigned voff[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int lo = (wv * PPW + j) * 1024 + lane * 16;        // my 16 bytes inside the (linear) stage
+        const int row = lo / RB, pos = (lo % RB) / 16;
+        const int c = (pos & ~15) | ((pos ^ row) & 15);
+        voff[j] = (unsigned)(row * RB + c * 16);
+    }
+    auto issue = [&](int i, int stg) {   // tile number i of this workgroup's list (past the end: rows >= M, zero-filled)
+        const long tile = (long)g0 + (long)i * gt;
+        const unsigned so = (unsigned)((tile < T32 ? tile : T32) * TILE_BYTES);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_void *)(lds + stg * TILE_BYTES + (wv * PPW + j) * 1024), 16, voff[j],
+                                                     so, 0, 0);
+    };
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    unsigned xa[8];
+    {
+        const unsigned l0 = lbase + (unsigned)(r32 * RB) + (unsigned)((((hi ^ r32) & 15)) << 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xa[j] = l0 ^ (unsigned)(j << 5);
+    }
+    const unsigned tba = lbase + (unsigned)(NSTG * TILE_BYTES) + (unsigned)((wv * NCW * 32 + 4 * hi) * 4);   // my bias / colsum floats
+    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(y, (unsigned)(M * (long)N * 2));
+    const __amdgpu_buffer_rsrc_t rsp = make_rsrc(DUAL ? y_pre : y, (unsigned)(M * (long)N * 2));
+    const __amdgpu_buffer_rsrc_t rsr = make_rsrc(RES ? res : x, (unsigned)(RES ? M * (long)N * 2 : 0));
+    const unsigned yoff = (unsigned)(r32 * N * 2 + (n0w + hi * 8) * 2);    // 16-byte stores: 8 consecutive columns per lane
+    const unsigned roff = (unsigned)(r32 * N * 2 + (n0w + hi * 4) * 2);    // 8-byte residual loads: my 4-column groups
+    const float invk = 1.f / (float)K;
+
+#pragma unroll
+    for (int i = 0; i < NSTG - 1; ++i) issue(i, i);
+
+    auto tile_step = [&](int t, auto stg_c) {
+        constexpr int STG = decltype(stg_c)::value;
+        // my pieces of tile t have landed (ops issued after them may still be in flight: see the header)
+        if (t >= 3) TRAMBA_VMCNT_(3 * S + 2 * RL + 2 * PPW);
+        else if (STG == 2) TRAMBA_VMCNT_(2 * (RL + PPW + S));
+        else if (STG == 1) TRAMBA_VMCNT_(2 * PPW + RL + S);
+        else TRAMBA_VMCNT_(2 * PPW);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const long tile = (long)g0 + (long)t * gt;
+        const unsigned so_y = (unsigned)(tile * 32 * N * 2);
+        v2u_t rv[RES ? NCW * 4 : 1];
+        if constexpr (RES) {
+#pragma unroll
+            for (int cb = 0; cb < NCW; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4"
+                                 : "=v"(rv[cb * 4 + g])
+                                 : "v"(roff), "s"(rsr), "s"(so_y), "i"((cb * 32 + 8 * g) * 2)
+                                 : "memory");
+        }
+        issue(t + NSTG - 1, (STG + NSTG - 1) % NSTG);
+
+        // ---- fragments + MFMAs, groups of 4 k blocks double-buffered
+        acc16_t acc[NCW];
+#pragma unroll
+        for (int cb = 0; cb < NCW; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+        float s1 = 0.f, s2 = 0.f;
+        frag8_t a[2][4];
+#define TRAMBA_RDG_(G, BUF)                                                                                        \
+    TRAMBA_DSR128I_(a[BUF][0], xa[((G) * 4 + 0) & 7], (((G) * 4 + 0) >> 3) * 256 + STG * TILE_BYTES);               \
+    TRAMBA_DSR128I_(a[BUF][1], xa[((G) * 4 + 1) & 7], (((G) * 4 + 1) >> 3) * 256 + STG * TILE_BYTES);               \
+    TRAMBA_DSR128I_(a[BUF][2], xa[((G) * 4 + 2) & 7], (((G) * 4 + 2) >> 3) * 256 + STG * TILE_BYTES);               \
+    TRAMBA_DSR128I_(a[BUF][3], xa[((G) * 4 + 3) & 7], (((G) * 4 + 3) >> 3) * 256 + STG * TILE_BYTES)
+        TRAMBA_RDG_(0, 0);
+#pragma unroll
+        for (int grp = 0; grp < KB / 4; ++grp) {
+            if (grp + 1 < KB / 4) {
+                if ((grp & 1) == 0) { TRAMBA_RDG_(grp + 1, 1); } else { TRAMBA_RDG_(grp + 1, 0); }
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[grp & 1][0]), "+v"(a[grp & 1][1]), "+v"(a[grp & 1][2]), "+v"(a[grp & 1][3]) : : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[grp & 1][0]), "+v"(a[grp & 1][1]), "+v"(a[grp & 1][2]), "+v"(a[grp & 1][3]) : : "memory");
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (LNIN) {
+                    const v4u_t av = __builtin_bit_cast(v4u_t, a[grp & 1][q]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1 = dot2_ones<T>(av[e], s1);
+                        s2 = dot2_self<T>(av[e], s2);
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < NCW; ++cb) acc[cb] = Mfma<T>::run(bf[cb][grp * 4 + q], a[grp & 1][q], acc[cb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise hoists the NEXT group's wait above these MFMAs)
+        }
+#undef TRAMBA_RDG_
+        float mean = 0.f, rstd = 1.f;
+        if constexpr (LNIN) {   // the two half rows of row r32 meet: lower half-wave + upper half-wave
+            const unsigned b1 = __builtin_bit_cast(unsigned, s1), b2 = __builtin_bit_cast(unsigned, s2);
+            const auto p1 = __builtin_amdgcn_permlane32_swap(b1, b1, false, false);
+            const auto p2 = __builtin_amdgcn_permlane32_swap(b2, b2, false, false);
+            const unsigned p1a = p1[0], p1b = p1[1], p2a = p2[0], p2b = p2[1];
+            const float t1 = __builtin_bit_cast(float, p1a) + __builtin_bit_cast(float, p1b);
+            const float t2 = __builtin_bit_cast(float, p2a) + __builtin_bit_cast(float, p2b);
+            mean = t1 * invk;
+            rstd = rsqrtf(fmaxf(t2 * invk - mean * mean, 0.f) + li.eps);
+        }
+        if constexpr (RES) {   // the residual rows were requested before the DMA pieces of this step
+            static_assert(NCW <= 2, "operand count of the wait below");
+            if constexpr (NCW == 1)
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) : "n"(PPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%8)"
+                             : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4 % (RES ? NCW * 4 : 1)]),
+                               "+v"(rv[5 % (RES ? NCW * 4 : 1)]), "+v"(rv[6 % (RES ? NCW * 4 : 1)]), "+v"(rv[7 % (RES ? NCW * 4 : 1)])
+                             : "n"(PPW)
+                             : "memory");
+        }
+        // ---- epilogue from the accumulators
+#pragma unroll
+        for (int cb = 0; cb < NCW; ++cb) {
+            v4u_t bq[4], cq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // (hand-written: an LDS read hipcc can see is ordered behind every pending LDS-DMA)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[g]) : "v"(tba), "i"((cb * 32 + 8 * g) * 4) : "memory");
+                if constexpr (LNIN)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cq[g]) : "v"(tba), "i"(PANEL * 4 + (cb * 32 + 8 * g) * 4) : "memory");
+            }
+            if constexpr (LNIN)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]) : : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : : "memory");
+            unsigned pk[4][2], pp[4][2];
+            float o[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[cb][4 * g + q];
+                    if constexpr (LNIN) v = rstd * fmaf(-mean, __builtin_bit_cast(float, cq[g][q]), v);
+                    o[4 * g + q] = v + __builtin_bit_cast(float, bq[g][q]);
+                }
+            if constexpr (DUAL) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    pp[g][0] = pack2_<T>(o[4 * g], o[4 * g + 1]);
+                    pp[g][1] = pack2_<T>(o[4 * g + 2], o[4 * g + 3]);
+                }
+            }
+            // ONE (wave-uniform) branch per 16 values: apply_act's per-element chain of comparisons does not get unswitched
+            if (act == TRAMBA_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] = geluf_(o[e]);
+            } else if (act == TRAMBA_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] = siluf_(o[e]);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (RES) {
+                    const v2u_t r2 = rv[cb * 4 + g];
+                    o[4 * g + 0] += unpack_lo_<T>(r2[0]);
+                    o[4 * g + 1] += unpack_hi_<T>(r2[0]);
+                    o[4 * g + 2] += unpack_lo_<T>(r2[1]);
+                    o[4 * g + 3] += unpack_hi_<T>(r2[1]);
+                }
+                pk[g][0] = pack2_<T>(o[4 * g], o[4 * g + 1]);
+                pk[g][1] = pack2_<T>(o[4 * g + 2], o[4 * g + 3]);
+            }
+            // lanes l and l + 32 hold columns 8g + 0..3 / 8g + 4..7 of the same row: after the swaps the lower lane holds 8
+            // consecutive columns of group pair (0, 1) or (2, 3) first half, the upper lane the second half
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const auto w0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+                const auto w1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+                const unsigned a0 = w0[0], b0 = w0[1], a1 = w1[0], b1 = w1[1];
+                const v4u_t out = {a0, a1, b0, b1};
+                __builtin_amdgcn_raw_buffer_store_b128(out, rsy, yoff + (unsigned)((cb * 32 + pr * 16) * 2), so_y, 0);
+                if constexpr (DUAL) {
+                    const auto u0 = __builtin_amdgcn_permlane32_swap(pp[2 * pr][0], pp[2 * pr + 1][0], false, false);
+                    const auto u1 = __builtin_amdgcn_permlane32_swap(pp[2 * pr][1], pp[2 * pr + 1][1], false, false);
+                    const unsigned c0 = u0[0], d0 = u0[1], c1 = u1[0], d1 = u1[1];
+                    const v4u_t outp = {c0, c1, d0, d1};
+                    __builtin_amdgcn_raw_buffer_store_b128(outp, rsp, yoff + (unsigned)((cb * 32 + pr * 16) * 2), so_y, 0);
+                }
+            }
+        }
+    };
+    for (int t0 = 0; t0 < nt; t0 += NSTG) {
+        tile_step(t0, std::integral_constant<int, 0>{});
+        if (t0 + 1 < nt) tile_step(t0 + 1, std::integral_constant<int, 1>{});
+        if (t0 + 2 < nt) tile_step(t0 + 2, std::integral_constant<int, 2>{});
+        if (t0 + 3 < nt) tile_step(t0 + 3, std::integral_constant<int, 3>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pieces requested past the end of the list land before the LDS is released
+#endif
+}
+#undef TRAMBA_DSR128I_
+#undef TRAMBA_VMCNT_
+
+static bool ws_rule(long m, int n, int k)
+{
+    (void)m;
+    (void)n;
+    (void)k;
+    return false;   // (until measured)
+}
+
 static int pc_rule(long tiles64, int k)
 {
     (void)tiles64;
     (void)k;
     return 0;      // (until measured)
+}
+
+// Weight-stationary form (linear_ws_kernel, r04): column blocks per wave (4 / 2 / 1), or 0 = not used.  16-bit in and out, K = 128 /
+// 256, N a whole number of 128 NCW-column panels, tall M.  TRAMBA_TUNE_GEMM_TILE 19 forces it wherever it can run, 0 = the
+// library's rule (scripts/bench_gemm_pc.py, profiles/r04_gemm_ws.txt); every other value keeps it off.
+static int ws_ncw(long m, int n, int k, int tile_tune, bool has_res)
+{
+    if (tile_tune != 19 && tile_tune != 0) return 0;
+    if (k != 128 && k != 256) return 0;
+    if ((double)m * n * 2.0 >= 2147483648.0 || (double)(m + 32) * k * 2.0 >= 2147483648.0) return 0;
+    int ncw = 512 / k;                         // NCW * K <= 512
+    if (has_res && ncw > 2) ncw = 2;
+    while (ncw >= 1 && n % (128 * ncw)) ncw >>= 1;
+    if (ncw < 1) return 0;
+    if (tile_tune == 19) return m >= 64 ? ncw : 0;
+    return ws_rule(m, n, k) ? ncw : 0;
+}
+
+template <typename T, int K, bool LNIN, bool DUAL, bool RES>
+static void launch_ws(int ncw, const void *x, const void *w, const float *bias, const void *res, void *y, long m, int n, int act,
+                      LnIn li, void *y_pre, hipStream_t s)
+{
+    const int npanel = n / (128 * ncw);
+    const long t32 = (m + 31) / 32;
+    // persistent workgroups, two per CU: every workgroup walks tiles g, g + G, ... of its panel
+    const long rounds = (t32 * npanel + 511) / 512;
+    long gt = (t32 + rounds - 1) / rounds;
+    if (gt < 1) gt = 1;
+    dim3 grid((unsigned)(gt * npanel)), block(256);
+#define WS_(NCW_)                                                                                                      \
+    hipLaunchKernelGGL((linear_ws_kernel<T, K, NCW_, LNIN, DUAL, RES>), grid, block, 0, s, (const T *)x, (const T *)w, bias, \
+                       (const T *)res, (T *)y, m, n, act, li, (T *)y_pre, npanel, (int)gt)
+    if constexpr (K == 128) {
+        if (ncw == 4) { if constexpr (!RES) { WS_(4); } }
+        else if (ncw == 2) { WS_(2); }
+        else { WS_(1); }
+    } else {
+        if (ncw == 2) { WS_(2); } else { WS_(1); }
+    }
+#undef WS_
+}
+
+template <typename T, bool LNIN, bool DUAL>
+static void launch_ws_k(int ncw, const void *x, const void *w, const float *bias, const void *res, void *y, long m, int n, int k,
+                        int act, LnIn li, void *y_pre, hipStream_t s)
+{
+    if (k == 128) {
+        if (res) { if constexpr (!DUAL) launch_ws<T, 128, LNIN, false, true>(ncw, x, w, bias, res, y, m, n, act, li, y_pre, s); }
+        else launch_ws<T, 128, LNIN, DUAL, false>(ncw, x, w, bias, res, y, m, n, act, li, y_pre, s);
+    } else {
+        if (res) { if constexpr (!DUAL) launch_ws<T, 256, LNIN, false, true>(ncw, x, w, bias, res, y, m, n, act, li, y_pre, s); }
+        else launch_ws<T, 256, LNIN, DUAL, false>(ncw, x, w, bias, res, y, m, n, act, li, y_pre, s);
+    }
 }
 
 // Producer / consumer form (linear_pc_kernel, r04): 0 = not used, else its LDS stage count.  TRAMBA_TUNE_GEMM_TILE 16 / 17 force it
@@ -1317,7 +1684,7 @@ static int pc_stages(long m, int n, int k, int tile_tune)
 {
     if (tile_tune == 16) return 3;
     if (tile_tune == 17) return 4;
-    if (tile_tune != 0) return 0;
+    if (tile_tune != 0 && tile_tune != 19) return 0;
     const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
     return pc_rule(tiles64, k);
 }
@@ -1346,17 +1713,24 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
     // (4 stages = 3 tiles in flight where at most one block lands on a CU and K is long: nothing else hides the load latency
     //  there -- M = 576, N = 1024, K = 4096: 27 -> 22 us with operands that are not cache-resident; 8 stages = one block per
     //  CU by LDS, was measured slower on every shape and is not built)
-    const bool dma_deep = tile_tune == 7 || ((tile_tune == 0 || tile_tune == 18) && tiles64 <= 256 && k >= 1024);
+    const bool dma_deep = tile_tune == 7 || ((tile_tune == 0 || tile_tune == 18 || tile_tune == 19) && tiles64 <= 256 && k >= 1024);
+    if constexpr (!CONV && std::is_same<T, TO>::value) {
+        const int ncw = (lean_ok && !x2) ? ws_ncw(m, n, k, tile_tune, res != nullptr) : 0;
+        if (ncw && (act == TRAMBA_ACT_NONE || act == TRAMBA_ACT_GELU || act == TRAMBA_ACT_SILU)) {
+            launch_ws_k<T, false, false>(ncw, x, w, bias, res, y, m, n, k, act, LnIn{nullptr, 0.f}, nullptr, s);
+            return;
+        }
+    }
     if (!CONV && lean_ok && !x2 && tile96_dma(m, n, k, tile_tune)) {
         dim3 grid((n + 63) / 64, (unsigned)((m + 95) / 96)), block(256);
         hipLaunchKernelGGL((linear_dma96_kernel<T, TO, 3>), grid, block, 0, s, (const T *)x, (const T *)w, bias, (const T *)res,
                            (TO *)y, m, n, k, act);
     } else if (!CONV && lean_ok && !x2 && (tile_tune == 0 || tile_tune == 6 || tile_tune == 7 || tile_tune == 13 || tile_tune == 14 ||
-                                           tile_tune == 15 || tile_tune == 16 || tile_tune == 17 || tile_tune == 18)) {
+                                           tile_tune == 15 || tile_tune == 16 || tile_tune == 17 || tile_tune == 18 || tile_tune == 19)) {
         dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
         // short K (<= 4 steps) on a grid of many tiles: the launch is prologue + epilogue, and what it needs is workgroups in
         // flight -- 2 stages = 32 KB of LDS = 5 per CU instead of 3 (TRAMBA_TUNE_GEMM_TILE 13 forces it, 14 forbids it)
-        const bool dma_short = tile_tune == 13 || ((tile_tune == 0 || tile_tune == 18) && DMA_SHORT_K > 0 && k <= DMA_SHORT_K && tiles64 >= 1024);
+        const bool dma_short = tile_tune == 13 || ((tile_tune == 0 || tile_tune == 18 || tile_tune == 19) && DMA_SHORT_K > 0 && k <= DMA_SHORT_K && tiles64 >= 1024);
         const int pc = pc_stages(m, n, k, tile_tune);
         if (pc == 3)
             hipLaunchKernelGGL((linear_pc_kernel<T, TO, 3>), grid, dim3(512), 0, s, (const T *)x, (const T *)w, bias,
@@ -1535,7 +1909,7 @@ extern "C" int tramba_linear_ln_cl(const void *x, const void *w_folded, const fl
     const int pc = pc_stages(m, n, k, tile_tune);
     dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
     const LnIn li{colsum, eps};
-    const bool dma_short = dma && (tile_tune == 0 || tile_tune == 18) && k <= DMA_SHORT_K && ((m + 63) / 64) * ((n + 63) / 64) >= 1024;   // (launch_tiled)
+    const bool dma_short = dma && (tile_tune == 0 || tile_tune >= 18) && k <= DMA_SHORT_K && ((m + 63) / 64) * ((n + 63) / 64) >= 1024;   // (launch_tiled)
 #define LNIN_(T, TO)                                                                                                     \
     if (pc == 3)                                                                                                         \
         hipLaunchKernelGGL((linear_pc_kernel<T, TO, 3, true>), grid, dim3(512), 0, s, (const T *)x, (const T *)w_folded, bias, \
@@ -1557,7 +1931,12 @@ extern "C" int tramba_linear_ln_cl(const void *x, const void *w_folded, const fl
         hipLaunchKernelGGL((linear_lean_kernel<T, TO, 64, 64, 1, false, 2, true>), grid, block, 0, s, (const T *)x,       \
                            (const T *)w_folded, bias, (const T *)residual, (TO *)y, m, n, k, act, (const T *)nullptr, 0,  \
                            LnHead{}, li)
-    if (dtype == TRAMBA_BF16) {
+    const int ncw = out_dtype == dtype && (act == TRAMBA_ACT_NONE || act == TRAMBA_ACT_GELU || act == TRAMBA_ACT_SILU)
+                        ? ws_ncw(m, n, k, tile_tune, residual != nullptr) : 0;
+    if (ncw) {
+        if (dtype == TRAMBA_BF16) launch_ws_k<__hip_bfloat16, true, false>(ncw, x, w_folded, bias, residual, y, m, n, k, act, li, nullptr, s);
+        else launch_ws_k<__half, true, false>(ncw, x, w_folded, bias, residual, y, m, n, k, act, li, nullptr, s);
+    } else if (dtype == TRAMBA_BF16) {
         if (out_dtype == TRAMBA_F32) { LNIN_(__hip_bfloat16, float); } else { LNIN_(__hip_bfloat16, __hip_bfloat16); }
     } else {
         if (out_dtype == TRAMBA_F32) { LNIN_(__half, float); } else { LNIN_(__half, __half); }
@@ -1657,7 +2036,7 @@ extern "C" int tramba_linear_dual_cl(const void *x, const void *w, const float *
     const bool dma96 = tile96_dma(m, n, k, tramba_tune_get(TRAMBA_TUNE_GEMM_TILE));
     dim3 grid((n + 63) / 64, (unsigned)(dma96 ? (m + 95) / 96 : (m + 63) / 64)), block(256);
     const int tune_ = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE);
-    const bool dma_short = (tune_ == 0 || tune_ == 18) && k <= DMA_SHORT_K && ((m + 63) / 64) * ((n + 63) / 64) >= 1024;   // (launch_tiled)
+    const bool dma_short = (tune_ == 0 || tune_ >= 18) && k <= DMA_SHORT_K && ((m + 63) / 64) * ((n + 63) / 64) >= 1024;   // (launch_tiled)
     const int pc = pc_stages(m, n, k, tune_);
 #define DUAL_(T, S_)                                                                                                    \
     hipLaunchKernelGGL((linear_dma_kernel<T, T, S_, false, true>), grid, block, 0, s, (const T *)x, (const T *)w, bias,   \
@@ -1668,7 +2047,11 @@ extern "C" int tramba_linear_dual_cl(const void *x, const void *w, const float *
 #define DUALPC_(T, S_)                                                                                                  \
     hipLaunchKernelGGL((linear_pc_kernel<T, T, S_, false, true>), grid, dim3(512), 0, s, (const T *)x, (const T *)w, bias, \
                        (const T *)nullptr, (T *)y_act, m, n, k, act, LnIn{nullptr, 0.f}, (T *)y_pre)
-    if (dtype == TRAMBA_BF16) {
+    const int ncw = ws_ncw(m, n, k, tune_, false);
+    if (ncw) {
+        if (dtype == TRAMBA_BF16) launch_ws_k<__hip_bfloat16, false, true>(ncw, x, w, bias, nullptr, y_act, m, n, k, act, LnIn{nullptr, 0.f}, y_pre, s);
+        else launch_ws_k<__half, false, true>(ncw, x, w, bias, nullptr, y_act, m, n, k, act, LnIn{nullptr, 0.f}, y_pre, s);
+    } else if (dtype == TRAMBA_BF16) {
         if (dma96) DUAL96_(__hip_bfloat16); else if (pc == 3) DUALPC_(__hip_bfloat16, 3); else if (pc == 4) DUALPC_(__hip_bfloat16, 4);
         else if (dma_short) DUAL_(__hip_bfloat16, 2); else DUAL_(__hip_bfloat16, 3);
     } else {
