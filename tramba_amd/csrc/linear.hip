@@ -1318,7 +1318,7 @@ static bool tile96_dma(long m, int n, int k, int tile_tune)
 //   * 4 waves own a PANEL of 128 NCW columns (NCW = 4 / 2 / 1 column blocks of 32 per wave, NCW * K <= 512): every wave loads
 //     its NCW x K/16 MFMA B-fragments ONCE into registers (<= 128 VGPRs) and keeps them;
 //   * the workgroup then walks its list of 32-row tiles (tile = g + i * G: neighbouring workgroups stream neighbouring rows);
-//     the 32 x K activation tiles travel L2 -> LDS by `buffer_load ... lds` on a 4-stage ring, three tiles ahead, every wave
+//     the 32 x K activation tiles travel L2 -> LDS by `buffer_load ... lds` on a 6- / 4-stage ring (K = 128 / 256), every wave
 //     fetching K/64 1 KB pieces per tile, the 16-byte chunk c of row r stored at position c ^ (r & 15) (applied on the
 //     global side, undone in the ds_read_b128 addresses: the 16 rows of a read group land on 16 different bank groups);
 //   * per tile: K/16 fragment reads (shared by the wave's NCW column blocks), NCW K/16 MFMAs with swapped operands (a lane
@@ -1328,8 +1328,10 @@ static bool tile96_dma(long m, int n, int k, int tile_tune)
 //     tile, no workgroup barrier inside the epilogue;
 //   * one s_barrier per tile (tile t is in LDS for everyone; everyone has read tile t - 1), vector-memory waits counted by
 //     hand: the stores of the epilogue, the residual loads and the DMA pieces retire in order on ONE counter, so the wait in
-//     front of the barrier is "everything but the ops issued after the pieces of tile t" (3 S + 2 RL + 2 PPW in steady
-//     state) -- a plain vmcnt(0) would wait for the stores just issued, every tile.
+//     front of the barrier is "everything but the ops issued after the pieces of tile t" ((NSTG - 1) S + (NSTG - 2)(RL + PPW)
+//     in steady state) -- a plain vmcnt(0) would wait for the stores just issued, every tile.  Because the counter retires
+//     IN ORDER the pieces of tile t also wait for the stores of tile t - NSTG: the ring is as deep as LDS and the 6-bit
+//     counter allow, so that a store has NSTG tile-times to be acknowledged before anything waits behind it.
 // LayerNorm folded in: the statistics of a row are summed from the A fragments as they pass (a lane holds half of row
 // lane & 31: the two halves meet through one v_permlane32_swap), exact products, fp32 sums.
 template <typename T> __device__ __forceinline__ unsigned pack2_(float a, float b);
@@ -1370,12 +1372,16 @@ __global__ __launch_bounds__(256, 2) void linear_ws_kernel(const T *__restrict__
 #if defined(__HIP_DEVICE_COMPILE__)   // (vector-register asm in a kernel template: see ss2d_scan_dma_kernel)
     static_assert(K == 128 || K == 256, "row = one or two 256-byte bank rows");
     static_assert(NCW * K <= 512, "the wave's B fragments stay in <= 128 registers");
+    static_assert((((K == 128 && NCW <= 2) ? 6 : 4) - 1) * 32 * K * 2 + 512 <= 65535, "the last ring stage inside ds_read's 16-bit offset");
+    static_assert((((K == 128 && NCW <= 2) ? 6 : 4) - 1) * (NCW * 2 * (DUAL ? 2 : 1)) +
+                          (((K == 128 && NCW <= 2) ? 6 : 4) - 2) * ((RES ? NCW * 4 : 0) + K / 64) <= 63,
+                  "the counted vmcnt fits its 6-bit field");
     static_assert(!(DUAL && RES), "a dual-output launch has no residual");
     static_assert(!RES || NCW <= 2, "residual rows are prefetched into registers");
     constexpr int KB = K / 16;                 // MFMA k blocks
     constexpr int RB = K * 2;                  // bytes per activation row
     constexpr int TILE_BYTES = 32 * RB;
-    constexpr int NSTG = 4;
+    constexpr int NSTG = (K == 128 && NCW <= 2) ? 6 : 4;     // ring depth: the pieces of tile t retire behind the stores of tile t - NSTG (see header)
     constexpr int PPW = K / 64;                // 1 KB DMA pieces per wave and tile
     constexpr int PANEL = 128 * NCW;
     constexpr int S = NCW * 2 * (DUAL ? 2 : 1);   // 16-byte stores per wave and tile
@@ -1444,11 +1450,12 @@ __global__ __launch_bounds__(256, 2) void linear_ws_kernel(const T *__restrict__
 
     auto tile_step = [&](int t, auto stg_c) {
         constexpr int STG = decltype(stg_c)::value;
-        // my pieces of tile t have landed (ops issued after them may still be in flight: see the header)
-        if (t >= 3) TRAMBA_VMCNT_(3 * S + 2 * RL + 2 * PPW);
-        else if (STG == 2) TRAMBA_VMCNT_(2 * (RL + PPW + S));
-        else if (STG == 1) TRAMBA_VMCNT_(2 * PPW + RL + S);
-        else TRAMBA_VMCNT_(2 * PPW);
+        // my pieces of tile t have landed; ops issued after them may still be in flight.  Order of a step's vector-memory ops:
+        // [RL residual loads][PPW pieces of tile t + NSTG - 1][S stores].  The pieces of tile t were issued NSTG - 1 steps ago:
+        // behind them came that step's stores and NSTG - 2 whole steps; in the first NSTG - 1 steps (t == STG) the pieces come
+        // from the prologue: the prologue pieces of the later tiles and t whole steps are younger
+        if (t >= NSTG - 1) TRAMBA_VMCNT_((NSTG - 1) * S + (NSTG - 2) * (RL + PPW));
+        else TRAMBA_VMCNT_((NSTG - 2 - STG) * PPW + STG * (RL + PPW + S));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const long tile = (long)g0 + (long)t * gt;
@@ -1543,14 +1550,20 @@ __global__ __launch_bounds__(256, 2) void linear_ws_kernel(const T *__restrict__
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : : "memory");
             unsigned pk[4][2], pp[4][2];
             float o[16];
+            typedef float v4f_t __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
+                // (bit-cast the WHOLE vector: hipcc compiles __builtin_bit_cast(float, vec[q]) to element 0)
+                const v4f_t bf4 = __builtin_bit_cast(v4f_t, bq[g]);
+                v4f_t cf4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (LNIN) cf4 = __builtin_bit_cast(v4f_t, cq[g]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v = acc[cb][4 * g + q];
-                    if constexpr (LNIN) v = rstd * fmaf(-mean, __builtin_bit_cast(float, cq[g][q]), v);
-                    o[4 * g + q] = v + __builtin_bit_cast(float, bq[g][q]);
+                    if constexpr (LNIN) v = rstd * fmaf(-mean, cf4[q], v);
+                    o[4 * g + q] = v + bf4[q];
                 }
+            }
             if constexpr (DUAL) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1602,6 +1615,10 @@ __global__ __launch_bounds__(256, 2) void linear_ws_kernel(const T *__restrict__
         if (t0 + 1 < nt) tile_step(t0 + 1, std::integral_constant<int, 1>{});
         if (t0 + 2 < nt) tile_step(t0 + 2, std::integral_constant<int, 2>{});
         if (t0 + 3 < nt) tile_step(t0 + 3, std::integral_constant<int, 3>{});
+        if constexpr (NSTG > 4) {
+            if (t0 + 4 < nt) tile_step(t0 + 4, std::integral_constant<int, 4>{});
+            if (t0 + 5 < nt) tile_step(t0 + 5, std::integral_constant<int, 5>{});
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pieces requested past the end of the list land before the LDS is released
 #endif
@@ -1609,35 +1626,49 @@ __global__ __launch_bounds__(256, 2) void linear_ws_kernel(const T *__restrict__
 #undef TRAMBA_DSR128I_
 #undef TRAMBA_VMCNT_
 
-static bool ws_rule(long m, int n, int k)
+// Where the weight-stationary kernel is the library's choice (scripts/bench_gemm_pc.py on MI355X, profiles/r04_gemm_forms.txt; us per
+// launch, r03 kernel / producer-consumer / weight-stationary): the K = 128 layers of the 96 x 96 stage with the LayerNorm folded
+// in -- M = 36864, N = 512 + GELU 29.1 / 36.0 / 22.1, N = 256 16.8 / 20.1 / 15.2; M = 73728, N = 512 53.2 / 66.7 / 36.8 -- and, from
+// batch 8 on, their plain and dual-output forms (M = 73728, N = 512: 49.2 / 45.5 / 40.3 plain, 47.0 / 49.5 / 42.4 dual).  At K = 256
+// and on the 48 x 48 stage (M = 9216) the three forms are within 10 % of each other and the tile kernels stay.
+static bool ws_rule(long m, int n, int k, int kind /* 0 plain, 1 LayerNorm folded in, 2 dual output */)
 {
-    (void)m;
-    (void)n;
-    (void)k;
-    return false;   // (until measured)
+    if (k != 128 || n < 256) return false;
+    return kind == 1 ? m >= 16384 : m >= 65536;
 }
 
-static int pc_rule(long tiles64, int k)
+// Where the producer / consumer kernel is the library's choice (same measurements; kind as in ws_rule):
+//   plain: everywhere (-3 .. -20 %: M = 2304, N = 136, K = 1024 8.0 -> 6.3 us, M = 9216, N = 1024, K = 256 19.6 -> 16.5) except the
+//          288-tile K = 2048 launches (12.7 -> 12.9: the r03 kernel stays); 4 stages for K >= 2048 on <= 256 tiles (M = 576,
+//          N = 1024, K = 4096: 19.3 -> 16.1);
+//   LayerNorm folded in: up to 320 tiles (M = 2304, N = 512, K = 2048 16.3 -> 13.6; M = 576, N = 2048, K = 1024 11.8 -> 10.7); on
+//          more tiles the statistics reads cost the multiplier waves more than the loader waves save (10.3 -> 11.3);
+//   dual output: everywhere except the >= 4096-tile K <= 256 launches (25.2 -> 26.2).
+static int pc_rule(long tiles64, int k, int kind)
 {
-    (void)tiles64;
-    (void)k;
-    return 0;      // (until measured)
+    if (kind == 1) return tiles64 <= 320 ? 3 : 0;
+    if (kind == 2) return (k <= 256 && tiles64 >= 4096) ? 0 : 3;
+    if (k >= 2048 && tiles64 <= 256) return 4;
+    if (k >= 2048 && tiles64 <= 320) return 0;
+    return 3;
 }
 
 // Weight-stationary form (linear_ws_kernel, r04): column blocks per wave (4 / 2 / 1), or 0 = not used.  16-bit in and out, K = 128 /
 // 256, N a whole number of 128 NCW-column panels, tall M.  TRAMBA_TUNE_GEMM_TILE 19 forces it wherever it can run, 0 = the
 // library's rule (scripts/bench_gemm_pc.py, profiles/r04_gemm_ws.txt); every other value keeps it off.
-static int ws_ncw(long m, int n, int k, int tile_tune, bool has_res)
+static int ws_ncw(long m, int n, int k, int tile_tune, bool has_res, int kind)
 {
     if (tile_tune != 19 && tile_tune != 0) return 0;
     if (k != 128 && k != 256) return 0;
     if ((double)m * n * 2.0 >= 2147483648.0 || (double)(m + 32) * k * 2.0 >= 2147483648.0) return 0;
-    int ncw = 512 / k;                         // NCW * K <= 512
+    int ncw = 256 / k;                         // NCW * K <= 256: ~150 VGPRs = 3 workgroups per CU, half the weight prologue per
+                                               // workgroup of the NCW * K = 512 form (measured, profiles/r04_gemm_ws.txt)
+    if (tile_tune == 19 && tramba_tune_get(TRAMBA_TUNE_SCAN_W) == 99) ncw = 512 / k;   // (A/B of the wide panel: scripts only)
     if (has_res && ncw > 2) ncw = 2;
     while (ncw >= 1 && n % (128 * ncw)) ncw >>= 1;
     if (ncw < 1) return 0;
     if (tile_tune == 19) return m >= 64 ? ncw : 0;
-    return ws_rule(m, n, k) ? ncw : 0;
+    return ws_rule(m, n, k, kind) ? ncw : 0;
 }
 
 template <typename T, int K, bool LNIN, bool DUAL, bool RES>
@@ -1646,9 +1677,12 @@ static void launch_ws(int ncw, const void *x, const void *w, const float *bias, 
 {
     const int npanel = n / (128 * ncw);
     const long t32 = (m + 31) / 32;
-    // persistent workgroups, two per CU: every workgroup walks tiles g, g + G, ... of its panel
-    const long rounds = (t32 * npanel + 511) / 512;
-    long gt = (t32 + rounds - 1) / rounds;
+    // persistent workgroups, as many as are resident at once (256 CUs x 3 at K = 128 with NCW <= 2, x 2 otherwise), the tiles of a panel dealt
+    // round-robin: every workgroup walks tiles g, g + G, ... -- an even split, whereas a grid sized by whole rounds of tiles
+    // (384 workgroups for 1152 tiles) left half of the CUs with one workgroup and the other half with two
+    const long resident = 256L * ((K == 128 && ncw <= 2) ? 3 : 2);     // (by registers and LDS: 51 KB / 67 KB per workgroup)
+    long gt = resident / npanel;
+    if (gt > t32) gt = t32;
     if (gt < 1) gt = 1;
     dim3 grid((unsigned)(gt * npanel)), block(256);
 #define WS_(NCW_)                                                                                                      \
@@ -1680,13 +1714,13 @@ static void launch_ws_k(int ncw, const void *x, const void *w, const float *bias
 // Producer / consumer form (linear_pc_kernel, r04): 0 = not used, else its LDS stage count.  TRAMBA_TUNE_GEMM_TILE 16 / 17 force it
 // on 3 / 4 stages wherever the LDS-DMA kernel could run, 18 forbids it; the library's own rule (tune 0) is fitted to
 // scripts/bench_gemm_pc.py (profiles/r04_gemm_pc.txt).
-static int pc_stages(long m, int n, int k, int tile_tune)
+static int pc_stages(long m, int n, int k, int tile_tune, int kind)
 {
     if (tile_tune == 16) return 3;
     if (tile_tune == 17) return 4;
     if (tile_tune != 0 && tile_tune != 19) return 0;
     const long tiles64 = ((m + 63) / 64) * ((n + 63) / 64);
-    return pc_rule(tiles64, k);
+    return pc_rule(tiles64, k, kind);
 }
 
 // K up to which a grid of >= 1024 tiles runs linear_dma_kernel on 2 LDS stages (5 workgroups per CU instead of 3):
@@ -1715,7 +1749,7 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
     //  CU by LDS, was measured slower on every shape and is not built)
     const bool dma_deep = tile_tune == 7 || ((tile_tune == 0 || tile_tune == 18 || tile_tune == 19) && tiles64 <= 256 && k >= 1024);
     if constexpr (!CONV && std::is_same<T, TO>::value) {
-        const int ncw = (lean_ok && !x2) ? ws_ncw(m, n, k, tile_tune, res != nullptr) : 0;
+        const int ncw = (lean_ok && !x2) ? ws_ncw(m, n, k, tile_tune, res != nullptr, 0) : 0;
         if (ncw && (act == TRAMBA_ACT_NONE || act == TRAMBA_ACT_GELU || act == TRAMBA_ACT_SILU)) {
             launch_ws_k<T, false, false>(ncw, x, w, bias, res, y, m, n, k, act, LnIn{nullptr, 0.f}, nullptr, s);
             return;
@@ -1731,7 +1765,7 @@ static void launch_tiled(const void *x, const void *w, const float *bias, const 
         // short K (<= 4 steps) on a grid of many tiles: the launch is prologue + epilogue, and what it needs is workgroups in
         // flight -- 2 stages = 32 KB of LDS = 5 per CU instead of 3 (TRAMBA_TUNE_GEMM_TILE 13 forces it, 14 forbids it)
         const bool dma_short = tile_tune == 13 || ((tile_tune == 0 || tile_tune == 18 || tile_tune == 19) && DMA_SHORT_K > 0 && k <= DMA_SHORT_K && tiles64 >= 1024);
-        const int pc = pc_stages(m, n, k, tile_tune);
+        const int pc = pc_stages(m, n, k, tile_tune, 0);
         if (pc == 3)
             hipLaunchKernelGGL((linear_pc_kernel<T, TO, 3>), grid, dim3(512), 0, s, (const T *)x, (const T *)w, bias,
                                (const T *)res, (TO *)y, m, n, k, act);
@@ -1906,7 +1940,7 @@ extern "C" int tramba_linear_ln_cl(const void *x, const void *w_folded, const fl
     const int tile_tune = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE);
     const bool deep = tile_tune == 5;                    // 4-stage register ring: measurement only (see launch_tiled)
     const bool dma = tile_tune == 0 || tile_tune == 6 || tile_tune == 15 || tile_tune >= 16;   // the LDS-DMA staged kernel (default)
-    const int pc = pc_stages(m, n, k, tile_tune);
+    const int pc = pc_stages(m, n, k, tile_tune, 1);
     dim3 grid((n + 63) / 64, (unsigned)((m + 63) / 64)), block(256);
     const LnIn li{colsum, eps};
     const bool dma_short = dma && (tile_tune == 0 || tile_tune >= 18) && k <= DMA_SHORT_K && ((m + 63) / 64) * ((n + 63) / 64) >= 1024;   // (launch_tiled)
@@ -1932,7 +1966,7 @@ extern "C" int tramba_linear_ln_cl(const void *x, const void *w_folded, const fl
                            (const T *)w_folded, bias, (const T *)residual, (TO *)y, m, n, k, act, (const T *)nullptr, 0,  \
                            LnHead{}, li)
     const int ncw = out_dtype == dtype && (act == TRAMBA_ACT_NONE || act == TRAMBA_ACT_GELU || act == TRAMBA_ACT_SILU)
-                        ? ws_ncw(m, n, k, tile_tune, residual != nullptr) : 0;
+                        ? ws_ncw(m, n, k, tile_tune, residual != nullptr, 1) : 0;
     if (ncw) {
         if (dtype == TRAMBA_BF16) launch_ws_k<__hip_bfloat16, true, false>(ncw, x, w_folded, bias, residual, y, m, n, k, act, li, nullptr, s);
         else launch_ws_k<__half, true, false>(ncw, x, w_folded, bias, residual, y, m, n, k, act, li, nullptr, s);
@@ -2037,7 +2071,7 @@ extern "C" int tramba_linear_dual_cl(const void *x, const void *w, const float *
     dim3 grid((n + 63) / 64, (unsigned)(dma96 ? (m + 95) / 96 : (m + 63) / 64)), block(256);
     const int tune_ = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE);
     const bool dma_short = (tune_ == 0 || tune_ >= 18) && k <= DMA_SHORT_K && ((m + 63) / 64) * ((n + 63) / 64) >= 1024;   // (launch_tiled)
-    const int pc = pc_stages(m, n, k, tune_);
+    const int pc = pc_stages(m, n, k, tune_, 2);
 #define DUAL_(T, S_)                                                                                                    \
     hipLaunchKernelGGL((linear_dma_kernel<T, T, S_, false, true>), grid, block, 0, s, (const T *)x, (const T *)w, bias,   \
                        (const T *)nullptr, (T *)y_act, m, n, k, act, LnIn{nullptr, 0.f}, (T *)y_pre)
@@ -2047,7 +2081,7 @@ extern "C" int tramba_linear_dual_cl(const void *x, const void *w, const float *
 #define DUALPC_(T, S_)                                                                                                  \
     hipLaunchKernelGGL((linear_pc_kernel<T, T, S_, false, true>), grid, dim3(512), 0, s, (const T *)x, (const T *)w, bias, \
                        (const T *)nullptr, (T *)y_act, m, n, k, act, LnIn{nullptr, 0.f}, (T *)y_pre)
-    const int ncw = ws_ncw(m, n, k, tune_, false);
+    const int ncw = ws_ncw(m, n, k, tune_, false, 2);
     if (ncw) {
         if (dtype == TRAMBA_BF16) launch_ws_k<__hip_bfloat16, false, true>(ncw, x, w, bias, nullptr, y_act, m, n, k, act, LnIn{nullptr, 0.f}, y_pre, s);
         else launch_ws_k<__half, false, true>(ncw, x, w, bias, nullptr, y_act, m, n, k, act, LnIn{nullptr, 0.f}, y_pre, s);
