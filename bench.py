@@ -103,7 +103,26 @@ def spawn_ranks(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.run(cmd, env=env).returncode
+    # The child's stdout passes through this process: if rank 0 printed its line and a rank then ABORTED (a runtime abort inside a
+    # captured collective takes the whole job down with a non-zero code), the measurement that was printed still stands -- exit 0
+    # and say on stderr what happened (VERDICT r3 "next" 3c)
+    return relay_child(cmd, env)
+
+
+def relay_child(cmd, env=None):
+    """run `cmd`, pass its stdout through; exit code 0 if it printed a result line, whatever it died of afterwards"""
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    have_line = False
+    for out in proc.stdout:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            have_line = True
+    rc = proc.wait()
+    if rc != 0 and have_line:
+        print(f"bench.py: the rank job ended with code {rc} AFTER rank 0 had printed its line; exiting 0", file=sys.stderr)
+        return 0
+    return rc
 
 
 def pmc_traffic(key):
@@ -782,6 +801,26 @@ def main():
         os._exit(0 if rank == 0 else 3)
 
     threading.Thread(target=watchdog, daemon=True).start()
+
+    # A rank that ABORTS (rather than hangs) makes the launcher send the others SIGTERM: rank 0 then prints the line it holds -- the
+    # forward result, and the eager data-parallel result if the leg had got that far -- before it leaves (VERDICT r3 "next" 3c).
+    def on_term(signum, _frame):
+        if rank == 0 and line is not None and not done.is_set():
+            msg = f"terminated by signal {signum} during the training leg (another rank failed; N = {world})"
+            if isinstance(line.get("train"), dict) and "eager" in line["train"]:
+                line["train"]["graphed"] = {"error": msg}
+            else:
+                line["train"] = {"error": msg}
+            try:
+                sys.stdout.write(json.dumps(line) + "\n")
+                sys.stdout.flush()
+            except Exception:
+                pass
+        os._exit(0 if rank == 0 else 3)
+
+    if world > 1:
+        import signal
+        signal.signal(signal.SIGTERM, on_term)
     train_obj = None
     if not args.no_train:
         ok = torch.ones(1, device="cuda")
