@@ -104,8 +104,8 @@ int tramba_tune_get(int knob);
                                         weight-gradient TN GEMMs (tramba_wgrad_cl): 0 = token tiles staged by LDS-DMA on 3 stages, one
                                         workgroup per CU (the default); 8 = register-staged, one tile in flight; 9 = LDS-DMA on 4 stages;
                                         10 / 11 / 12 = 384 / 512 / 768 workgroups wanted by the token split */
-#define TRAMBA_TUNE_MAILBOX_POLLS 4  /* poll budget of the fused scans' carry mailbox (0 = the library's 2^20, ~0.1 s); tests force a
-                                        time-out with a tiny budget to see the device error word reported */
+#define TRAMBA_TUNE_MAILBOX_SKIP 4   /* tests only: > 0 withholds the carry hand-over of that tile (chain order) in the fused scans, so that
+                                        the wave waiting for it runs out of polls (~0.1 s) and the device error word is raised; 0 = off */
 #define TRAMBA_TUNE_COUNT 5
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Which tramba_amd source lines issue the torch (non-library) ops of one training step?  A TorchDispatchMode logs every
 aten op that runs a device kernel with the innermost tramba_amd frame of the Python stack (autograd-engine internals such as
-gradient accumulation show up as "(engine)").  usage: python scripts/trace_glue.py [batch]"""
+gradient accumulation show up as "(engine)").  usage: python scripts/trace_glue.py [batch] [infer]   (infer: the bf16 inference
+forward of bench.py instead of the training step)"""
 import collections, os, sys, traceback, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tramba_amd as ta
@@ -38,6 +39,23 @@ class Log(TorchDispatchMode):
             self.elems[(name, site)] += n
         return out
 
+
+if len(sys.argv) > 2 and sys.argv[2] == "infer":
+    torch.manual_seed(1026)
+    m = ta.prepare_inference(ta.bulid_model(deep_supervision=True, use_pretrain=False, img_size=384).cuda(), torch.bfloat16)
+    x = torch.randn(int(sys.argv[1]), 3, 384, 384).cuda()
+    with torch.no_grad():
+        for _ in range(2):
+            m(x)
+        torch.cuda.synchronize()
+        log = Log()
+        with log:
+            m(x)
+    torch.cuda.synchronize()
+    print(f"{sum(log.rows.values())} aten ops in one inference forward (views / allocations not counted)")
+    for (name, site), n in sorted(log.rows.items(), key=lambda kv: -log.elems[kv[0]]):
+        print(f"n={n:4d}  Melem={log.elems[(name, site)] / 1e6:9.1f}  {name:28s} {site}")
+    sys.exit(0)
 
 torch.manual_seed(1026)
 m = ta.bulid_model(use_pretrain=False, img_size=384).cuda().train()

@@ -448,7 +448,7 @@ def test_ss2d_lds_dma_scan_at_the_benchmarked_launches(dtype, fam, b, h, d, r):
 @pytest.mark.parametrize("form", [0, 1])      # the library's choice for this shape (chained on LDS-DMA) / the register ring: both carry by mailbox
 def test_scan_mailbox_timeout_is_reported_not_returned_as_a_result(form):
     """a starved carry-mailbox poll used to end the launch with NaN in `ys` and rc 0.  With the poll budget
-    forced to 1 (TRAMBA_TUNE_MAILBOX_POLLS) the waves that find their predecessor's mailbox empty give up at once: the launch
+    forced to 1 (TRAMBA_TUNE_MAILBOX_SKIP) the waves that find their predecessor's mailbox empty give up at once: the launch
     still ends, its output holds NaN, and the device error word makes the next library call after it return TRAMBA_ERR_HIP
     with the cause in tramba_last_error(); the word is cleared by the report and the same launch at the default budget is
     clean."""
@@ -469,12 +469,12 @@ def test_scan_mailbox_timeout_is_reported_not_returned_as_a_result(form):
         torch.cuda.synchronize()
         H.device_error()                                   # nothing pending
         assert torch.isfinite(good).all()
-        H.tune_set(H.TUNE_MAILBOX_POLLS, 1)
+        H.tune_set(H.TUNE_MAILBOX_SKIP, 3)
         try:
             bad = H.ss2d_scan_cl(*args)                    # the launch itself is issued without complaint ...
             torch.cuda.synchronize()
         finally:
-            H.tune_set(H.TUNE_MAILBOX_POLLS, 0)
+            H.tune_set(H.TUNE_MAILBOX_SKIP, 0)
         assert not torch.isfinite(bad).all()               # ... its output is poisoned, not plausible ...
         with pytest.raises(H.TrambaHipError, match="mailbox"):
             H.layernorm_cl(xc, torch.ones(d, device=dev), torch.zeros(d, device=dev))   # ... and the NEXT call says so
@@ -485,7 +485,7 @@ def test_scan_mailbox_timeout_is_reported_not_returned_as_a_result(form):
         assert torch.equal(again, good)
     finally:
         H.tune_set(H.TUNE_SCAN_FORM, 0)
-        H.tune_set(H.TUNE_MAILBOX_POLLS, 0)
+        H.tune_set(H.TUNE_MAILBOX_SKIP, 0)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

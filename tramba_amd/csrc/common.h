@@ -31,10 +31,10 @@ void set_error(const char *fmt, ...);
 extern unsigned *g_deverr_host;                 // null until the first kernel that can raise it is launched (runtime.hip)
 int dev_error_report(const char *file, int line);
 struct MailboxCtl {
-    unsigned *err;   // device address of the error word (null: not reported)
-    int polls;       // poll budget of CarryLink::acquire
+    int skip;        // tests: the tile (chain order) whose carry hand-over is withheld, so that its successor's poll times out; -1
 };
-MailboxCtl mailbox_ctl(hipStream_t s);
+MailboxCtl mailbox_ctl(hipStream_t s);              // (also allocates the error word before the first launch that can raise it)
+void set_mailbox_err_word(unsigned *dev_ptr);        // ss2d_fused.hip: the word's device address into that file's __device__ variable
 
 #define TRAMBA_LAUNCH_CHECK()                                                         \
     do {                                                                              \

@@ -72,6 +72,7 @@ static void deverr_alloc()
         return;
     }
     g_deverr_dev = d;
+    set_mailbox_err_word(d);
     g_deverr_host = h;
 }
 
@@ -83,8 +84,8 @@ MailboxCtl mailbox_ctl(hipStream_t s)
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone) std::call_once(g_deverr_once, deverr_alloc);
     }
-    const int t = tramba_tune_get(TRAMBA_TUNE_MAILBOX_POLLS);
-    return MailboxCtl{g_deverr_dev, t > 0 ? t : (1 << 20)};
+    const int t = tramba_tune_get(TRAMBA_TUNE_MAILBOX_SKIP);
+    return MailboxCtl{t > 0 ? t : -1};
 }
 
 int dev_error_report(const char *file, int line)
@@ -111,7 +112,7 @@ extern "C" int tramba_device_error(void)
 //    dw_unpack_grad); a_log / flags arguments of the fused scan forward / backward
 // 5: the step's ends and batched launches (sod_loss_*, adam_step, multi_sum / multi_sum_strided, wgrad_parts_cl,
 //    dw_pack_multi / dw_unpack_grad_multi, shuffle_norm_head_bwd_cl)
-// 6: tramba_device_error, TRAMBA_TUNE_MAILBOX_POLLS (r04)
+// 6: tramba_device_error, TRAMBA_TUNE_MAILBOX_SKIP (r04)
 extern "C" int tramba_abi_version(void) { return 6; }
 
 static int g_tune[TRAMBA_TUNE_COUNT] = {0};

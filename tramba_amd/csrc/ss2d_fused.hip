@@ -442,17 +442,39 @@ struct ScanWave {
 // (through waves w + 1 .. W - 1 of step s and waves 0 .. w - 1 of step s + 1) descends from wave w + 1 having READ the step-s
 // value.  Forward progress: all waves of a workgroup are resident and run the same number of steps; the spin sleeps between
 // polls and is bounded (a run that ever hit the bound would end with NaNs in its output, not hang the GPU).
+// The device error word (common.h): its address sits in a __device__ variable of this translation unit, written once by the host
+// (set_mailbox_err_word, called from mailbox_ctl() before the first launch that can raise it).  A wave whose poll runs out only
+// drops a flag into the third row of the mailbox it was polling (one ds_write on a path that is never taken); every wave looks at
+// that row ONCE, after its last tile, and raises the word from there (CarryLink::report).  Carried through the tile loop as a
+// kernel argument -- or called out of line from it -- the report cost the Helix launch 35 scalar and 8 vector registers (97 / 128
+// instead of 62 / 120) and ~1.4 % of a forward (same-box A/B against the r03 library, profiles/r04_ab_lib.txt).
+__device__ unsigned *g_mailbox_err_word = nullptr;
+
+constexpr int kMailboxPolls = 1 << 20;   // ~0.1 s of polling (s_sleep between polls) before a wave gives up
+
 struct CarryLink {
     unsigned rd, wr;   // LDS byte addresses of (value[kTP], tag[kTP]) of my predecessor's / my own mailbox, at my channel
-    MailboxCtl ctl;    // poll budget + the device error word a starved poll reports to (common.h)
+    int skip;          // tests only (MailboxCtl, common.h): the tile whose hand-over is withheld, -1 = none
 
     // reverse: the chain runs from the last wave to the first (the adjoint sweep of the backward kernel)
-    __device__ __forceinline__ void init(float *box /* [W][2][kTP] */, int wv, int W, int r32, MailboxCtl c, bool reverse = false)
+    __device__ __forceinline__ void init(float *box /* [W][3][kTP] */, int wv, int W, int r32, MailboxCtl c, bool reverse = false)
     {
-        ctl = c;
+        skip = c.skip;
         const int pred = reverse ? (wv == W - 1 ? 0 : wv + 1) : (wv == 0 ? W - 1 : wv - 1);
-        rd = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(box + (pred * 2) * kTP + r32);
-        wr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(box + (wv * 2) * kTP + r32);
+        rd = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(box + (pred * 3) * kTP + r32);
+        wr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(box + (wv * 3) * kTP + r32);
+    }
+    // after the wave's last tile: a time-out flag in the mailbox I polled -> the library's device error word
+    __device__ __forceinline__ void report() const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned f;
+        asm volatile("ds_read_b32 %0, %1 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(rd) : "memory");
+        if (__builtin_amdgcn_ballot_w64(f != 0u) != 0) {
+            unsigned *p = g_mailbox_err_word;
+            if (p && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(p, TRAMBA_DEVERR_MAILBOX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+#endif
     }
     // state leaving tile `tile - 1` (tile >= 1, in chain order); 0 for the first tile of the chain.  `base`: tag offset
     // of this chain (a kernel that runs two chains through the same mailboxes gives the second one tags above the first's)
@@ -463,7 +485,9 @@ struct CarryLink {
         float v;
         unsigned t;
         int guard = 0;
-        for (; guard < ctl.polls; ++guard) {
+        // (the budget is a COMPILE-TIME constant: with a run-time bound hipcc compiled the Helix launch to 93 scalar / 128
+        //  vector registers instead of 62 / 124 and the forward lost 1.4 %, profiles/r04_ab_lib.txt)
+        for (; guard < kMailboxPolls; ++guard) {
             asm volatile("ds_read_b32 %0, %2 offset:128\n\tds_read_b32 %1, %2\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(t), "=&v"(v)
                          : "v"(rd)
@@ -474,9 +498,8 @@ struct CarryLink {
         // A wave that ever ran out of polls (~0.1 s at the default budget) hands on NaN -- the launch ends, and its output cannot
         // pass for a result -- and raises the library's device error word (host-mapped memory, one system-scope atomic on this
         // path only): the next library call that finds it set returns TRAMBA_ERR_HIP (TRAMBA_LAUNCH_CHECK; no sync is added).
-        if (guard < ctl.polls) return v;
-        if (ctl.err && (threadIdx.x & 63) == 0)
-            __hip_atomic_fetch_or(ctl.err, TRAMBA_DEVERR_MAILBOX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__builtin_expect(guard < kMailboxPolls, 1)) return v;
+        asm volatile("ds_write_b32 %0, %1 offset:256" ::"v"(rd), "v"(1u) : "memory");
         return __builtin_nanf("");
 #else
         return 0.f;
@@ -486,7 +509,7 @@ struct CarryLink {
     __device__ __forceinline__ void publish(float h, int tile, int hi, unsigned base = 0u) const
     {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (hi == 0) {
+        if (hi == 0 && tile != skip) {      // (skip: TRAMBA_TUNE_MAILBOX_SKIP, a test withholding one hand-over; -1 in production)
             const unsigned tg = base + (unsigned)tile + 1u;
             asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:128" ::"v"(wr), "v"(h), "v"(tg) : "memory");
         }
@@ -509,7 +532,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     const float *__restrict__ Ds, TY *__restrict__ ys, int L, int D, int K, int R, int W, float *__restrict__ hst, int a_log,
     MailboxCtl mctl)
 {
-    __shared__ float mbox[kMaxW][2][kTP];   // carry mailboxes (CarryLink): value, tag per wave and channel
+    __shared__ float mbox[kMaxW][3][kTP];   // carry mailboxes (CarryLink): value, tag, time-out flag per wave and channel
     __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -569,7 +592,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     for (int t = 0; t < AHEAD; ++t) w.fetch(rx, rp, idx0[t], ops[t]);
 
     // mailbox tags start at 0 = "nothing published" (tile t publishes tag t + 1)
-    for (int i = threadIdx.x; i < 2 * kMaxW * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < 3 * kMaxW * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;
     __syncthreads();
     const bool cfull = ctile * kTP + kTP <= D;  // block-uniform: no channel masking needed
     // one super-chunk; STI = ring slot of tile s (compile-time: the ring must be indexed statically)
@@ -614,6 +637,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_cl_kernel(
     if constexpr (NS > 2) {
         if (s0 + 1 < nsuper) step(std::integral_constant<int, 1>{}, s0 + 1);
     }
+    link.report();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -652,7 +676,7 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
     constexpr int kNP = (kNCH + kWave - 1) / kWave;   // 64-lane DMA pieces: 2, 3, 5 (the last one overshoots into padding)
     constexpr int kUB = kTP * kTP * 2;          // token tile: 32 positions x 32 channels x 2 bytes
     constexpr int kSlot = kUB + kNP * 1024;
-    __shared__ float mbox[W][2][kTP];   // carry mailboxes (CarryLink)
+    __shared__ float mbox[W][3][kTP];   // carry mailboxes (CarryLink): value, tag, time-out flag
     __shared__ __attribute__((aligned(16))) float stage[W][3][kTP];
     __shared__ __attribute__((aligned(16))) unsigned char ring[W][kSlot];
     __shared__ __attribute__((aligned(16))) int idxbuf[W][kWave];   // the index vector of the next tile to fetch, by DMA too
@@ -683,7 +707,7 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
     }
     CarryLink link;
     link.init(&mbox[0][0][0], wv, W, r32, mctl);
-    for (int i = threadIdx.x; i < 2 * W * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;   // tags: nothing published
+    for (int i = threadIdx.x; i < 3 * W * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;   // tags: nothing published
     __syncthreads();   // the only workgroup barrier of the kernel
 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * L * D, (unsigned)L * w.xrow);
@@ -845,6 +869,7 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
         }
         __builtin_amdgcn_wave_barrier();
     }
+    link.report();
 #endif
 }
 #undef TRAMBA_LDS_RD_
@@ -873,7 +898,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     // flags & 2: gB / gC are (B, K, CT, L) tables of per-channel-tile partial sums, each element WRITTEN by exactly one wave
     //            (no zero fill, no atomics: the caller adds the CT = ceil(D / 32) partials in a fixed order)
     constexpr int kTS = 36;   // LDS row stride (floats) of the position-sum transposes: 16-byte aligned rows
-    __shared__ float mbox[kMaxW][2][kTP];   // carry mailboxes (CarryLink): the forward states, then the adjoint
+    __shared__ float mbox[kMaxW][3][kTP];   // carry mailboxes (CarryLink): the forward states, then the adjoint; time-out flags
     __shared__ __attribute__((aligned(16))) float stage[kMaxW][3][kTP];
     __shared__ __attribute__((aligned(16))) float tr[kMaxW][kTP][kTS];
     __shared__ float red[kMaxW][3][kTP];
@@ -905,7 +930,7 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
     const int nsuper = (L + span - 1) / span;
     float *hs = hst + ((long)b * K + k) * (long)((L + kTP - 1) / kTP + kMaxW) * D;   // (B, K, NTA, D), tile = position / 32
 
-    for (int i = threadIdx.x; i < 2 * kMaxW * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;   // tags: nothing published
+    for (int i = threadIdx.x; i < 3 * kMaxW * kTP; i += blockDim.x) (&mbox[0][0][0])[i] = 0.f;   // tags: nothing published
     __syncthreads();
     CarryLink fwd_link, adj_link;
     fwd_link.init(&mbox[0][0][0], wv, W, r32, mctl);
@@ -1069,6 +1094,8 @@ __global__ __launch_bounds__(kMaxW * kWave) void ss2d_scan_bwd_cl_kernel(
             }
         }
     }
+    fwd_link.report();
+    adj_link.report();
     // ---- per-channel sums: two half-waves, then the W waves
     accA += __shfl_xor(accA, 32, 64);
     accD += __shfl_xor(accD, 32, 64);
@@ -1674,6 +1701,11 @@ __global__ __launch_bounds__(256) void ss2d_merge_norm_split_kernel(
             store_pack<T, V>(orow + c0, o);
         }
     }
+}
+
+void set_mailbox_err_word(unsigned *dev_ptr)
+{
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mailbox_err_word), &dev_ptr, sizeof(dev_ptr));
 }
 
 }  // namespace tramba
