@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Same-box A/B of the training step (Tramba-V 384x384, batch 8, bf16, stochastic depth on; BASELINE configs[2]) between
 TRAMBA_TUNE_GEMM_TILE settings: every variant is its own model + GraphedTrainStep captured with that knob value, and the graphs
-are replayed alternately in ONE process.  usage: python scripts/ab_train.py [tune values, default: 18 0]"""
+are replayed alternately in ONE process.  usage: python scripts/ab_train.py [tune values, default: 18 0]
+A value >= 200 means: tune value - 200 with the guide branches on a side stream (models.OVERLAP_TRAINING = True, off by default)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tramba_amd as ta
-from tramba_amd import hip, train
+from tramba_amd import hip, models, train
 
 vals = [int(v) for v in sys.argv[1:]] or [18, 0]
 b = 8
@@ -17,12 +18,14 @@ for v in vals:
     m = ta.bulid_model(use_pretrain=False, img_size=384).cuda().train()
     m.compute_dtype = torch.bfloat16
     st = ta.GraphedTrainStep(m, train.get_opt(1e-4, m, capturable=True))
-    hip.tune_set(hip.TUNE_GEMM_TILE, v)
+    hip.tune_set(hip.TUNE_GEMM_TILE, v % 200)
+    models.OVERLAP_TRAINING = v >= 200
     try:
         for _ in range(3):
             loss = st(x, y)
     finally:
         hip.tune_set(hip.TUNE_GEMM_TILE, 0)
+        models.OVERLAP_TRAINING = False
     torch.cuda.synchronize()
     steps[v] = st
     print(f"tune {v}: captured, loss {float(loss):.4f}", flush=True)

@@ -1220,6 +1220,7 @@ def flush_sums():
         nsl = (ctypes.c_int * cnt)(*[it[3] for it in its])
         strides = (ctypes.c_int64 * cnt)(*[it[6] for it in its])
         _check(lib().tramba_multi_sum_strided(parts, outs, ns, strides, nsl, cnt, stream), "multi_sum")
+    streams = set(by_stream)
     by_stream = {}
     for it in unpacks:          # (a table and its unpack are recorded on the same stream: the sums above come first)
         by_stream.setdefault(it[8], []).append(it)
@@ -1228,6 +1229,18 @@ def flush_sums():
         cols = [(ctypes.c_void_p * cnt)(*[it[k] for it in its]) for k in range(5)]
         ints = [(ctypes.c_int * cnt)(*[it[k] for it in its]) for k in (5, 6, 7)]
         _check(lib().tramba_dw_unpack_grad_multi(*cols, *ints, cnt, stream), "dw_unpack_grad_multi")
+    streams |= set(by_stream)
+    # sums recorded on ANOTHER stream (the guide branches' backward runs on the side stream of models._forward_overlapped) were
+    # launched there: whatever the caller's stream does next -- the optimizer reads these gradients -- must come after them
+    cur = _stream()
+    others = [st for st in streams if st != cur]
+    if others:
+        here = torch.cuda.current_stream()
+        for st in others:
+            ext = torch.cuda.ExternalStream(st)
+            ev = torch.cuda.Event()
+            ev.record(ext)
+            here.wait_event(ev)
 
 
 def pending_sums():
