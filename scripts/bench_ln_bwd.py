@@ -13,6 +13,7 @@ def child(path):
     from tramba_amd import hip
     if path != "product":
         hip.LIB_PATH = path
+        hip.SIGNATURES.pop("tramba_device_error", None)     # (older libraries: ABI 5)
     dev = torch.device("cuda")
     tot = 0.0
     for rows, c in SHAPES:
