@@ -106,7 +106,10 @@ int tramba_tune_get(int knob);
                                         10 / 11 / 12 = 384 / 512 / 768 workgroups wanted by the token split */
 #define TRAMBA_TUNE_MAILBOX_SKIP 4   /* tests only: > 0 withholds the carry hand-over of that tile (chain order) in the fused scans, so that
                                         the wave waiting for it runs out of polls (~0.1 s) and the device error word is raised; 0 = off */
-#define TRAMBA_TUNE_COUNT 5
+#define TRAMBA_TUNE_WGRAD_FORM 5     /* weight-gradient TN GEMM alone: 1 = the register-staged kernel (as TRAMBA_TUNE_GEMM_TILE 8, which also switches
+                                        the projections); 2 = the LDS-DMA kernel with r03's counted lgkmcnt waits on its transposed reads
+                                        (NOT safe beside other kernels on the same CU: scripts/dev/debug_wgrad_concurrent.py) */
+#define TRAMBA_TUNE_COUNT 6
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1
 #define TRAMBA_PROF_GEMM 2          /* tramba_linear_cl (1x1-conv projections) */

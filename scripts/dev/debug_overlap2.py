@@ -18,6 +18,16 @@ x = torch.randn(8, 3, 384, 384, generator=torch.Generator().manual_seed(0)).cuda
 y = (torch.rand(8, 1, 384, 384, generator=torch.Generator().manual_seed(1)) > 0.7).float().cuda()
 opt = train.get_opt(1e-4, m)
 models._DEBUG_STREAMS = []
+if mode.startswith("tn"):          # no LDS-DMA GEMM kernels: register-staged weight-gradient and projection kernels (tune 8)
+    hip.tune_set(hip.TUNE_GEMM_TILE, 8)
+if mode.startswith("t18"):         # the r03 LDS-DMA projection kernels (no producer / consumer, no weight-stationary form)
+    hip.tune_set(hip.TUNE_GEMM_TILE, 18)
+if mode.startswith("wg"):          # only the weight-gradient GEMM on its register-staged kernel
+    hip.tune_set(hip.TUNE_WGRAD_FORM, 1)
+if mode.startswith("sc"):          # the fused scans on the register ring (no LDS-DMA scan kernel)
+    hip.tune_set(hip.TUNE_SCAN_FORM, 1)
+if mode.startswith("st"):          # st0 / st1 / st2 / st01 ...: only these guide branches run on the side stream
+    models._OVERLAP_TRAINING_STAGES = {int(c) for c in mode[2:].split("_")[0]}
 print("main stream", torch.cuda.current_stream().cuda_stream, "side", models._side_stream(x.device).cuda_stream)
 if mode == "anomaly":
     torch.autograd.set_detect_anomaly(True, check_nan=True)

@@ -915,6 +915,51 @@ def test_ss2d_scan_backward_at_the_benchmarked_launches(fam, b, h, d, r):
     print("scan backward vs fp64 oracle (max / rms relative):", fam, h, {n: (round(a, 5), round(c, 5)) for n, (a, c) in worst.items()})
 
 
+@pytest.mark.parametrize("partner", ["linear_pc", "linear_ws", "scan_dma"])
+def test_wgrad_is_bitwise_stable_beside_another_stream(partner):
+    """r04: tramba_wgrad_cl (wgrad_dma_kernel: LDS-DMA staged token tiles read back TRANSPOSED by ds_read_b64_tr_b16) while a
+    second stream keeps the CUs busy with an LDS-heavy kernel of another kind -- the producer / consumer and weight-stationary
+    projections, the LDS-DMA scan.  With r03's counted lgkmcnt waits on the transposed reads 16-28 of 180 such launches
+    differed from the launch running alone (a few elements, NaN now and then: the data-parallel step overlaps RCCL kernels
+    with backward the same way); the kernel now waits for all reads of a step before its first MFMA."""
+    H = hip()
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(3)
+    shapes = [(4608, 512, 2048), (4608, 1024, 512), (18432, 256, 1024), (73728, 128, 512), (1152, 1024, 4096)]
+    ops = [(torch.randn(m, n, generator=g).bfloat16().to(dev), torch.randn(m, k, generator=g).bfloat16().to(dev)) for m, n, k in shapes]
+    if partner == "scan_dma":
+        b, h, d, r, kk = 8, 96, 256, 8, 8
+        order = H.scan_order("helix", h, h, dev)
+        xc = torch.randn(b, h * h, d, generator=g).bfloat16().to(dev)
+        wx = (torch.randn(kk, r + 2, d, generator=g) * d ** -0.5).bfloat16().to(dev)
+        xdbl = H.linear_cl(xc, H.pad_x_proj_weight(wx), out_dtype=torch.float32)
+        sargs = (xc, xdbl, order, (torch.randn(kk, d, r, generator=g) * r ** -0.5).to(dev),
+                 (torch.randn(kk * d, generator=g) * 0.5 - 2.0).to(dev), (-0.5 - torch.rand(kk * d, generator=g)).to(dev),
+                 torch.ones(kk * d).to(dev), torch.bfloat16)
+        other = lambda: H.ss2d_scan_cl(*sargs)
+    elif partner == "linear_ws":
+        a = torch.randn(73728, 128, generator=g).bfloat16().to(dev)
+        w = (torch.randn(512, 128, generator=g) * 0.1).bfloat16().to(dev)
+        other = lambda: H.linear_cl(a, w, None, None, 2)
+    else:
+        a = torch.randn(4608, 2048, generator=g).bfloat16().to(dev)
+        w = (torch.randn(512, 2048, generator=g) * 0.02).bfloat16().to(dev)
+        other = lambda: H.linear_cl(a, w, None, None, 0)
+    ref = [H.wgrad_cl(gy, x, True) for gy, x in ops]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    bad = 0
+    for _ in range(20):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                other()
+        outs = [H.wgrad_cl(gy, x, True) for gy, x in ops]
+        torch.cuda.synchronize()
+        bad += sum(int(not (torch.equal(o[0], r_[0]) and torch.equal(o[1], r_[1]))) for o, r_ in zip(outs, ref))
+    assert bad == 0, f"{bad} of {20 * len(ops)} weight-gradient launches differ beside {partner}"
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [(2304, 512, 512, 512), (300, 128, 64, 192), (9216, 256, 256, 256), (1000, 72, 128, 64)])
 def test_linear2_cl_matches_concatenated_gemm(dtype, cfg):

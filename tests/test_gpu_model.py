@@ -645,6 +645,45 @@ def test_tramba_v_768_fp16_at_the_baseline_batch(c5_oracle):
             assert float(((o[i] > 0) != (alone[i][j][0] > 0)).float().mean()) < 2e-3   # saliency decisions
 
 
+def test_training_guide_branch_overlap_is_bitwise_neutral():
+    """r04: under autograd the decoder's guide branches run on a side stream too (models.OVERLAP_TRAINING), forward and -- through
+    the autograd engine's stream rule -- backward, their deferred partial sums flushed on that stream: losses, every parameter
+    gradient and the weights after three optimisation steps at the BASELINE batch (8) are BIT-identical to the single-stream
+    step, eagerly and as one hipGraph.  (The first version of this test failed one run in four: wgrad_dma_kernel consumed
+    transposed LDS reads behind counted lgkmcnt waits, which only hold while no other kernel shares the CU.)"""
+    import tramba_amd as ta
+    from tramba_amd import models, train
+
+    def run(overlap, graphed):
+        models.OVERLAP_TRAINING = overlap
+        try:
+            torch.manual_seed(7)
+            m = ta.bulid_model(use_pretrain=False, img_size=384).to(DEV).train()
+            for mod in m.modules():
+                if isinstance(mod, ta.DropPath):
+                    mod.drop_prob = 0.0
+            m.compute_dtype = torch.bfloat16
+            x = torch.randn(8, 3, 384, 384, generator=torch.Generator().manual_seed(0)).to(DEV)
+            y = (torch.rand(8, 1, 384, 384, generator=torch.Generator().manual_seed(1)) > 0.7).float().to(DEV)
+            opt = train.get_opt(1e-4, m, capturable=graphed)
+            step = ta.GraphedTrainStep(m, opt) if graphed else (lambda a, b: train.train_step(m, opt, a, b))
+            losses = [float(step(x, y)) for _ in range(3)]
+            torch.cuda.synchronize()
+            grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+            return losses, grads, {n: p.detach().clone() for n, p in m.named_parameters()}
+        finally:
+            models.OVERLAP_TRAINING = True
+
+    for graphed in (False, True):
+        l0, g0, w0 = run(False, graphed)
+        for _ in range(2):                       # twice: the failure this test was written for came and went
+            l1, g1, w1 = run(True, graphed)
+            assert l0 == l1, (graphed, l0, l1)
+            assert g0.keys() == g1.keys()
+            bad = [n for n in g0 if not torch.equal(g0[n], g1[n])] + [n for n in w0 if not torch.equal(w0[n], w1[n])]
+            assert not bad, (graphed, len(bad), bad[:6])
+
+
 def test_training_weight_shadows_follow_the_optimizer():
     """train_step refreshes the bf16 shadows of the fp32 Linear2d weights with one fused cast; a shadow is used only while
     its parameter is unchanged (version counter), so an out-of-band update falls back to a fresh cast."""

@@ -869,6 +869,13 @@ __global__ __launch_bounds__(W * kWave, W == 16 ? 1 : 4) void ss2d_scan_dma_kern
         }
         __builtin_amdgcn_wave_barrier();
     }
+    // The last step has requested one more tile (clamped past the end, never read): those LDS-DMA writes must have LANDED before
+    // this wave ends.  A workgroup's LDS is released when its waves have ended, and a write still in flight then lands in
+    // whatever workgroup the CU gives that LDS to next -- under one stream there is none (one workgroup per CU, and the next
+    // kernel starts after this one has drained), but a GEMM workgroup of ANOTHER stream takes the CU at once and finds 1 KB
+    // pieces of a token tile in its staged operands: r04, the training step with the guide branches on a side stream ended in
+    // NaN gradients about one run in four (scripts/dev/debug_overlap2.py), and the inference forward has run this way since r01.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     link.report();
 #endif
 }

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a)
     float bsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-    const bool do_bias = a.want_bias && bx == 0;
+    const bool do_bias = (a.want_bias & 1) && bx == 0;
     auto stash = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradArgs a)
     }
     // bias column sums (k-tile 0 only): thread t re-reads chunk positions t % 16 of rows t / 16 and t / 16 + 16 of the gy
     // tile -- both rows hold the same channel chunk there, (t % 16) ^ 4 ((t / 16) & 3)
-    const bool do_bias = a.want_bias && bx == 0;
+    const bool do_bias = (a.want_bias & 1) && bx == 0;
+    const bool counted = (a.want_bias & 256) != 0;    // (TRAMBA_TUNE_WGRAD_FORM 2: the r03 counted waits, for measurements only)
     const unsigned ba = lbase + (unsigned)((tid >> 4) * 256 + (tid & 15) * 16);
     float bsum[8];
 #pragma unroll
@@ -345,6 +346,14 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradArgs a)
                 asm volatile("ds_read_b128 %0, %1 offset:53248" : "=v"(bv[1]) : "v"(ba) : "memory");
             }
         }
+        // r04: ALL of the step's transposed reads have returned before the first MFMA.  r03 waited for them four at a time with
+        // counted lgkmcnt values ("the reads return in order") -- true while only workgroups of THIS kernel share the CU, but with
+        // a workgroup of another LDS-heavy kernel beside it (the projections' ds_read_b128 traffic, the fused scans') the MFMAs
+        // now and then consumed a ds_read_b64_tr_b16 destination that had not been written yet: weight gradients that differ from
+        // run to run in a few elements, NaN about one training step in a hundred -- found when the guide branches' backward first ran on
+        // a second stream (scripts/dev/debug_wgrad_concurrent.py: 16-28 of 180 launches differ beside linear_pc / linear_ws /
+        // scan_dma, 0 with this wait; the counted waits below then never wait).  Costs nothing measurable (scripts/bench_wgrad.py).
+        if (!counted) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         auto mk = [](v2u32 lo, v2u32 hi) -> frag8s {
             const v4u32 v = {lo.x, lo.y, hi.x, hi.y};
             return __builtin_bit_cast(frag8s, v);
@@ -771,12 +780,13 @@ static int wgrad_launch(const void *gy, const void *x, float *out, void *workspa
     const bool direct = nsplit * nbatch == 1;          // one slab per group: it IS the result
     a.gy = gy; a.x = x; a.part = direct ? out : (float *)workspace;
     a.gy_bs = gy_bs; a.gy_gs = gy_gs; a.x_bs = x_bs; a.x_gs = x_gs; a.gy_ld = gy_ld; a.x_ld = x_ld;
-    a.M = (int)m; a.N = n; a.K = k; a.nbatch = nbatch; a.nsplit = nsplit; a.mchunk = mchunk; a.want_bias = want_bias;
+    a.M = (int)m; a.N = n; a.K = k; a.nbatch = nbatch; a.nsplit = nsplit; a.mchunk = mchunk; a.want_bias = want_bias ? 1 : 0;
+    if (tramba_tune_get(TRAMBA_TUNE_WGRAD_FORM) == 2) a.want_bias |= 256;
     dim3 grid((k + kWgTile - 1) / kWgTile, (n + kWgTile - 1) / kWgTile, groups * nbatch * nsplit), block(256);
     // LDS-DMA staged tiles (the default) need 32-bit byte offsets inside one (group, batch) operand -- checked above -- and
     // rows of whole 16-byte chunks; TRAMBA_TUNE_GEMM_TILE 8 / 9 select the register-staged form / 4 stages for measurements
     const int tune = tramba_tune_get(TRAMBA_TUNE_GEMM_TILE);
-    if (tune == 8) {
+    if (tune == 8 || tramba_tune_get(TRAMBA_TUNE_WGRAD_FORM) == 1) {
         if (dtype == TRAMBA_BF16) hipLaunchKernelGGL((wgrad_tn_kernel<__hip_bfloat16>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((wgrad_tn_kernel<__half>), grid, block, 0, s, a);
     } else if (tune == 9) {

@@ -245,7 +245,7 @@ def scan_order(family: str, h: int, w: int, device, param: int = 0) -> ScanOrder
 
 
 # ----------------------------------------------------------------------------- profiling / tuning
-TUNE_MERGE_FORM, TUNE_SCAN_FORM, TUNE_SCAN_W, TUNE_GEMM_TILE, TUNE_MAILBOX_SKIP = 0, 1, 2, 3, 4
+TUNE_MERGE_FORM, TUNE_SCAN_FORM, TUNE_SCAN_W, TUNE_GEMM_TILE, TUNE_MAILBOX_SKIP, TUNE_WGRAD_FORM = 0, 1, 2, 3, 4, 5
 
 
 def device_error():

@@ -21,16 +21,13 @@ from .ops import CrossMerge_Line, CrossScan_Line
 # Independent branches of the inference graph run on separate HIP streams; profiling passes that want every kernel timed
 # alone set this False (a scheduling choice: the kernels are the same either way).
 OVERLAP_BRANCHES = True
-# r04: the same fork under autograd (the training step) -- BUILT, MEASURED, OFF.  The autograd engine runs every backward node on the
-# stream its forward ran on and synchronises where a gradient changes hands, so the guide branches' backward overlaps the encoder's
-# deep stages as their forward does: 30.50 -> 29.99 ms per step as one hipGraph (scripts/ab_train.py 100 0, same box).  But the step
-# is then not reproducible: at batch 8 the loss after one update differs from run to run in the sixth digit and about one run in
-# four ends in NaN gradients upstream of the 96 x 96 fork (scripts/dev/debug_overlap2.py; never with the allocator's caching off or
-# under anomaly mode, both of which serialise the streams; explicit event waits and record_stream on both edges of every fork --
-# _StreamEdge below -- do not cure it; the single-stream step reads no uninitialised memory, scripts/dev/debug_poison.py).  A
-# dependency between the two streams is missing somewhere outside the edges autograd knows about; until it is found the training
-# step stays on one stream.
-OVERLAP_TRAINING = False
+# r04: the same fork under autograd (the training step).  The autograd engine runs every backward node on the stream its forward ran
+# on and synchronises where a gradient changes hands, so the guide branches' backward overlaps the encoder's deep stages as their
+# forward does: 30.50 -> 29.99 ms per step as one hipGraph (scripts/ab_train.py, same box).  Bit-identical to the single-stream step
+# (tests/test_gpu_model.py) -- once the weight-gradient GEMM waited for ALL of its transposed LDS reads: the first overlapped steps
+# differed from run to run and went NaN one time in four, and the cause was a kernel, not a missing dependency (train_gemm.hip,
+# wgrad_dma_kernel; scripts/dev/debug_overlap2.py and debug_wgrad_concurrent.py are the reproductions).
+OVERLAP_TRAINING = True
 _side_streams = {}
 
 
@@ -47,7 +44,7 @@ class _StreamEdge(torch.autograd.Function):
     gradient travelling the other way as used by the stream that will read it.  The caching allocator hands a freed block
     back to the pool of the stream it was allocated on at once; a gradient allocated on one stream and consumed on the other
     must therefore carry a record_stream for the consumer, or the block is re-used under the consumer's still-queued kernel
-    (r04, models.OVERLAP_TRAINING: necessary, not sufficient -- see the note there)."""
+    (r04, models.OVERLAP_TRAINING; the autograd engine does the same for the edges it routes itself)."""
 
     @staticmethod
     def forward(ctx, x, consumer_of_grad):
@@ -70,6 +67,7 @@ class _StreamEdge(torch.autograd.Function):
 
 
 _DEBUG_STREAMS = None
+_OVERLAP_TRAINING_STAGES = None
 
 
 def _bias_scalar(conv: nn.Conv2d) -> float:
@@ -227,6 +225,8 @@ class BaseUMamba(nn.Module):
             s = n - 2 - i
             if s < 0 or s >= len(dec.guide_layers):
                 return
+            if torch.is_grad_enabled() and _OVERLAP_TRAINING_STAGES is not None and s not in _OVERLAP_TRAINING_STAGES:
+                return                  # (debugging aid of scripts/dev/debug_overlap2.py: only these guide branches fork)
             side.wait_stream(main)
             feat.record_stream(side)
             with torch.cuda.stream(side):
