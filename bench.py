@@ -37,7 +37,8 @@ Rank 0 prints ONE JSON line.  Objects on that line besides the contract's fields
                 `train.eager` / `train.graphed`); `train.scaling_value` = `train.value` (THE figure a data-parallel scaling
                 curve is about: the forward leg at N > 1 is independent replicas); `train.roofline` = the forward +
                 input-gradient GEMMs of the step against the dense MFMA peak, `train.roofline_wgrad` = the weight-gradient
-                GEMMs, `train.roofline_scan_bwd` = the fused scan backward (12 B per element), `train.roofline_adam`
+                GEMMs, `train.roofline_scan_bwd` = the fused scan backward (12 B per element), `train.roofline_layernorm` / `train.roofline_dw`
+                = the two streaming families (LayerNorm forms and depth-wise stencils, HIP-event timed per call), `train.roofline_adam`
                 = the optimizer step against the HBM peak (28 B per parameter), all launches
                 and the Helix top-stage launch alone; each of the three carries `traffic` = PMC bytes per step of its kernel
                 family at batch 8 (`traffic_source`: profiles/<tag>_train_traffic.json, scripts/pmc_train.sh);
@@ -532,14 +533,17 @@ def bench_train(args, world, rank, dtype, sync_all, publish=None):
     # the dominant kernel family of the step: forward + input-gradient GEMMs (tramba_linear_cl), HIP-event pairs around
     # every launch of two extra eager steps (not part of the timed region)
     from tramba_amd import hip
-    for which in (hip.PROF_GEMM, hip.PROF_WGRAD, hip.PROF_SCAN_BWD):
+    fams = (hip.PROF_GEMM, hip.PROF_WGRAD, hip.PROF_SCAN_BWD, hip.PROF_LAYERNORM, hip.PROF_DW)
+    for which in fams:
         hip.profile_enable(which, True)
     for _ in range(2):
         train.train_step(model, opt, x, y, reducer=red)
     ng, msg, flops = hip.profile_read(hip.PROF_GEMM)
     nw, msw, flopw = hip.profile_read(hip.PROF_WGRAD)
     nsb, mssb, bytes_sb = hip.profile_read(hip.PROF_SCAN_BWD)
-    for which in (hip.PROF_GEMM, hip.PROF_WGRAD, hip.PROF_SCAN_BWD):
+    nln, msln, bytes_ln = hip.profile_read(hip.PROF_LAYERNORM)
+    ndw, msdw, bytes_dw = hip.profile_read(hip.PROF_DW)
+    for which in fams:
         hip.profile_enable(which, False)
     # the Helix top-stage launch of the scan backward alone (the largest one: 12 B x B*K*L*D elements)
     hh = args.img // 4
@@ -595,6 +599,30 @@ def bench_train(args, world, rank, dtype, sync_all, publish=None):
               "launches": nw // 2, "avg_us": round(msw / max(nw, 1) * 1e3, 2), "ms_per_step": round(msw / 2, 3),
               "note": "2*M*N*K of every tramba_wgrad_cl call / HIP-event time around the call (TN GEMM + its fixed-order slab "
                       "sum), two eager steps"}
+    # the two streaming families of the step: every launch of the LayerNorm family (forward, residual-add forms,
+    # pixel-shuffle forms, backward) and of the depth-wise stencils (forward, input gradient = the same kernel on flipped taps,
+    # weight gradient); bytes = each activation-sized tensor of a call once
+    tr_ln, src_ln = train_traffic(("layernorm forward",)) if b == 8 else (None, None)
+    tr_dw, src_dw = train_traffic(("depth-wise",)) if b == 8 else (None, None)
+    gln = bytes_ln / (msln * 1e-3) / 1e9 if msln > 0 else 0.0
+    gdw = bytes_dw / (msdw * 1e-3) / 1e9 if msdw > 0 else 0.0
+    roof_ln = {"bound": "hbm", "kernel": "layernorm_* / add_ln_* / layernorm_bwd_* kernels, every launch of a step",
+               "achieved": round(gln, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gln / HBM_PEAK_GBS, 4),
+               "traffic": tr_ln, "traffic_source": src_ln, "traffic_unit": "bytes per step, all launches of the family",
+               "algorithmic_bytes_per_step": int(bytes_ln / 2), "launches": nln // 2,
+               "avg_us": round(msln / max(nln, 1) * 1e3, 2), "ms_per_step": round(msln / 2, 3),
+               "formula": "bytes of every activation-sized tensor a call reads or writes once (forward: x, y; residual form: + the "
+                          "branch and the sum; backward: x, dy, dx (+ the skip gradient and the masked copy)) / HIP-event time "
+                          "around the call, two eager steps"}
+    roof_dw = {"bound": "hbm", "kernel": "dwconv4_cl_kernel (forward and input gradient) + dwconv_wgrad_cl_kernel, every launch of a step",
+               "achieved": round(gdw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gdw / HBM_PEAK_GBS, 4),
+               "traffic": tr_dw, "traffic_source": src_dw, "traffic_unit": "bytes per step, all launches of the family",
+               "algorithmic_bytes_per_step": int(bytes_dw / 2), "launches": ndw // 2,
+               "avg_us": round(msdw / max(ndw, 1) * 1e3, 2), "ms_per_step": round(msdw / 2, 3),
+               "formula": "x read + y written (+ the pre-activation copy) per stencil launch, x + gy read per weight-gradient launch / "
+                          "HIP-event time around the call, two eager steps",
+               "note": "the 7x7 launches are bound by their 49 FMAs per output through the vector ALUs and the L1 re-reads of the "
+                       "taps' rows (DESIGN section 4), not by HBM"}
     gsb = bytes_sb / (mssb * 1e-3) / 1e9 if mssb > 0 else 0.0
     roof_sb = {"bound": "valu", "kernel": "ss2d_scan_bwd_cl_kernel, all 33 launches of a step", "achieved": round(gsb, 1),
                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gsb / HBM_PEAK_GBS, 4), "traffic": tr_sb,
@@ -634,7 +662,8 @@ def bench_train(args, world, rank, dtype, sync_all, publish=None):
                 "parallelism": f"dp{world}" + ((", RCCL all-reduce (ncclAvg)" if args.backend == "nccl" else ", gloo all-reduce")
                                                 + " of gradient buckets from autograd hooks" if world > 1 else ", no collective"),
                 "stochastic_depth": "on (0.6 enc / 0.2 dec)", "dtype": args.dtype + " activations, fp32 master weights",
-                "roofline": roof, "roofline_wgrad": roof_w, "roofline_scan_bwd": roof_sb, "roofline_adam": roof_adam, "eager": eager,
+                "roofline": roof, "roofline_wgrad": roof_w, "roofline_scan_bwd": roof_sb, "roofline_adam": roof_adam,
+                "roofline_layernorm": roof_ln, "roofline_dw": roof_dw, "eager": eager,
                 "graphed": graphed,
                 "step_ms_by_rank": dict(by_rank)}
 

@@ -117,7 +117,12 @@ int tramba_tune_get(int knob);
 #define TRAMBA_PROF_SCAN_BWD 4      /* tramba_ss2d_scan_bwd_cl: SURVEY 8(d) backward bytes of the op it replaces, 12 B per (b,k,d,l)
                                        element at 16-bit activations (u, delta, dout read; du, ddelta written), 20 B at fp32 */
 #define TRAMBA_PROF_WGRAD 5         /* tramba_wgrad_cl: 2*M*N*K flop per group and batch */
-#define TRAMBA_PROF_COUNT 6
+#define TRAMBA_PROF_LAYERNORM 6     /* the LayerNorm family (tramba_layernorm_cl, tramba_add_layernorm_cl, tramba_shuffle_norm_cl and the
+                                       tramba_layernorm_bwd_* / tramba_shuffle_norm_bwd_cl launches): bytes of every activation-sized tensor
+                                       the call reads or writes once (x, dy, dx, the residual and its sum ... ), the per-channel rows not counted */
+#define TRAMBA_PROF_DW 7            /* the depth-wise stencils (tramba_dwconv_cl / _dual_cl: x read, y (and y_pre) written;
+                                       tramba_dwconv_wgrad_cl: x and gy read) */
+#define TRAMBA_PROF_COUNT 8
 
 /* ------------------------------------------------------------------ scan-order tables (host) */
 /* Number of directions K of a family. */

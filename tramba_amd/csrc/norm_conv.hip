@@ -1178,6 +1178,7 @@ extern "C" int tramba_layernorm_cl(const void *x, const float *w, const float *b
     TRAMBA_CHECK(x && w && b && y, "layernorm_cl: null tensor");
     TRAMBA_CHECK(rows > 0 && c > 0, "layernorm_cl: empty shape");
     TRAMBA_CHECK(aligned16(x) && aligned16(y), "layernorm_cl: tensors must be 16-byte aligned");
+    ProfScope prof(TRAMBA_PROF_LAYERNORM, (hipStream_t)stream, 2.0 * (double)rows * c * dtype_size(dtype));
     TRAMBA_DISPATCH_DTYPE(dtype, T,
         return launch_layernorm<T>(x, w, b, y, rows, c, eps, act, 1, 1, 1, (hipStream_t)stream));
     return TRAMBA_OK;
@@ -1246,6 +1247,7 @@ extern "C" int tramba_layernorm_bwd_any_cl(const void *x, const void *dy, const 
     const int v = (c % 4 == 0) ? 4 : ((c % 2 == 0) ? 2 : 1);
     TRAMBA_CHECK((c + kWave * v - 1) / (kWave * v) <= kNormMaxIt, "layernorm_bwd_cl: C=%d too large", c);
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(TRAMBA_PROF_LAYERNORM, s, (3.0 + (gres ? 1.0 : 0.0) + (dxm ? 1.0 : 0.0)) * (double)rows * c * dtype_size(dtype));
     const long rpw = ln_bwd_rows_per_wave(rows, ln_bwd_rows_form(c, dtype));
     const long waves = (rows + rpw - 1) / rpw;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
@@ -1457,6 +1459,7 @@ extern "C" int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *part
     const int rpw = dw_wgrad_rpw(h), cs = dw_wgrad_cs(wd), nw = dwg_waves(ks);
     dim3 grid((unsigned)((c / 2 + kWave - 1) / kWave), (unsigned)(((h + nw * rpw - 1) / (nw * rpw)) * cs), (unsigned)batch),
         block(nw * kWave);
+    ProfScope prof(TRAMBA_PROF_DW, s, 2.0 * (double)batch * h * wd * c * dtype_size(dtype));
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
         if (ks == 3) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 3>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw, cs);
         else if (ks == 5) hipLaunchKernelGGL((dwconv_wgrad_cl_kernel<T, 5>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, rpw, cs);
@@ -1665,6 +1668,7 @@ extern "C" int tramba_dwconv_dual_cl(const void *x, const float *wt, const float
     TRAMBA_CHECK(ks == 3 || ks == 5 || ks == 7, "dwconv_cl: kernel size %d unsupported (3,5,7)", ks);
     TRAMBA_CHECK(aligned16(x) && aligned16(y) && aligned16(wt) && aligned16(bt), "dwconv_cl: tensors must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(TRAMBA_PROF_DW, s, (y_pre ? 3.0 : 2.0) * (double)batch * h * wd * c * dtype_size(dtype));
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
         if (ks == 3) return launch_dw<T, 3>(x, wt, bt, y, batch, h, wd, c, act, s, y_pre, flip_taps);
         if (ks == 5) return launch_dw<T, 5>(x, wt, bt, y, batch, h, wd, c, act, s, y_pre, flip_taps);

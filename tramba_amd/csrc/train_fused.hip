@@ -406,6 +406,8 @@ extern "C" int tramba_add_layernorm_cl(const void *x, const void *y, const float
     TRAMBA_CHECK(!mask || rows_per_sample > 0, "add_layernorm_cl: rows_per_sample must be positive with a mask");
     TRAMBA_CHECK(aligned16(x) && aligned16(n) && (!y || (aligned16(y) && aligned16(xsum))) && (!n_act || aligned16(n_act)),
                  "add_layernorm_cl: tensors must be 16-byte aligned");
+    ProfScope prof(TRAMBA_PROF_LAYERNORM, (hipStream_t)stream,
+                   (2.0 + (y ? 2.0 : 0.0) + (n_act ? 1.0 : 0.0)) * (double)rows * c * dtype_size(dtype));
     TRAMBA_DISPATCH_DTYPE(dtype, T, return launch_add_ln<T>(x, y, mask, rows_per_sample > 0 ? rows_per_sample : 1, w, b, xsum,
                                                             n, n_act, rows, c, eps, act, (hipStream_t)stream));
     return TRAMBA_OK;

@@ -20,7 +20,7 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_SIGMOID_GATE, ACT_GELU_GRAD_MUL = 0, 1, 2, 3, 
 SCAN_RASTER, SCAN_LINE, SCAN_HELIX, SCAN_WINDOW, SCAN_DILATION = range(5)
 FAMILY = {"raster": SCAN_RASTER, "line": SCAN_LINE, "helix": SCAN_HELIX, "window": SCAN_WINDOW,
           "dilation": SCAN_DILATION}
-PROF_SCAN_BOUNDARY, PROF_SCAN_FUSED, PROF_GEMM, PROF_MERGE, PROF_SCAN_BWD, PROF_WGRAD = 0, 1, 2, 3, 4, 5
+PROF_SCAN_BOUNDARY, PROF_SCAN_FUSED, PROF_GEMM, PROF_MERGE, PROF_SCAN_BWD, PROF_WGRAD, PROF_LAYERNORM, PROF_DW = 0, 1, 2, 3, 4, 5, 6, 7
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -1232,6 +1232,8 @@ def flush_sums():
     streams |= set(by_stream)
     # sums recorded on ANOTHER stream (the guide branches' backward runs on the side stream of models._forward_overlapped) were
     # launched there: whatever the caller's stream does next -- the optimizer reads these gradients -- must come after them
+    if not streams:     # (nothing was recorded: e.g. a host-tensor model, which has no stream to ask about)
+        return
     cur = _stream()
     others = [st for st in streams if st != cur]
     if others:
