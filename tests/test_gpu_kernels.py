@@ -650,6 +650,85 @@ def test_dwconv_training_path_matches_autograd(dtype, cfg):
                                atol=wtol * float(cr.bias.grad.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("cfg", [(2, 96, 96, 512, 0), (1, 48, 48, 1024, 0), (2, 24, 24, 2048, 0), (1, 13, 50, 130, 0), (3, 7, 5, 6, 0),
+                                 (1, 96, 96, 128, 5), (1, 30, 22, 64, 7), (2, 24, 24, 256, 100), (2, 13, 50, 136, 0), (1, 9, 6, 8, 0)])
+def test_dwconv7_marching_kernel_is_bit_identical_to_the_row_kernel(dtype, cfg):
+    """dwconv7_march_kernel (r04: a lane = 2 channels x 4 columns walking a band of rows, every input row converted once, the 49
+    tap pairs in registers) does the products of dwconv4_cl_kernel<7> in the same order: the plain, the dual-store (training
+    forward) and the flipped-tap (input gradient) launches are BIT-identical to that kernel (TRAMBA_TUNE_DW_FORM 1) at the
+    decoder's three DWMSMlp shapes, on ragged maps (13 x 50 with 136 channels: a channel tile of 8; channel counts that are
+    not a multiple of 8 -- 130, 6 -- stay with the row kernel) and with forced band heights
+    (5, 7, 100 rows: bands that end inside the map, a single band); fp64 on the same inputs holds both."""
+    b, h, w, c, rows = cfg
+    if dtype == torch.float32 and h * w * c > 96 * 96 * 128:
+        pytest.skip("fp32 covered on the small maps")
+    H = hip()
+    g = torch.Generator().manual_seed(h * w + c)
+    x = torch.randn(b, h, w, c, generator=g).to(dtype).to(DEV)
+    wt = (0.15 * torch.randn(49, c, generator=g)).to(DEV)
+    bt = (0.1 * torch.randn(c, generator=g)).to(DEV)
+
+    def run():
+        return [H.dwconv_cl(x, wt, bt, 2), H.dwconv_cl(x, wt, bt, 0), *H.dwconv_dual_cl(x, wt, bt, 2, True, False),
+                H.dwconv_dual_cl(x, wt, bt, 0, False, True)[1], H.dwconv_cl(x, wt, bt, 1)]
+
+    try:
+        H.tune_set(H.TUNE_DW_FORM, 1)
+        old = run()
+        H.tune_set(H.TUNE_DW_FORM, 0)
+        H.tune_set(H.TUNE_DW_ROWS, rows)
+        new = run()
+    finally:
+        H.tune_set(H.TUNE_DW_FORM, 0)
+        H.tune_set(H.TUNE_DW_ROWS, 0)
+    torch.cuda.synchronize()
+    for i, (o, n) in enumerate(zip(old, new)):
+        assert torch.equal(o, n), f"launch {i}: {int((o != n).sum())} of {o.numel()} values differ"
+    xn = x.double().permute(0, 3, 1, 2)
+    k = wt.double().view(7, 7, c).permute(2, 0, 1).unsqueeze(1)
+    want = F.conv2d(xn, k, bt.double(), padding=3, groups=c).permute(0, 2, 3, 1)
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    np.testing.assert_allclose(new[1].cpu().double().numpy(), want.cpu().numpy(), rtol=tol, atol=tol)
+    wantf = F.conv2d(xn, k.flip(2, 3), bt.double(), padding=3, groups=c).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(new[4].cpu().double().numpy(), wantf.cpu().numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("cfg", [(2, 96, 96, 256, 0), (2, 48, 48, 512, 0), (2, 24, 24, 1024, 0), (1, 13, 50, 130, 0), (3, 7, 5, 6, 0),
+                                 (1, 40, 36, 64, 5), (1, 30, 100, 64, 7), (2, 24, 24, 128, 100), (2, 13, 50, 136, 0), (1, 9, 6, 8, 0)])
+def test_dwconv7_marching_weight_gradient(dtype, cfg):
+    """dwconv7_wgrad_march_kernel (r04: an x row converted once meets the seven gy rows it pairs with from a rotating register
+    window) against fp64 on the same inputs and against the tap-row-outer kernel (TRAMBA_TUNE_DW_FORM 1; another summation
+    order: fp32 rounding apart); ragged maps, more column groups than waves (W = 100: 4 column ranges), forced band heights;
+    twice = bitwise run to run (ordered fold, no atomics)."""
+    b, h, w, c, rows = cfg
+    H = hip()
+    g = torch.Generator().manual_seed(h * w + c + 1)
+    x = torch.randn(b, h, w, c, generator=g).to(dtype).to(DEV)
+    gy = torch.randn(b, h, w, c, generator=g).to(dtype).to(DEV)
+    try:
+        H.tune_set(H.TUNE_DW_FORM, 1)
+        gw_old, gb_old = H.dwconv_wgrad_cl(x, gy, 7)
+        H.tune_set(H.TUNE_DW_FORM, 0)
+        H.tune_set(H.TUNE_DW_ROWS, rows)
+        gw, gb = H.dwconv_wgrad_cl(x, gy, 7)
+        gw2, gb2 = H.dwconv_wgrad_cl(x, gy, 7)
+    finally:
+        H.tune_set(H.TUNE_DW_FORM, 0)
+        H.tune_set(H.TUNE_DW_ROWS, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    xp = F.pad(x.double().permute(0, 3, 1, 2), (3, 3, 3, 3))
+    gd = gy.double().permute(0, 3, 1, 2)
+    want = torch.stack([(xp[:, :, dy:dy + h, dx:dx + w] * gd).sum(dim=(0, 2, 3)) for dy in range(7) for dx in range(7)])
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(gw.cpu().double().numpy(), want.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(gb.cpu().double().numpy(), gd.sum(dim=(0, 2, 3)).cpu().numpy(), rtol=1e-4,
+                               atol=2e-5 * float(gd.sum(dim=(0, 2, 3)).abs().max()))
+    np.testing.assert_allclose(gw.cpu().numpy(), gw_old.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+
+
 def test_dwms_training_fold_matches_reference_sum():
     """h + dw3(h) + dw5(h) + dw7(h) as one folded stencil: outputs and all six parameter gradients."""
     from tramba_amd import modules as M

@@ -19,7 +19,7 @@ def test_header_symbols_are_exported_and_bound():
     hdr = open(os.path.join(ROOT, "include", "tramba_hip.h")).read()
     declared = set(re.findall(r"\b(tramba_[a-z0-9_]+)\s*\(", hdr))
     lib = hip.lib()
-    assert lib.tramba_abi_version() == 6
+    assert lib.tramba_abi_version() == 7
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/tramba_hip.h but not exported"
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)

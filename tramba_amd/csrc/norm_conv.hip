@@ -987,6 +987,215 @@ __global__ __launch_bounds__(256) void dwconv4_cl_kernel(const T *__restrict__ x
     }
 }
 
+// ---- 7x7, marching down the rows (r04) ----
+// The one-row-per-thread kernel above issues 2260 vector instructions per wave of which 784 are its FMAs (counters,
+// scripts/dev/pmc_stream.sh): every output row converts its 7 x 14 input pixels again and re-reads the taps.  Here a lane owns
+// TWO channels and 4 output columns and walks a band of TH output rows from top to bottom: each input row is loaded and
+// converted ONCE (10 pixels) and feeds the seven output rows it touches, whose accumulators sit in a rotating window of
+// 7 x 4 register pairs (static indices: the row loop is unrolled by 7); all 49 tap pairs stay in registers.  Per input row:
+// 10 loads, 20 conversions, 196 packed FMAs.  Same products in the same order as the one-row kernel (bias first, then dy, dx
+// ascending): bit-identical results.
+template <typename T> struct DwRaw2 { unsigned v; };
+template <> struct DwRaw2<float> { dw_v2u v; };
+
+template <typename T>
+__device__ __forceinline__ DwRaw2<T> dw_load2_raw(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    DwRaw2<T> o;
+    if constexpr (sizeof(T) == 4) o.v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    else o.v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    return o;
+}
+
+template <typename T>
+__device__ __forceinline__ dw_v2f dw_cvt2(const DwRaw2<T> &raw)
+{
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(dw_v2f, raw.v);
+    } else {
+        const Pack<T, 2> pk = __builtin_bit_cast(Pack<T, 2>, raw.v);
+        return dw_v2f{Cvt<T>::to_f(pk.v[0]), Cvt<T>::to_f(pk.v[1])};
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void dw_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, dw_v2f v)
+{
+    if constexpr (sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(dw_v2u, v), r, voff, soff, 0);
+    } else {
+        Pack<T, 2> pk;
+        pk.v[0] = Cvt<T>::from_f(v.x);
+        pk.v[1] = Cvt<T>::from_f(v.y);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), r, voff, soff, 0);
+    }
+}
+
+constexpr int kDwmTW = 4;    // output columns per lane
+constexpr int kDwmD = 4;     // input rows in flight ahead of the row being consumed (forward; LDS-DMA ring of kDwmD + 1 rows per wave)
+constexpr int kDwgD = 3;     // the same for the weight gradient (x and gy rows: ring of kDwgD + 1)
+typedef __attribute__((address_space(3))) void dw_lds_void;
+struct alignas(16) DwQuad { unsigned v[4]; };      // element type of the LDS rings below
+template <int N> __device__ __forceinline__ void dw_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// DUAL: the pre-activation map leaves too (training forward): 8 instead of 4 stores per finished row, which the counted
+// waits below have to know.  The input rows of a wave travel global -> LDS by LDS-DMA (16 bytes per lane: three instructions move
+// the 10 pixels x 128 channels of a row), kDwmD rows ahead of the row being consumed, into a ring of the wave's own -- no barriers,
+// only s_waitcnt vmcnt(N) with N counted by hand: loads, LDS-DMA and stores retire in issue order, every phase issues exactly 3
+// DMA (rows outside the image through a zero-length descriptor: zeros, no traffic) and, from phase 6 on, exactly 4 (8) stores.
+// (Register-staged with one row in flight the kernel waited for memory once per row: 87 us at batch 8, 96x96, C = 512; with
+// one 4-byte LDS-DMA per pixel 79 us -- an LDS-DMA instruction costs its wave ~100 issue cycles whatever it moves.)
+template <typename T, bool DUAL>
+__global__ __launch_bounds__(256) void dwconv7_march_kernel(const T *__restrict__ x, const float *__restrict__ wt,
+                                                           const float *__restrict__ bt, T *__restrict__ y, int B, int H,
+                                                           int W, int C, int act, T *__restrict__ ypre, int flip, int TH,
+                                                           int nbands, int nct, int ncg)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // (a 16-byte LDS-DMA builtin in a kernel template: the host pass would drop the launch stub, see ss2d_scan_dma_kernel)
+    constexpr int PX = sizeof(T) == 4 ? 2 : 1;      // dwords per lane and pixel
+    constexpr int KS = 7, R = 3, TW = kDwmTW, NI = TW + KS - 1, D = PX == 2 ? 2 : kDwmD, NS = D + 1, S = DUAL ? 2 * TW : TW;
+    // a pixel of the wave's channel tile = 128 channels = PXB bytes; one 16-byte LDS-DMA instruction moves 1 KB = 4 (2) pixels
+    // (lane -> pixel lane / 16 (8), 16-byte piece lane % 16 (8)); a ring slot = the 10 pixels of a row, padded to whole KB
+    constexpr int PXB = 128 * (int)sizeof(T), NDMA = (NI * PXB + 1023) / 1024, SLOTW = NDMA * 256;
+    static_assert((D - 1) * (NDMA + S) <= 63 && D <= 4, "vmcnt is a 6-bit field; the ramp of the store count below covers D <= 4");
+    __shared__ DwQuad ring4[4 * NS * SLOTW / 4];      // (16-byte elements: the LDS-DMA destinations are 16-byte aligned)
+    // work item of a WAVE = (channel tile of 128, column group of 4, image); a band of TH rows of it per workgroup row.
+    // Linear block id -> (XCD, slot): an XCD takes whole items with all their bands (band fastest), so the 6 halo rows two
+    // neighbouring bands share are read through one L2.
+    const unsigned lin = blockIdx.x, nblk = gridDim.x;
+    const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = lin & 7, slot8 = lin >> 3;
+    const unsigned t_ = xcd * q8 + (xcd < r8 ? xcd : r8) + slot8;     // position in the (item block, band) list, band fastest
+    const unsigned band = t_ % (unsigned)nbands, iblk = t_ / (unsigned)nbands;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const unsigned item = iblk * 4u + (unsigned)wave;
+    if (item >= (unsigned)(nct * ncg * B)) return;
+    const int ct = (int)(item % (unsigned)nct);
+    const int cgp = (int)((item / (unsigned)nct) % (unsigned)ncg);
+    const int b = (int)(item / (unsigned)(nct * ncg));
+    const int c0 = (ct * 64 + lane) * 2;
+    const bool cok = c0 + 2 <= C;
+    const int w0 = cgp * TW;
+    const int h0 = (int)band * TH, hend = h0 + TH < H ? h0 + TH : H;
+
+    const unsigned colb = (unsigned)C * (unsigned)sizeof(T), rowb = (unsigned)W * colb;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (long)b * H * W * C, (unsigned)H * rowb);
+    const __amdgpu_buffer_rsrc_t rp = make_rsrc(DUAL ? ypre + (long)b * H * W * C : y, DUAL ? (unsigned)H * rowb : 0u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(wt, (unsigned)(KS * KS) * (unsigned)C * 4u);
+
+    unsigned voff[NI];      // byte offset of (column w0 - R + i, channel c0) inside a row; out of range where it does not exist
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int wx = w0 - R + i;
+        voff[i] = (cok && wx >= 0 && wx < W) ? (unsigned)(wx * C + c0) * (unsigned)sizeof(T) : kOutOfRange;
+    }
+    unsigned *const myring = reinterpret_cast<unsigned *>(ring4) + wave * (NS * SLOTW);
+    unsigned vd[NDMA];      // my 16-byte piece of LDS-DMA instruction k: byte offset inside an image row, or out of range
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) {
+        const int e = k * 1024 + lane * 16, i = e / PXB, ch = ct * 128 + (e % PXB) / (int)sizeof(T), wx = w0 - R + i;
+        vd[k] = (i < NI && wx >= 0 && wx < W && ch + 16 / (int)sizeof(T) <= C) ? (unsigned)(wx * C + ch) * (unsigned)sizeof(T)
+                                                                               : kOutOfRange;
+    }
+    auto issue = [&](int r, int sl) {      // row r of the image -> ring slot sl (always NDMA LDS-DMA instructions)
+        const bool ok = r >= 0 && r < H;      // (a row outside the image: a zero-length descriptor, every lane out of range -> zeros)
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(x + (long)b * H * W * C, ok ? (unsigned)H * rowb : 0u);
+        const unsigned so = ok ? (unsigned)r * rowb : 0u;
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (dw_lds_void *)(myring + sl * SLOTW + k * 256), 16, vd[k], so, 0, 0);
+    };
+    dw_v2f wv[KS * KS];
+    {
+        const unsigned wo = cok ? (unsigned)c0 * 4u : kOutOfRange;
+#pragma unroll
+        for (int i = 0; i < KS * KS; ++i)
+            wv[i] = __builtin_bit_cast(dw_v2f, __builtin_amdgcn_raw_buffer_load_b64(
+                                                   rw, wo, (unsigned)(flip ? KS * KS - 1 - i : i) * (unsigned)C * 4u, 0));
+    }
+    dw_v2f bias = {0.f, 0.f};
+    if (cok) bias = dw_v2f{bt[c0], bt[c0 + 1]};
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(h0 - R + d, d);
+    dw_v2f acc[KS][TW];
+#pragma unroll
+    for (int sl = 0; sl < KS; ++sl)
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[sl][t] = bias;
+
+    // phase q: input row r = h0 - R + q feeds output rows r + R - dy (dy = 0 .. 6), whose window slot is (q + 6 - dy) % 7;
+    // after it output row r - R is complete (slot q % 7) and the slot starts over for row r + R + 1
+    const int nq = (hend - h0) + KS - 1;
+    int srd = 0, swr = D;      // ring slots: the row consumed now, the row issued now
+    for (int qb = 0; qb < nq; qb += KS) {
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const int q = qb + u;
+            if (q < nq) {
+                const int r = h0 - R + q;
+                // newer than row q's DMA: the DMA of rows q + 1 .. q + D - 1 and the stores of phases q - D + 1 .. q - 1 (a phase
+                // stores from q = 6 on)
+                if (qb == 0) dw_vm_wait<(D - 1) * NDMA>();
+                else if (qb == KS && u == 0) dw_vm_wait<(D - 1) * NDMA + (D - 1 < 1 ? D - 1 : 1) * S>();
+                else if (qb == KS && u == 1) dw_vm_wait<(D - 1) * NDMA + (D - 1 < 2 ? D - 1 : 2) * S>();
+                else if (qb == KS && u == 2) dw_vm_wait<(D - 1) * NDMA + (D - 1 < 3 ? D - 1 : 3) * S>();
+                else dw_vm_wait<(D - 1) * (NDMA + S)>();
+                if (r >= 0 && r < H) {
+                    dw_v2f xin[NI];
+                    const unsigned *src = myring + srd * SLOTW + lane * PX;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        DwRaw2<T> raw;
+                        if constexpr (sizeof(T) == 4) raw.v = *reinterpret_cast<const dw_v2u *>(src + i * 2 * kWave);
+                        else raw.v = src[i * kWave];
+                        xin[i] = dw_cvt2<T>(raw);
+                    }
+#pragma unroll
+                    for (int dy = 0; dy < KS; ++dy) {
+                        const int o = r + R - dy;
+                        if (o >= h0 && o < hend) {
+                            const int sl = (u + 6 - dy) % KS;
+#pragma unroll
+                            for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                                for (int t = 0; t < TW; ++t) acc[sl][t] = xin[t + dx] * wv[dy * KS + dx] + acc[sl][t];
+                        }
+                    }
+                }
+                if (q >= KS - 1) {      // output row r - R = h0 + q - 6 is complete
+                    const unsigned so = (unsigned)(r - R) * rowb;
+                    dw_v2f p[TW];
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) {
+                        p[t] = acc[u % KS][t];
+                        acc[u % KS][t] = bias;
+                    }
+                    if constexpr (DUAL) {   // training: the pre-activation leaves too, the activation is taken of it AS STORED
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) {
+                            dw_store2<T>(rp, voff[t + R], so, p[t]);
+                            p[t] = dw_v2f{Cvt<T>::to_f(Cvt<T>::from_f(p[t].x)), Cvt<T>::to_f(Cvt<T>::from_f(p[t].y))};
+                        }
+                    }
+                    if (act == TRAMBA_ACT_GELU) {
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) p[t] = dw_v2f{geluf_(p[t].x), geluf_(p[t].y)};
+                    } else if (act == TRAMBA_ACT_SILU) {
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) p[t] = dw_v2f{siluf_(p[t].x), siluf_(p[t].y)};
+                    }
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) dw_store2<T>(ry, voff[t + R], so, p[t]);
+                }
+                issue(q + D < nq ? r + D : -1, swr);
+                srd = srd + 1 == NS ? 0 : srd + 1;
+                swr = swr + 1 == NS ? 0 : swr + 1;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA of this wave may land after its workgroup's LDS is handed on
+#endif
+}
+
 // Weight / bias gradient of the depth-wise stencil (training): gw[tap][c] += sum over pixels of
 // gy[b,h,w,c] * x[b,h+dy-R,w+dx-R,c], gb[c] += sum gy.  Lanes = channel pairs, a wave owns RPW image rows
 // of one 128-channel tile and walks them 4 columns at a time (the forward kernel's register reuse with the
@@ -1138,6 +1347,153 @@ __global__ __launch_bounds__(dwg_waves(KS) * kWave) void dwconv_wgrad_cl_kernel(
     }
 }
 
+// Weight / bias gradient of the 7x7 stencil, marching (r04).  The tap-row-outer kernel above re-reads and re-converts gy and the
+// x window once per tap row: 28 packed FMAs per 14 loads + 28 conversions + their offsets (counters: 7664 vector and 9137 scalar
+// instructions per wave, vector ALU busy 21 % of the wave's cycles).  Here a lane owns two channels and 4 columns and walks a
+// band of rows: an x row is loaded and converted once and meets the SEVEN gy rows it pairs with (tap row dy <-> gy row r + 3 - dy),
+// which wait converted in a rotating window of 7 x 4 register pairs; the 49 tap sums are register pairs.  Per x row: 14 loads,
+// 28 conversions, 196 packed FMAs.  Waves of a workgroup = the column groups of one column range; ordered fold through LDS as
+// above, one partial row per (image, band, column range).
+template <typename T>
+__global__ __launch_bounds__(512) void dwconv7_wgrad_march_kernel(const T *__restrict__ x, const T *__restrict__ gy,
+                                                                 float *__restrict__ part, int H, int W, int C, int TH,
+                                                                 int nbands, int NW, int ncg)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // (as in dwconv7_march_kernel)
+    constexpr int PX = sizeof(T) == 4 ? 2 : 1;      // dwords per lane and pixel
+    constexpr int KS = 7, R = 3, TW = kDwmTW, NI = TW + KS - 1, D = PX == 2 ? 1 : kDwgD, NS = D + 1;
+    constexpr int PXB = 128 * (int)sizeof(T), NDX = (NI * PXB + 1023) / 1024, NDG = (TW * PXB + 1023) / 1024, SLOTW = (NDX + NDG) * 256;
+    static_assert((D - 1) * (NDX + NDG) <= 63, "vmcnt is a 6-bit field");
+    // per wave a ring of NS rows (10 x pixels, then 4 gy pixels, each padded to whole KB) filled by 16-byte LDS-DMA, D rows ahead of
+    // the row being consumed (see dwconv7_march_kernel; no stores inside the loop: the counted wait is (D - 1) * 4 in every phase);
+    // the fold table of the epilogue lies over the rings
+    __shared__ DwQuad smem4[8 * NS * SLOTW / 4];      // (16-byte elements: the LDS-DMA destinations are 16-byte aligned)
+    static_assert(sizeof(smem4) >= (KS * KS + 1) * 2 * kWave * sizeof(float), "the fold table fits the rings");
+    unsigned *const smem = reinterpret_cast<unsigned *>(smem4);
+    float (*red)[2 * kWave] = reinterpret_cast<float (*)[2 * kWave]>(smem4);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int band = blockIdx.y % nbands, cs = blockIdx.y / nbands;
+    const int cgp = cs * NW + wv;
+    const bool active = cgp < ncg;
+    const int w0 = cgp * TW;
+    const int h0 = band * TH, hend = h0 + TH < H ? h0 + TH : H;
+    const int b = blockIdx.z;
+    const unsigned colb = (unsigned)C * (unsigned)sizeof(T), rowb = (unsigned)W * colb;
+
+    dw_v2f acc[KS][KS], accb = {0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) acc[dy][dx] = dw_v2f{0.f, 0.f};
+
+    if (active) {
+        unsigned *const myring = smem + wv * (NS * SLOTW);
+        unsigned vdx[NDX], vdg[NDG];      // my 16-byte piece of each LDS-DMA instruction: byte offset inside an image row, or out of range
+#pragma unroll
+        for (int k = 0; k < NDX; ++k) {
+            const int e = k * 1024 + lane * 16, i = e / PXB, ch = (int)blockIdx.x * 128 + (e % PXB) / (int)sizeof(T), wx = w0 - R + i;
+            vdx[k] = (i < NI && wx >= 0 && wx < W && ch + 16 / (int)sizeof(T) <= C) ? (unsigned)(wx * C + ch) * (unsigned)sizeof(T)
+                                                                                    : kOutOfRange;
+        }
+#pragma unroll
+        for (int k = 0; k < NDG; ++k) {
+            const int e = k * 1024 + lane * 16, i = e / PXB, ch = (int)blockIdx.x * 128 + (e % PXB) / (int)sizeof(T), wx = w0 + i;
+            vdg[k] = (i < TW && wx < W && ch + 16 / (int)sizeof(T) <= C) ? (unsigned)(wx * C + ch) * (unsigned)sizeof(T) : kOutOfRange;
+        }
+        // phase q: x row r = h0 - R + q; the gy row that joins the window is h0 + q (slot (q + 6) % 7); tap row dy pairs the x row
+        // with gy row r + R - dy (slot (q + 6 - dy) % 7)
+        auto issue = [&](int q, int sl) {      // the rows of phase q -> ring slot sl (always NL * PX LDS-DMA instructions)
+            const int r = h0 - R + q, gr = h0 + q;
+            const bool xok = r >= 0 && r < H, gok = gr >= h0 && gr < hend;     // (outside: a zero-length descriptor -> zeros)
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (long)b * H * W * C, xok ? (unsigned)H * rowb : 0u);
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(gy + (long)b * H * W * C, gok ? (unsigned)H * rowb : 0u);
+            const unsigned sx = xok ? (unsigned)r * rowb : 0u, sg = gok ? (unsigned)gr * rowb : 0u;
+#pragma unroll
+            for (int k = 0; k < NDX; ++k)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (dw_lds_void *)(myring + sl * SLOTW + k * 256), 16, vdx[k], sx, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NDG; ++k)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (dw_lds_void *)(myring + sl * SLOTW + (NDX + k) * 256), 16, vdg[k], sg, 0, 0);
+        };
+        auto fetch = [&](const unsigned *src, int i) {      // my channel pair of pixel i of a region
+            DwRaw2<T> raw;
+            if constexpr (sizeof(T) == 4) raw.v = *reinterpret_cast<const dw_v2u *>(src + i * 2 * kWave);
+            else raw.v = src[i * kWave];
+            return dw_cvt2<T>(raw);
+        };
+        dw_v2f gwin[KS][TW];
+        const int nq = (hend - h0) + KS - 1;
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(d, d);
+        int srd = 0, swr = D;
+        for (int qb = 0; qb < nq; qb += KS) {
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                const int q = qb + u;
+                if (q < nq) {
+                    const int r = h0 - R + q;
+                    dw_vm_wait<(D - 1) * (NDX + NDG)>();
+                    const unsigned *src = myring + srd * SLOTW + lane * PX;
+                    if (h0 + q < hend) {
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) {
+                            gwin[(u + 6) % KS][t] = fetch(src + NDX * 256, t);
+                            accb = accb + gwin[(u + 6) % KS][t];
+                        }
+                    }
+                    if (r >= 0 && r < H) {
+                        dw_v2f xin[NI];
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) xin[i] = fetch(src, i);
+#pragma unroll
+                        for (int dy = 0; dy < KS; ++dy) {
+                            const int o = r + R - dy;
+                            if (o >= h0 && o < hend) {
+                                const int sl = (u + 6 - dy) % KS;
+#pragma unroll
+                                for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                                    for (int t = 0; t < TW; ++t) acc[dy][dx] = gwin[sl][t] * xin[t + dx] + acc[dy][dx];
+                            }
+                        }
+                    }
+                    issue(q + D < nq ? q + D : -1000000, swr);
+                    srd = srd + 1 == NS ? 0 : srd + 1;
+                    swr = swr + 1 == NS ? 0 : swr + 1;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every LDS-DMA of this wave has landed before the rings are reused
+    }
+    __syncthreads();
+    // ordered fold of the waves: wave 0 stores, the others add in turn (idle waves add zeros)
+    for (int q = 0; q < NW; ++q) {
+        if (wv == q) {
+#pragma unroll
+            for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx) {
+                    float2 *r = reinterpret_cast<float2 *>(&red[dy * KS + dx][2 * lane]);
+                    const float2 o = q == 0 ? make_float2(0.f, 0.f) : *r;
+                    *r = make_float2(o.x + acc[dy][dx].x, o.y + acc[dy][dx].y);
+                }
+            float2 *r = reinterpret_cast<float2 *>(&red[KS * KS][2 * lane]);
+            const float2 o = q == 0 ? make_float2(0.f, 0.f) : *r;
+            *r = make_float2(o.x + accb.x, o.y + accb.y);
+        }
+        __syncthreads();
+    }
+    // slot = (image, column range, band)
+    float *p = part + ((long)b * gridDim.y + blockIdx.y) * (long)(KS * KS + 1) * C + (long)blockIdx.x * 2 * kWave;
+    const int cleft = C - blockIdx.x * 2 * kWave;      // channels of this tile that exist
+    for (int i = threadIdx.x; i < (KS * KS + 1) * 2 * kWave; i += NW * kWave) {
+        const int t = i / (2 * kWave), c = i % (2 * kWave);
+        if (c < cleft) p[(long)t * C + c] = red[t][c];
+    }
+#endif
+}
+
 template <typename T, int KS>
 static int launch_dw(const void *x, const float *wt, const float *bt, void *y, int B, int H, int W, int C, int act,
                      hipStream_t s, void *ypre = nullptr, int flip = 0)
@@ -1164,6 +1520,43 @@ static int launch_dw(const void *x, const float *wt, const float *bt, void *y, i
     else if (v == 2) GO_(2);
     else GO_(1);
 #undef GO_
+    TRAMBA_LAUNCH_CHECK();
+    return TRAMBA_OK;
+}
+
+// rows per band of the marching 7x7 kernels: the workgroups of a launch should come in whole rounds of the 256 CUs, and a
+// band pays for its 6 halo rows (loads + conversions, ~50 of the ~250 vector instructions of a full row)
+static int dw7_band_rows(long items4, int H)
+{
+    const int cand[] = {6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192};
+    int best = H;
+    double best_cost = 1e30;
+    for (int th : cand) {
+        if (th > H && th != cand[0]) continue;
+        const int t = th > H ? H : th;
+        const long nwg = items4 * ((H + t - 1) / t);
+        const double cost = (double)((nwg + 255) / 256) * (t * 196.0 + (t + 6) * 50.0 + 150.0);
+        if (cost < best_cost) { best_cost = cost; best = t; }
+    }
+    return best;
+}
+
+template <typename T>
+static int launch_dw7_march(const void *x, const float *wt, const float *bt, void *y, int B, int H, int W, int C, int act,
+                            hipStream_t s, void *ypre, int flip)
+{
+    const int nct = (C / 2 + 63) / 64, ncg = (W + kDwmTW - 1) / kDwmTW;
+    const long items4 = ((long)nct * ncg * B + 3) / 4;
+    int th = dw7_band_rows(items4, H);
+    const int forced = tramba_tune_get(TRAMBA_TUNE_DW_ROWS);
+    if (forced > 0) th = forced > H ? H : forced;
+    const int nbands = (H + th - 1) / th;
+    if (ypre)
+        hipLaunchKernelGGL((dwconv7_march_kernel<T, true>), dim3((unsigned)(items4 * nbands)), dim3(256), 0, s, (const T *)x, wt, bt,
+                           (T *)y, B, H, W, C, act, (T *)ypre, flip, th, nbands, nct, ncg);
+    else
+        hipLaunchKernelGGL((dwconv7_march_kernel<T, false>), dim3((unsigned)(items4 * nbands)), dim3(256), 0, s, (const T *)x, wt, bt,
+                           (T *)y, B, H, W, C, act, (T *)ypre, flip, th, nbands, nct, ncg);
     TRAMBA_LAUNCH_CHECK();
     return TRAMBA_OK;
 }
@@ -1440,9 +1833,30 @@ extern "C" int tramba_dw_pack_multi(const float *const *w, const float *const *b
 static int dw_wgrad_rpw(int h) { return h > 96 ? 2 : 1; }
 static int dw_wgrad_cs(int wd) { return wd >= 48 ? 2 : 1; }
 
-extern "C" int64_t tramba_dwconv_wgrad_parts(int batch, int h, int wd, int ks)
+// the marching 7x7 weight gradient: rows per band, column ranges and waves (= column groups) per workgroup
+static bool dw7_wgrad_march(int ks, int c) { return ks == 7 && c % 8 == 0 && tramba_tune_get(TRAMBA_TUNE_DW_FORM) != 1; }
+static int dw7_wgrad_rows(int h)
 {
-    if (batch <= 0 || h <= 0 || wd <= 0 || ks <= 0) return 0;
+    const int forced = tramba_tune_get(TRAMBA_TUNE_DW_ROWS);
+    const int th = forced > 0 ? forced : (h >= 48 ? 24 : 12);      // (measured at batch 8: 96x96 81 -> 78 us, 48x48 52 -> 41, 24x24 28 (12 rows) / 38 (24))
+    return th > h ? h : th;
+}
+static void dw7_wgrad_cols(int wd, int &cs, int &nw, int &ncg)
+{
+    ncg = (wd + kDwmTW - 1) / kDwmTW;
+    cs = (ncg + 7) / 8;
+    nw = (ncg + cs - 1) / cs;
+}
+
+extern "C" int64_t tramba_dwconv_wgrad_parts(int batch, int h, int wd, int c, int ks)
+{
+    if (batch <= 0 || h <= 0 || wd <= 0 || c <= 0 || ks <= 0) return 0;
+    if (dw7_wgrad_march(ks, c)) {
+        int cs, nw, ncg;
+        dw7_wgrad_cols(wd, cs, nw, ncg);
+        const int th = dw7_wgrad_rows(h);
+        return (int64_t)batch * ((h + th - 1) / th) * cs;
+    }
     const int rpw = dw_wgrad_rpw(h), nw = dwg_waves(ks);
     return (int64_t)batch * ((h + nw * rpw - 1) / (nw * rpw)) * dw_wgrad_cs(wd);
 }
@@ -1456,6 +1870,18 @@ extern "C" int tramba_dwconv_wgrad_cl(const void *x, const void *gy, float *part
     TRAMBA_CHECK(c % 2 == 0, "dwconv_wgrad_cl: C=%d must be even", c);
     TRAMBA_CHECK(batch <= 65535 && (double)h * wd * c * 4.0 < 2147483648.0, "dwconv_wgrad_cl: shape exceeds this build's limits");
     hipStream_t s = (hipStream_t)stream;
+    if (dw7_wgrad_march(ks, c)) {
+        int cs7, nw7, ncg;
+        dw7_wgrad_cols(wd, cs7, nw7, ncg);
+        const int th = dw7_wgrad_rows(h), nbands = (h + th - 1) / th;
+        ProfScope prof(TRAMBA_PROF_DW, s, 2.0 * (double)batch * h * wd * c * dtype_size(dtype));
+        dim3 grid((unsigned)((c / 2 + kWave - 1) / kWave), (unsigned)(nbands * cs7), (unsigned)batch), block(nw7 * kWave);
+        TRAMBA_DISPATCH_DTYPE(dtype, T,
+            hipLaunchKernelGGL((dwconv7_wgrad_march_kernel<T>), grid, block, 0, s, (const T *)x, (const T *)gy, part, h, wd, c, th,
+                               nbands, nw7, ncg));
+        TRAMBA_LAUNCH_CHECK();
+        return TRAMBA_OK;
+    }
     const int rpw = dw_wgrad_rpw(h), cs = dw_wgrad_cs(wd), nw = dwg_waves(ks);
     dim3 grid((unsigned)((c / 2 + kWave - 1) / kWave), (unsigned)(((h + nw * rpw - 1) / (nw * rpw)) * cs), (unsigned)batch),
         block(nw * kWave);
@@ -1669,7 +2095,11 @@ extern "C" int tramba_dwconv_dual_cl(const void *x, const float *wt, const float
     TRAMBA_CHECK(aligned16(x) && aligned16(y) && aligned16(wt) && aligned16(bt), "dwconv_cl: tensors must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(TRAMBA_PROF_DW, s, (y_pre ? 3.0 : 2.0) * (double)batch * h * wd * c * dtype_size(dtype));
+    // 7x7: the marching kernel (a lane = 2 channels x 4 columns walking a band of rows) wherever its 32-bit offsets reach
+    const bool march = ks == 7 && c % 8 == 0 && tramba_tune_get(TRAMBA_TUNE_DW_FORM) != 1 &&
+                       (double)h * wd * c * 4.0 < 2147483648.0 && (double)batch * wd * c < 2147483648.0;
     TRAMBA_DISPATCH_DTYPE(dtype, T, {
+        if (march) return launch_dw7_march<T>(x, wt, bt, y, batch, h, wd, c, act, s, y_pre, flip_taps);
         if (ks == 3) return launch_dw<T, 3>(x, wt, bt, y, batch, h, wd, c, act, s, y_pre, flip_taps);
         if (ks == 5) return launch_dw<T, 5>(x, wt, bt, y, batch, h, wd, c, act, s, y_pre, flip_taps);
         return launch_dw<T, 7>(x, wt, bt, y, batch, h, wd, c, act, s, y_pre, flip_taps);

@@ -113,7 +113,7 @@ extern "C" int tramba_device_error(void)
 // 5: the step's ends and batched launches (sod_loss_*, adam_step, multi_sum / multi_sum_strided, wgrad_parts_cl,
 //    dw_pack_multi / dw_unpack_grad_multi, shuffle_norm_head_bwd_cl)
 // 6: tramba_device_error, TRAMBA_TUNE_MAILBOX_SKIP (r04)
-extern "C" int tramba_abi_version(void) { return 6; }
+extern "C" int tramba_abi_version(void) { return 7; }
 
 static int g_tune[TRAMBA_TUNE_COUNT] = {0};
 extern "C" int tramba_tune_set(int knob, int value)

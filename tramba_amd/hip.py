@@ -78,7 +78,7 @@ SIGNATURES = {
     "tramba_im2col3x3_cl": (c_int, [c_vp] * 2 + [c_int] * 8 + [c_vp]),
     "tramba_upsample_bilinear_bwd": (c_int, [c_vp] * 2 + [c_int] * 5 + [c_vp]),
     "tramba_col2im3x3_cl": (c_int, [c_vp] * 2 + [c_int] * 8 + [c_vp]),
-    "tramba_dwconv_wgrad_parts": (c_i64, [c_int, c_int, c_int, c_int]),
+    "tramba_dwconv_wgrad_parts": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     "tramba_dwconv_wgrad_cl": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp]),
     "tramba_dct_split_cl": (c_int, [c_vp] * 6 + [c_int] * 4 + [c_vp]),
     "tramba_linear_cl": (c_int, [c_vp] * 5 + [c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
@@ -245,7 +245,7 @@ def scan_order(family: str, h: int, w: int, device, param: int = 0) -> ScanOrder
 
 
 # ----------------------------------------------------------------------------- profiling / tuning
-TUNE_MERGE_FORM, TUNE_SCAN_FORM, TUNE_SCAN_W, TUNE_GEMM_TILE, TUNE_MAILBOX_SKIP, TUNE_WGRAD_FORM = 0, 1, 2, 3, 4, 5
+TUNE_MERGE_FORM, TUNE_SCAN_FORM, TUNE_SCAN_W, TUNE_GEMM_TILE, TUNE_MAILBOX_SKIP, TUNE_WGRAD_FORM, TUNE_DW_FORM, TUNE_DW_ROWS = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def device_error():
@@ -928,7 +928,7 @@ def dwconv_wgrad_cl(x, gy, ks):
     bb, h, wd, c = x.shape
     if gy.shape != x.shape or gy.dtype != x.dtype:
         raise TrambaHipError("dwconv_wgrad_cl: x / gy mismatch")
-    part = torch.empty((lib().tramba_dwconv_wgrad_parts(bb, h, wd, ks), ks * ks + 1, c), dtype=torch.float32, device=x.device)
+    part = torch.empty((lib().tramba_dwconv_wgrad_parts(bb, h, wd, c, ks), ks * ks + 1, c), dtype=torch.float32, device=x.device)
     _check(lib().tramba_dwconv_wgrad_cl(_ptr(x), _ptr(gy), _ptr(part), bb, h, wd, c, ks, dt(x), _stream()),
            "dwconv_wgrad_cl")
     s = slab_sum(part)
@@ -942,7 +942,7 @@ def dwconv_wgrad_table(x, gy, ks, defer=False):
     bb, h, wd, c = x.shape
     if gy.shape != x.shape or gy.dtype != x.dtype:
         raise TrambaHipError("dwconv_wgrad_cl: x / gy mismatch")
-    part = torch.empty((lib().tramba_dwconv_wgrad_parts(bb, h, wd, ks), ks * ks + 1, c), dtype=torch.float32, device=x.device)
+    part = torch.empty((lib().tramba_dwconv_wgrad_parts(bb, h, wd, c, ks), ks * ks + 1, c), dtype=torch.float32, device=x.device)
     _check(lib().tramba_dwconv_wgrad_cl(_ptr(x), _ptr(gy), _ptr(part), bb, h, wd, c, ks, dt(x), _stream()),
            "dwconv_wgrad_cl")
     return slab_sum(part, defer=defer)
