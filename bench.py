@@ -614,15 +614,15 @@ def bench_train(args, world, rank, dtype, sync_all, publish=None):
                "formula": "bytes of every activation-sized tensor a call reads or writes once (forward: x, y; residual form: + the "
                           "branch and the sum; backward: x, dy, dx (+ the skip gradient and the masked copy)) / HIP-event time "
                           "around the call, two eager steps"}
-    roof_dw = {"bound": "hbm", "kernel": "dwconv4_cl_kernel (forward and input gradient) + dwconv_wgrad_cl_kernel, every launch of a step",
+    roof_dw = {"bound": "hbm", "kernel": "dwconv4_cl_kernel (3x3) / dwconv7_march_kernel (7x7): forward and input gradient; dwconv_wgrad_cl_kernel / dwconv7_wgrad_march_kernel: weight gradient; every launch of a step",
                "achieved": round(gdw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gdw / HBM_PEAK_GBS, 4),
                "traffic": tr_dw, "traffic_source": src_dw, "traffic_unit": "bytes per step, all launches of the family",
                "algorithmic_bytes_per_step": int(bytes_dw / 2), "launches": ndw // 2,
                "avg_us": round(msdw / max(ndw, 1) * 1e3, 2), "ms_per_step": round(msdw / 2, 3),
                "formula": "x read + y written (+ the pre-activation copy) per stencil launch, x + gy read per weight-gradient launch / "
                           "HIP-event time around the call, two eager steps",
-               "note": "the 7x7 launches are bound by their 49 FMAs per output through the vector ALUs and the L1 re-reads of the "
-                       "taps' rows (DESIGN section 4), not by HBM"}
+               "note": "the 7x7 launches are bound by the vector ALUs (49 FMAs per output plus the exact GELU of the forward: counters in "
+                       "profiles/r04_dw7_counters.txt), not by HBM"}
     gsb = bytes_sb / (mssb * 1e-3) / 1e9 if mssb > 0 else 0.0
     roof_sb = {"bound": "valu", "kernel": "ss2d_scan_bwd_cl_kernel, all 33 launches of a step", "achieved": round(gsb, 1),
                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gsb / HBM_PEAK_GBS, 4), "traffic": tr_sb,
