@@ -15,7 +15,8 @@ region.  `value` = images/s of that forward, whole job.
 
 Rank 0 prints ONE JSON line.  Objects on that line besides the contract's fields:
   std_ms        standard deviation of the per-step device time (HIP events between the steps of the timed region)
-  latency_b1    the reference's own latency protocol (Trambav6.py:219-255): batch 1, 50 warm-up + 500 timed forwards,
+  latency_b1    the reference's own latency protocol (Trambav6.py:219-255): batch 1, 50 warm-up + 500 timed forwards
+                (`wall_clock`: its other protocol, test_TSOD.py:71-108 -- 5 + 195 synchronised forwards on the host's clock),
                 one HIP-event pair per forward, mean / std / FPS
   roofline      the Helix-SS2D core at the decoder's top stage (img/4 squared positions: 96x96 at 384, 192x192 at 768; K = 8,
                 D = 256; 2 per forward) as a PAIR of launches, fused scan + merge/out_norm: `achieved` / `peak` / `frac` =
@@ -427,11 +428,23 @@ def latency_b1(model, img, graph_ok):
             run()
             b.record()
         torch.cuda.synchronize()
+        # the reference's other protocol (test_TSOD.py:71-108, measure_inference_speed): 200 forwards, each between two
+        # synchronisations on the host's clock, the first 5 not counted
+        pure = 0.0
+        for i in range(200):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            if i >= 5:
+                pure += time.perf_counter() - t0
     ts = torch.tensor([a.elapsed_time(b) for a, b in evs], dtype=torch.float64)
     mean, std = float(ts.mean()), float(ts.std(unbiased=False))
     return {"mean_ms": round(mean, 4), "std_ms": round(std, 4), "fps": round(1000.0 / mean, 2), "batch": 1,
             "warmup": 50, "reps": reps, "launch": "hipGraph replay" if gf is not None else "eager",
-            "protocol": "Trambav6.py:219-255 (one event pair per forward)"}
+            "protocol": "Trambav6.py:219-255 (one event pair per forward)",
+            "wall_clock": {"fps": round(195.0 / pure, 2), "ms_per_image": round(pure / 195.0 * 1e3, 4), "warmup": 5, "iters": 200,
+                           "protocol": "test_TSOD.py:71-108 (host clock around each synchronised forward)"}}
 
 
 def graphed_train_leg(model, red, x, y, world, b, steps, timed):
