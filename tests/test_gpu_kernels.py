@@ -1304,3 +1304,25 @@ def test_layernorm_folded_into_the_gemm(m, n, k, act, res, dtype):
     e_fused, e_two = float((got - want).abs().max()), float((two - want).abs().max())
     assert e_fused <= tol, (e_fused, e_two, scale)
     assert e_fused <= 2.0 * e_two + 1e-3 * scale, (e_fused, e_two)          # no worse than the path it replaces
+
+
+def test_refreshing_the_depthwise_packs_invalidates_a_forward_that_saved_them():
+    """refresh_dw_packs rewrites the standing packs through raw pointers after an optimizer step; a backward whose forward saved
+    a pack BEFORE the refresh must raise autograd's in-place error instead of silently using the new weights' stencil
+    (forward - forward - step - backward, a second loss on an earlier graph)"""
+    import tramba_amd as ta
+    from tramba_amd import modules as M, train
+    torch.manual_seed(7)
+    m = ta.bulid_model(use_pretrain=False, img_size=384).to(DEV).train()
+    m.compute_dtype = torch.bfloat16
+    opt = train.get_opt(1e-4, m)
+    x = torch.randn(1, 3, 384, 384, device=DEV)
+    y = (torch.rand(1, 1, 384, 384, device=DEV) > 0.7).float()
+    train.train_step(m, opt, x, y)             # (the standing packs exist from the first step's refresh on)
+    outs = m(x)
+    assert M.refresh_dw_packs(m) > 0           # as after an optimizer step
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        train.tramba_loss(outs, y).backward()
+    opt.zero_grad(set_to_none=True)
+    loss = train.train_step(m, opt, x, y)      # the normal order is untouched
+    assert bool(torch.isfinite(loss))

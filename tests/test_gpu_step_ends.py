@@ -242,3 +242,38 @@ def test_get_opt_builds_the_library_optimizer_with_the_reference_groups():
     enc = {id(p) for n, p in names.items() if "encoder" in n}
     assert {id(p) for p in opt.param_groups[0]["params"]} == enc
     assert np.isclose(sum(p.numel() for g in opt.param_groups for p in g["params"]), sum(p.numel() for p in m.parameters()))
+
+
+def test_adam_follows_state_entries_replaced_behind_its_back():
+    """the cached pointer arrays are only valid for the state tensors they were built from: after `opt.state.clear()` or a
+    hand-made replacement of `exp_avg` the next step must update (and report in state_dict) the NEW tensors, not the orphans"""
+    from tramba_amd import train
+    g = torch.Generator().manual_seed(5)
+    p = torch.nn.Parameter(torch.randn(1000, generator=g).to(DEV))
+    opt = train.Adam([p], 1e-2)
+    p.grad = torch.randn(1000, generator=g).to(DEV)
+    opt.step()
+    old_avg = opt.state[p]["exp_avg"]
+    opt.state[p]["exp_avg"] = torch.zeros_like(p)          # replaced: the plan's pointer is stale now
+    opt.step()
+    new_avg = opt.state[p]["exp_avg"]
+    assert new_avg is not old_avg and float(new_avg.abs().max()) > 0
+    assert torch.allclose(new_avg, 0.1 * p.grad)           # (1 - beta1) * g on a zero average
+    opt.state.clear()
+    opt.step()
+    assert float(opt.state[p]["step"]) == 1 and torch.allclose(opt.state[p]["exp_avg"], 0.1 * p.grad)
+
+
+def test_loss_weight_count_and_wide_labels():
+    """a weight list that does not match the outputs raises (the fallback would have, the kernel would have zero-filled); a label
+    wider than the gradient kernel's LDS rows (4096) with a resized output takes the framework path instead of failing in backward"""
+    from tramba_amd import train
+    lab = (torch.rand(1, 1, 8, 8, device=DEV) > 0.5).float()
+    outs = [torch.randn(1, 1, 4, 4, device=DEV), torch.randn(1, 1, 8, 8, device=DEV)]
+    with pytest.raises(ValueError):
+        train.tramba_loss(outs, lab, [1.0])
+    wide = (torch.rand(1, 1, 2, 4100, device=DEV) > 0.5).float()
+    small = torch.randn(1, 1, 1, 2050, device=DEV, requires_grad=True)
+    assert not train._loss_on_device([small], wide)
+    train.tramba_loss([small], wide).backward()
+    assert small.grad is not None and bool(torch.isfinite(small.grad).all())

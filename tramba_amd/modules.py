@@ -1340,6 +1340,15 @@ def refresh_dw_packs(model):
         plan = (sig, hip.dw_pack_multi_prepare(items), srcs)
         _dw_plans[model] = plan
     hip.dw_pack_multi_run(plan[1])
+    # the kernel rewrote the standing packs through raw pointers: bump their version counters as an in-place torch op would, so
+    # that a backward whose forward saved a pack BEFORE this refresh raises instead of using the new weights' stencil
+    packs = []
+    for g in srcs:
+        ent = _dw_pack_store.get(g[0].data_ptr())
+        if ent is not None:
+            packs += [ent[0], ent[1]]
+    if packs:
+        torch.autograd.graph.increment_version(packs)
     restamp_dw_packs(model)
     return len(srcs)
 

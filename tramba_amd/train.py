@@ -66,14 +66,18 @@ class _SodLossHIP(torch.autograd.Function):
 
 def _loss_on_device(outputs, label):
     """the library's loss takes logit maps no larger than the label, plane for plane"""
+    # (a resized output's gradient kernel holds rows of the label in LDS: labels wider than 4096 only with outputs at label size)
     return (label.is_cuda and label.dim() == 4 and 0 < len(outputs) <= 8 and label.shape[0] * label.shape[1] <= 512
             and all(o.is_cuda and o.dim() == 4 and o.shape[:2] == label.shape[:2] and o.shape[-2] <= label.shape[-2]
-                    and o.shape[-1] <= label.shape[-1] for o in outputs))
+                    and o.shape[-1] <= label.shape[-1] for o in outputs)
+            and (label.shape[-1] <= 4096 or all(o.shape[-2:] == label.shape[-2:] for o in outputs)))
 
 
 def tramba_loss(outputs, label, loss_weights=None):
     """Sum over the deep-supervision outputs (3 for Tramba-R, 4 otherwise) of BCE-with-logits + IoU."""
     outputs = list(outputs)
+    if loss_weights is not None and len(loss_weights) != len(outputs):
+        raise ValueError(f"tramba_loss: {len(loss_weights)} loss weights for {len(outputs)} outputs")
     if _loss_on_device(outputs, label):
         weights = None if loss_weights is None else tuple(float(w) for w in loss_weights)
         return _SodLossHIP.apply(label.float().contiguous(), weights, *[o.float().contiguous() for o in outputs])
@@ -116,7 +120,12 @@ class Adam(torch.optim.Adam):
         ptrs = [p.data_ptr() for p in ps]
         plan = self._plans.get(gi)
         if plan is not None and plan[0] == ptrs:
-            return plan
+            # the state entries may have been replaced behind the optimizer's back (opt.state.clear(), a hand-made restore):
+            # the plan must never keep updating orphaned tensors
+            ms, vs, steps = plan[6]
+            if all((st := self.state.get(p)) and st.get("exp_avg") is m and st.get("exp_avg_sq") is v and st.get("step") is t
+                   for p, m, v, t in zip(ps, ms, vs, steps)):
+                return plan
         ms, vs, steps = [], [], []
         for p in ps:
             if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
