@@ -726,3 +726,37 @@ def test_training_weight_shadows_follow_the_optimizer():
     assert M._lowp_t(lin.weight, torch.bfloat16) is None                           # stale: the caller transposes
     l2 = float(train.train_step(m, opt, x, y))                                      # and training goes on
     assert np.isfinite(l2)
+
+
+def test_bucket_fill_waits_for_gradients_finished_on_another_stream():
+    """With the guide branches on a side stream under autograd (models.OVERLAP_TRAINING) the gradients of ONE bucket are finished
+    on different streams, and the hook that completes the bucket runs on only one of them: the fill (and the collective behind
+    it) must wait for the others.  Emulated exactly: parameter a's gradient is written on a side stream BEHIND a device-side
+    sleep, its hook fires there; parameter b's hook completes the bucket on the main stream right after."""
+    from tramba_amd import parallel
+
+    class Two(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.zeros(4096, device=DEV))
+            self.b = torch.nn.Parameter(torch.zeros(4096, device=DEV))
+
+    m = Two()
+    red = parallel.GradBucketReducer(m, bucket_dtype=torch.bfloat16)      # (world 1, bf16 buckets: the fill path without a collective)
+    assert len(red.buckets) == 1
+    side = torch.cuda.Stream()
+    for trial in range(3):
+        red.prepare()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            g = torch.empty(4096, device=DEV)
+            torch.cuda._sleep(200_000_000)          # ~0.1 s on the device: the fill below is enqueued long before this ends
+            g.fill_(3.0 + trial)
+            m.a.grad = g
+            red._on_grad(m.a)
+        m.b.grad = torch.full((4096,), -1.0, device=DEV)
+        red._on_grad(m.b)                           # completes the bucket on the main stream
+        red.finish()
+        torch.cuda.synchronize()
+        assert float(m.a.grad.float().min()) == 3.0 + trial and float(m.a.grad.float().max()) == 3.0 + trial
+        assert float(m.b.grad.float().min()) == -1.0

@@ -97,6 +97,7 @@ class GradBucketReducer:
         if self.bucket_dtype is not None:
             self._wide = [[torch.zeros_like(p) for p in bucket] for bucket in self.buckets]
         self._pending = [0] * len(self.buckets)
+        self._streams = [set() for _ in self.buckets]
         self._handles = []
         self._have_local = {}
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._where]
@@ -119,6 +120,7 @@ class GradBucketReducer:
             self._build()
         self._handles = []
         self._have_local = {}
+        self._streams = [set() for _ in self.buckets]     # the streams the gradients of a bucket were finished on (see _flush)
         for bi, bucket in enumerate(self.buckets):
             self._pending[bi] = len(bucket)
             for p in bucket:
@@ -137,6 +139,17 @@ class GradBucketReducer:
             self._have_local[bi] = have
             return
         if bucket[0].is_cuda:
+            # The model runs the decoder's guide branches on a side stream, under autograd too (models.OVERLAP_TRAINING): the
+            # gradients of one bucket are then finished on DIFFERENT streams, and the hook that completes the bucket runs on only
+            # one of them.  The autograd engine drives a device from one thread, so everything the other streams need has been
+            # enqueued by now: an event at the tail of each of them, awaited here, orders the fill (and the collective, which
+            # ProcessGroupNCCL orders behind the current stream) after every gradient of the bucket.
+            cur = torch.cuda.current_stream(bucket[0].device)
+            for st in self._streams[bi]:
+                if st != cur:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    cur.wait_event(ev)
             # gradients whose partial sums are still pending (hip.deferred_sums() around backward) must hold their values
             # before they are copied into the bucket
             from . import hip
@@ -163,6 +176,8 @@ class GradBucketReducer:
         bi = self._where.get(p)
         if bi is None:
             return
+        if p.is_cuda:
+            self._streams[bi].add(torch.cuda.current_stream(p.device))
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._flush(bi)
