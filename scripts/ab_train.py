@@ -2,7 +2,8 @@
 """Same-box A/B of the training step (Tramba-V 384x384, batch 8, bf16, stochastic depth on; BASELINE configs[2]) between
 TRAMBA_TUNE_GEMM_TILE settings: every variant is its own model + GraphedTrainStep captured with that knob value, and the graphs
 are replayed alternately in ONE process.  usage: python scripts/ab_train.py [tune values, default: 18 0]
-A value >= 200 means: tune value - 200 with the guide branches on a side stream (models.OVERLAP_TRAINING = True, off by default)."""
+A value >= 200 means: tune value - 200 with the guide branches on a side stream under autograd (models.OVERLAP_TRAINING, the default
+since the end of round 4); a value < 200 captures the single-stream step.  (scripts/ab_knobs.py is the general form of this script.)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tramba_amd as ta
@@ -25,7 +26,7 @@ for v in vals:
             loss = st(x, y)
     finally:
         hip.tune_set(hip.TUNE_GEMM_TILE, 0)
-        models.OVERLAP_TRAINING = False
+        models.OVERLAP_TRAINING = True
     torch.cuda.synchronize()
     steps[v] = st
     print(f"tune {v}: captured, loss {float(loss):.4f}", flush=True)
