@@ -650,7 +650,7 @@ def test_dwconv_training_path_matches_autograd(dtype, cfg):
                                atol=wtol * float(cr.bias.grad.abs().max()))
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
 @pytest.mark.parametrize("cfg", [(2, 96, 96, 512, 0), (1, 48, 48, 1024, 0), (2, 24, 24, 2048, 0), (1, 13, 50, 130, 0), (3, 7, 5, 6, 0),
                                  (1, 96, 96, 128, 5), (1, 30, 22, 64, 7), (2, 24, 24, 256, 100), (2, 13, 50, 136, 0), (1, 9, 6, 8, 0)])
 def test_dwconv7_marching_kernel_is_bit_identical_to_the_row_kernel(dtype, cfg):
@@ -688,13 +688,13 @@ def test_dwconv7_marching_kernel_is_bit_identical_to_the_row_kernel(dtype, cfg):
     xn = x.double().permute(0, 3, 1, 2)
     k = wt.double().view(7, 7, c).permute(2, 0, 1).unsqueeze(1)
     want = F.conv2d(xn, k, bt.double(), padding=3, groups=c).permute(0, 2, 3, 1)
-    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    tol = 1e-5 if dtype == torch.float32 else (4e-3 if dtype == torch.float16 else 3e-2)
     np.testing.assert_allclose(new[1].cpu().double().numpy(), want.cpu().numpy(), rtol=tol, atol=tol)
     wantf = F.conv2d(xn, k.flip(2, 3), bt.double(), padding=3, groups=c).permute(0, 2, 3, 1)
     np.testing.assert_allclose(new[4].cpu().double().numpy(), wantf.cpu().numpy(), rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
 @pytest.mark.parametrize("cfg", [(2, 96, 96, 256, 0), (2, 48, 48, 512, 0), (2, 24, 24, 1024, 0), (1, 13, 50, 130, 0), (3, 7, 5, 6, 0),
                                  (1, 40, 36, 64, 5), (1, 30, 100, 64, 7), (2, 24, 24, 128, 100), (2, 13, 50, 136, 0), (1, 9, 6, 8, 0)])
 def test_dwconv7_marching_weight_gradient(dtype, cfg):
