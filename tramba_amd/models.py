@@ -68,6 +68,7 @@ class _StreamEdge(torch.autograd.Function):
 
 _DEBUG_STREAMS = None
 _OVERLAP_TRAINING_STAGES = None
+_OVERLAP_INFER_STAGES = None      # (the same for the inference forward: scripts/dev/ab_overlap_stages.py)
 
 
 def _bias_scalar(conv: nn.Conv2d) -> float:
@@ -225,7 +226,8 @@ class BaseUMamba(nn.Module):
             s = n - 2 - i
             if s < 0 or s >= len(dec.guide_layers):
                 return
-            if torch.is_grad_enabled() and _OVERLAP_TRAINING_STAGES is not None and s not in _OVERLAP_TRAINING_STAGES:
+            if (torch.is_grad_enabled() and _OVERLAP_TRAINING_STAGES is not None and s not in _OVERLAP_TRAINING_STAGES) or (
+                    not torch.is_grad_enabled() and _OVERLAP_INFER_STAGES is not None and s not in _OVERLAP_INFER_STAGES):
                 return                  # (debugging aid of scripts/dev/debug_overlap2.py: only these guide branches fork)
             side.wait_stream(main)
             feat.record_stream(side)
